@@ -1,0 +1,10 @@
+"""pixelwiseregression_amd -- MI355X-native hot path of IcarusWizard/PixelwiseRegression.
+
+Public surface mirrors the reference's ``model.py`` / ``utils.py`` names for the hot path:
+``PixelwiseRegression`` (model.py:154), ``recover_uvd`` (utils.py:332), ``uvd2xyz``
+(datasets.py:100), ``save_model`` / ``load_model`` (utils.py:302-314).
+"""
+from .model import PixelwiseRegression  # noqa: F401
+from .metric import recover_uvd, uvd2xyz, mean_joint_error, INTRINSICS  # noqa: F401
+
+__all__ = ["PixelwiseRegression", "recover_uvd", "uvd2xyz", "mean_joint_error", "INTRINSICS"]

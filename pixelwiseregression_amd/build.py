@@ -1,0 +1,76 @@
+"""In-tree build of libpwr_hip.so (gfx950) with hipcc.  No torch C++ ABI involved: the library is a
+plain C ABI (include/pwr.h) loaded with ctypes, which side-steps the hipcc 7.2 / torch-HIP 7.0 skew.
+
+    python -m pixelwiseregression_amd.build [--force]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libpwr_hip.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+         "-Wno-unused-result", "-ffp-contract=off"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "pwr.h"))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    jobs = []
+    for src in _sources():
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src + ".o")
+        stamp = op + ".sha"
+        dig = _digest([sp] + headers)
+        if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        jobs.append((sp, op, stamp, dig))
+
+    def run(job):
+        sp, op, stamp, dig = job
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", sp, "-o", op]
+        if verbose:
+            print("[pwr build]", os.path.basename(sp), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (sp, r.stdout, r.stderr))
+        with open(stamp, "w") as f:
+            f.write(dig)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s + ".o") for s in _sources()]
+    if jobs or not os.path.exists(LIB) or force:
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[pwr build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

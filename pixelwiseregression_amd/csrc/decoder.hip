@@ -1,0 +1,351 @@
+// Soft-argmax decoder, forward + backward, for gfx950 (wave64).
+//
+// Replaces the ~12 ATen ops of /root/reference/model.py:79-97 (PlaneRegression.forward after the
+// conv head) and model.py:123-132 (DepthRegression.forward after the conv head) with one kernel
+// per direction.  One workgroup owns one (b, j) map of N = P*P pixels:
+//
+//   forward   p = softmax_i(w_j * z_i)            | p = (relu(z)+1e-14)/sum        model.py:83-90
+//             u = sum p*gx, v = sum p*gy          gx = (col-P/2)/(P-1), gy = (row-P/2)/(P-1)
+//             d = sum (p*m)*(m*(D+L)) / (sum p*m + 1e-14)                          model.py:123-129
+//   backward  closed form of what autograd derives for those lines (SURVEY.md 8 a-D).
+//
+// Memory plan (HBM bound): every [B,J,P,P] operand is read exactly once with 16-byte coalesced
+// loads and kept in registers between the reduction and the element-wise tail; L and m
+// ([B,1,P,P]) are shared by the J maps of a sample and are served by L2.  Algorithmic traffic:
+// forward 12 B/pixel/map (z, D in; p out), backward 28 B (p, z, D, gH, gD in; gz, gD out).
+#include "pwr_common.h"
+
+namespace pwr {
+
+#define PWR_DEC_EPS 1e-14f
+
+__device__ __forceinline__ float grid_coord(int idx, int P) {
+  // utils.py:28-34 rounded to fp32 (model.py:68): (idx - P//2)/(P-1), correctly rounded divide
+  return __fdiv_rn((float)(idx - (P >> 1)), (float)(P - 1));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident path: N == NT*NV*4, P % 4 == 0 and (NT*4) % P == 0, so a thread's four
+// columns are the same for all of its NV vectors.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void decode_fwd_cached(const float* __restrict__ z, const float* __restrict__ D,
+                                                        const float* __restrict__ L, const float* __restrict__ m,
+                                                        const float* __restrict__ w, float* __restrict__ p_out,
+                                                        float* __restrict__ uvd, int J, int P, int method) {
+  constexpr int NW = NT / 64;
+  __shared__ float red[8 * NW];
+  const int map = blockIdx.x, b = map / J, j = map - b * J;
+  const int N = P * P;
+  const size_t mo = (size_t)map * N, bo = (size_t)b * N;
+  const int tid = threadIdx.x;
+  const int col0 = (tid * 4) % P;
+  const int rows_per_step = (NT * 4) / P;
+  const int row0 = (tid * 4) / P;
+
+  f32x4 e[NV];
+  float mx = -INFINITY;
+  const float wj = (method == 0) ? w[j] : 1.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    e[k] = *reinterpret_cast<const f32x4*>(z + mo + (size_t)(k * NT + tid) * 4);
+    if (method == 0) {
+      e[k] *= wj;
+      mx = fmaxf(mx, fmaxf(fmaxf(e[k].x, e[k].y), fmaxf(e[k].z, e[k].w)));
+    }
+  }
+  if (method == 0) mx = block_max<NW>(mx, red);
+
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};  // per-column sums of e
+  float sv = 0.f, sm = 0.f, sd = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const size_t off = (size_t)(k * NT + tid) * 4;
+    f32x4 dv = *reinterpret_cast<const f32x4*>(D + mo + off);
+    f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
+    f32x4 ev;
+    if (method == 0) {
+      ev.x = expf(e[k].x - mx); ev.y = expf(e[k].y - mx); ev.z = expf(e[k].z - mx); ev.w = expf(e[k].w - mx);
+    } else {
+      ev.x = fmaxf(e[k].x, 0.f) + PWR_DEC_EPS; ev.y = fmaxf(e[k].y, 0.f) + PWR_DEC_EPS;
+      ev.z = fmaxf(e[k].z, 0.f) + PWR_DEC_EPS; ev.w = fmaxf(e[k].w, 0.f) + PWR_DEC_EPS;
+    }
+    e[k] = ev;
+    cs[0] += ev.x; cs[1] += ev.y; cs[2] += ev.z; cs[3] += ev.w;
+    const float gy = grid_coord(row0 + k * rows_per_step, P);
+    sv += gy * ((ev.x + ev.y) + (ev.z + ev.w));
+    f32x4 em = ev * mv;              // p*m (unnormalised)
+    f32x4 mr = mv * (dv + lv);       // m*(D+L)
+    sm += (em.x + em.y) + (em.z + em.w);
+    sd += (em.x * mr.x + em.y * mr.y) + (em.z * mr.z + em.w * mr.w);
+  }
+  float r[5];
+  r[0] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
+  r[1] = (cs[0] * grid_coord(col0, P) + cs[1] * grid_coord(col0 + 1, P)) +
+         (cs[2] * grid_coord(col0 + 2, P) + cs[3] * grid_coord(col0 + 3, P));
+  r[2] = sv; r[3] = sm; r[4] = sd;
+  block_sum<5, NW>(r, red);
+  const float inv = __fdiv_rn(1.f, r[0]);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    f32x4 pv;
+    pv.x = __fdiv_rn(e[k].x, r[0]); pv.y = __fdiv_rn(e[k].y, r[0]);
+    pv.z = __fdiv_rn(e[k].z, r[0]); pv.w = __fdiv_rn(e[k].w, r[0]);
+    *reinterpret_cast<f32x4*>(p_out + mo + (size_t)(k * NT + tid) * 4) = pv;
+  }
+  if (tid == 0) {
+    uvd[(size_t)map * 3 + 0] = r[1] * inv;
+    uvd[(size_t)map * 3 + 1] = r[2] * inv;
+    uvd[(size_t)map * 3 + 2] = __fdiv_rn(r[4] * inv, r[3] * inv + PWR_DEC_EPS);
+  }
+}
+
+// Generic path: any P; three passes over the map (re-reads come from L2).
+template <int NT>
+__global__ __launch_bounds__(NT) void decode_fwd_generic(const float* __restrict__ z, const float* __restrict__ D,
+                                                         const float* __restrict__ L, const float* __restrict__ m,
+                                                         const float* __restrict__ w, float* __restrict__ p_out,
+                                                         float* __restrict__ uvd, int J, int P, int method) {
+  constexpr int NW = NT / 64;
+  __shared__ float red[8 * NW];
+  const int map = blockIdx.x, b = map / J, j = map - b * J;
+  const int N = P * P;
+  const size_t mo = (size_t)map * N, bo = (size_t)b * N;
+  const int tid = threadIdx.x;
+  const float wj = (method == 0) ? w[j] : 1.f;
+  float mx = -INFINITY;
+  if (method == 0) {
+    for (int i = tid; i < N; i += NT) mx = fmaxf(mx, wj * z[mo + i]);
+    mx = block_max<NW>(mx, red);
+  }
+  float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < N; i += NT) {
+    const float zz = z[mo + i];
+    const float ev = (method == 0) ? expf(wj * zz - mx) : fmaxf(zz, 0.f) + PWR_DEC_EPS;
+    const int row = i / P, col = i - row * P;
+    const float mv = m[bo + i];
+    const float em = ev * mv;
+    r[0] += ev;
+    r[1] += ev * grid_coord(col, P);
+    r[2] += ev * grid_coord(row, P);
+    r[3] += em;
+    r[4] += em * (mv * (D[mo + i] + L[bo + i]));
+  }
+  block_sum<5, NW>(r, red);
+  for (int i = tid; i < N; i += NT) {
+    const float zz = z[mo + i];
+    const float ev = (method == 0) ? expf(wj * zz - mx) : fmaxf(zz, 0.f) + PWR_DEC_EPS;
+    p_out[mo + i] = __fdiv_rn(ev, r[0]);
+  }
+  if (tid == 0) {
+    const float inv = __fdiv_rn(1.f, r[0]);
+    uvd[(size_t)map * 3 + 0] = r[1] * inv;
+    uvd[(size_t)map * 3 + 1] = r[2] * inv;
+    uvd[(size_t)map * 3 + 2] = __fdiv_rn(r[4] * inv, r[3] * inv + PWR_DEC_EPS);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward.  With S = sum p*m + 1e-14 and d = uvd[..,2]:
+//   g_p = gH + gu*gx + gv*gy + gd*m*(m*(D+L) - d)/S
+//   softmax: g_z = w * p * (g_p - sum p*g_p);  g_w[j] += sum_i (g_z/w ... ) = A2 - A1*A3
+//            with A1 = sum p*g_p, A2 = sum p*g_p*z, A3 = sum p*z
+//   sum:     g_z = (g_p - A1)/T * [z>0],  T = sum (relu(z)+1e-14)
+//   g_D = gD_in + gd * p * m*m / S
+// gH / gD_in may be null (treated as zeros).  gw_part is [B*J] (reduced over b by decode_gw_reduce).
+// ---------------------------------------------------------------------------------------------
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void decode_bwd_cached(const float* __restrict__ p, const float* __restrict__ z,
+                                                        const float* __restrict__ D, const float* __restrict__ L,
+                                                        const float* __restrict__ m, const float* __restrict__ w,
+                                                        const float* __restrict__ uvd, const float* __restrict__ gH,
+                                                        const float* __restrict__ gDin, const float* __restrict__ gU,
+                                                        float* __restrict__ gz, float* __restrict__ gDout,
+                                                        float* __restrict__ gw_part, int J, int P, int method) {
+  constexpr int NW = NT / 64;
+  __shared__ float red[8 * NW];
+  const int map = blockIdx.x, b = map / J, j = map - b * J;
+  const int N = P * P;
+  const size_t mo = (size_t)map * N, bo = (size_t)b * N;
+  const int tid = threadIdx.x;
+  const int col0 = (tid * 4) % P;
+  const int rows_per_step = (NT * 4) / P;
+  const int row0 = (tid * 4) / P;
+  const float gu = gU[(size_t)map * 3 + 0], gv = gU[(size_t)map * 3 + 1], gd = gU[(size_t)map * 3 + 2];
+  const float d = uvd[(size_t)map * 3 + 2];
+  const float wj = (method == 0) ? w[j] : 1.f;
+
+  f32x4 pv[NV], gp[NV], pm2[NV];
+  float r1[2] = {0.f, 0.f};  // S (without eps), T (sum method)
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const size_t off = (size_t)(k * NT + tid) * 4;
+    pv[k] = *reinterpret_cast<const f32x4*>(p + mo + off);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
+    f32x4 pmv = pv[k] * mv;
+    pm2[k] = pmv * mv;
+    r1[0] += (pmv.x + pmv.y) + (pmv.z + pmv.w);
+  }
+  if (method != 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      f32x4 zv = *reinterpret_cast<const f32x4*>(z + mo + (size_t)(k * NT + tid) * 4);
+      r1[1] += (fmaxf(zv.x, 0.f) + PWR_DEC_EPS) + (fmaxf(zv.y, 0.f) + PWR_DEC_EPS) +
+               (fmaxf(zv.z, 0.f) + PWR_DEC_EPS) + (fmaxf(zv.w, 0.f) + PWR_DEC_EPS);
+    }
+  }
+  block_sum<2, NW>(r1, red);
+  const float S = r1[0] + PWR_DEC_EPS;
+  const float gdS = __fdiv_rn(gd, S);
+  const float gxc[4] = {gu * grid_coord(col0, P), gu * grid_coord(col0 + 1, P), gu * grid_coord(col0 + 2, P),
+                        gu * grid_coord(col0 + 3, P)};
+  float r2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const size_t off = (size_t)(k * NT + tid) * 4;
+    f32x4 dv = *reinterpret_cast<const f32x4*>(D + mo + off);
+    f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
+    f32x4 zv = *reinterpret_cast<const f32x4*>(z + mo + off);
+    f32x4 g;
+    const float gyv = gv * grid_coord(row0 + k * rows_per_step, P);
+    g.x = gxc[0] + gyv + gdS * mv.x * (mv.x * (dv.x + lv.x) - d);
+    g.y = gxc[1] + gyv + gdS * mv.y * (mv.y * (dv.y + lv.y) - d);
+    g.z = gxc[2] + gyv + gdS * mv.z * (mv.z * (dv.z + lv.z) - d);
+    g.w = gxc[3] + gyv + gdS * mv.w * (mv.w * (dv.w + lv.w) - d);
+    if (gH) g += *reinterpret_cast<const f32x4*>(gH + mo + off);
+    gp[k] = g;
+    f32x4 pg = pv[k] * g;
+    r2[0] += (pg.x + pg.y) + (pg.z + pg.w);
+    r2[1] += (pg.x * zv.x + pg.y * zv.y) + (pg.z * zv.z + pg.w * zv.w);
+    r2[2] += (pv[k].x * zv.x + pv[k].y * zv.y) + (pv[k].z * zv.z + pv[k].w * zv.w);
+    if (method != 0) {  // keep the relu mask in pm-free form: store sign in gp via separate pass below
+      // sum-normalisation: g_z = (g_p - A1)/T * [z>0]; remember [z>0] by zeroing p where z<=0 later
+      f32x4 msk;
+      msk.x = zv.x > 0.f ? 1.f : 0.f; msk.y = zv.y > 0.f ? 1.f : 0.f;
+      msk.z = zv.z > 0.f ? 1.f : 0.f; msk.w = zv.w > 0.f ? 1.f : 0.f;
+      // A1 must use the true p, so the mask is folded into pv only after the products above
+      pv[k] = msk;  // pv now carries the relu mask (p itself no longer needed except via pm2)
+    }
+  }
+  block_sum<3, NW>(r2, red);
+  const float A1 = r2[0];
+  const float invT = (method != 0) ? __fdiv_rn(1.f, r1[1]) : 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const size_t off = (size_t)(k * NT + tid) * 4;
+    f32x4 gzv;
+    if (method == 0) gzv = wj * (pv[k] * (gp[k] - A1));
+    else gzv = pv[k] * ((gp[k] - A1) * invT);
+    *reinterpret_cast<f32x4*>(gz + mo + off) = gzv;
+    f32x4 gdv = gdS * pm2[k];
+    if (gDin) gdv += *reinterpret_cast<const f32x4*>(gDin + mo + off);
+    *reinterpret_cast<f32x4*>(gDout + mo + off) = gdv;
+  }
+  if (tid == 0 && gw_part) gw_part[map] = (method == 0) ? (r2[1] - A1 * r2[2]) : 0.f;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void decode_bwd_generic(const float* __restrict__ p, const float* __restrict__ z,
+                                                         const float* __restrict__ D, const float* __restrict__ L,
+                                                         const float* __restrict__ m, const float* __restrict__ w,
+                                                         const float* __restrict__ uvd, const float* __restrict__ gH,
+                                                         const float* __restrict__ gDin, const float* __restrict__ gU,
+                                                         float* __restrict__ gz, float* __restrict__ gDout,
+                                                         float* __restrict__ gw_part, int J, int P, int method) {
+  constexpr int NW = NT / 64;
+  __shared__ float red[8 * NW];
+  const int map = blockIdx.x, b = map / J, j = map - b * J;
+  const int N = P * P;
+  const size_t mo = (size_t)map * N, bo = (size_t)b * N;
+  const int tid = threadIdx.x;
+  const float gu = gU[(size_t)map * 3 + 0], gv = gU[(size_t)map * 3 + 1], gd = gU[(size_t)map * 3 + 2];
+  const float d = uvd[(size_t)map * 3 + 2];
+  const float wj = (method == 0) ? w[j] : 1.f;
+  float r1[2] = {0.f, 0.f};
+  for (int i = tid; i < N; i += NT) {
+    r1[0] += p[mo + i] * m[bo + i];
+    if (method != 0) r1[1] += fmaxf(z[mo + i], 0.f) + PWR_DEC_EPS;
+  }
+  block_sum<2, NW>(r1, red);
+  const float S = r1[0] + PWR_DEC_EPS;
+  const float gdS = __fdiv_rn(gd, S);
+  float r2[3] = {0.f, 0.f, 0.f};
+  for (int i = tid; i < N; i += NT) {
+    const int row = i / P, col = i - row * P;
+    const float mv = m[bo + i], pp = p[mo + i], zz = z[mo + i];
+    float g = gu * grid_coord(col, P) + gv * grid_coord(row, P) + gdS * mv * (mv * (D[mo + i] + L[bo + i]) - d);
+    if (gH) g += gH[mo + i];
+    r2[0] += pp * g; r2[1] += pp * g * zz; r2[2] += pp * zz;
+  }
+  block_sum<3, NW>(r2, red);
+  const float A1 = r2[0];
+  const float invT = (method != 0) ? __fdiv_rn(1.f, r1[1]) : 0.f;
+  for (int i = tid; i < N; i += NT) {
+    const int row = i / P, col = i - row * P;
+    const float mv = m[bo + i], pp = p[mo + i], zz = z[mo + i];
+    float g = gu * grid_coord(col, P) + gv * grid_coord(row, P) + gdS * mv * (mv * (D[mo + i] + L[bo + i]) - d);
+    if (gH) g += gH[mo + i];
+    gz[mo + i] = (method == 0) ? wj * (pp * (g - A1)) : (zz > 0.f ? (g - A1) * invT : 0.f);
+    float gdv = gdS * pp * mv * mv;
+    if (gDin) gdv += gDin[mo + i];
+    gDout[mo + i] = gdv;
+  }
+  if (tid == 0 && gw_part) gw_part[map] = (method == 0) ? (r2[1] - A1 * r2[2]) : 0.f;
+}
+
+// gw[j] (+)= sum_b gw_part[b*J + j]   (deterministic order)
+__global__ void decode_gw_reduce(const float* __restrict__ gw_part, float* __restrict__ gw, int B, int J,
+                                 int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += gw_part[(size_t)b * J + j];
+  gw[j] = accumulate ? gw[j] + s : s;
+}
+
+}  // namespace pwr
+
+// ---------------------------------------------------------------------------------------------
+// C ABI (declared in include/pwr.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, const float* m, const float* w,
+                              float* p_out, float* uvd_out, int B, int J, int P, int method, void* stream) {
+  if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = P * P, maps = B * J;
+  if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  else
+    hipLaunchKernelGGL((pwr::decode_fwd_generic<256>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, const float* L, const float* m,
+                              const float* w, const float* uvd, const float* gH, const float* gD_in,
+                              const float* gU, float* gz_out, float* gD_out, float* gw_part, int B, int J, int P,
+                              int method, void* stream) {
+  if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = P * P, maps = B * J;
+  if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  else
+    hipLaunchKernelGGL((pwr::decode_bwd_generic<256>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_decode_gw_reduce(const float* gw_part, float* gw, int B, int J, int accumulate, void* stream) {
+  hipLaunchKernelGGL(pwr::decode_gw_reduce, dim3((J + 63) / 64), dim3(64), 0, (hipStream_t)stream, gw_part, gw, B, J,
+                     accumulate);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,207 @@
+"""Drop-in boundary: ``PixelwiseRegression`` with the reference's constructor, forward signature and
+state_dict layout (/root/reference/model.py:154-210), computed by the
+MI355X-native engine (HIP kernels behind include/pwr.h).
+
+    from pixelwiseregression_amd import PixelwiseRegression
+    model = PixelwiseRegression(joints, stage=2, label_size=64, features=128, level=4,
+                                norm_method='instance', heatmap_method='softmax').to('cuda')
+    results = model(img, label_img, mask)     # list[(heatmaps, depthmaps, uvd)], len = stage
+
+Differences a caller can observe (all additive):
+  * parameters are views into one flat fp32 buffer (one fused optimizer / one RCCL all-reduce);
+  * ``model.set_precision('bf16' | 'fp32')`` picks the MFMA input type (fp32 = exact f32 MFMA,
+    parity mode; bf16 = the training configuration of BASELINE.json); under ``torch.autocast``
+    the engine uses bf16;
+  * the module refuses to run on the CPU: there is no fallback path.
+"""
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+
+class _Node(nn.Module):
+    """Pure namespace: holds Parameters / buffers / child nodes so that state_dict keys equal the
+    attribute paths of the reference's module tree.  Never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("namespace node")
+
+
+def com_grid(P):
+    """[2,P,P] fp32 expectation grid (utils.py:24-35, model.py:67-71)."""
+    ax = (np.arange(P, dtype=np.float64) - (P // 2)) / (P - 1)
+    g = np.stack([np.broadcast_to(ax[None, :], (P, P)), np.broadcast_to(ax[:, None], (P, P))])
+    return torch.from_numpy(np.ascontiguousarray(g)).float()
+
+
+class _Builder:
+    """Creates parameters in the reference's construction order so that (a) state_dict order and
+    names match and (b) the same torch seed yields the same initial weights as the reference."""
+
+    def __init__(self, norm_method):
+        if norm_method not in ("batch", "instance"):
+            # the reference dies with UnboundLocalError on `norm` (model.py:157-160)
+            raise UnboundLocalError("local variable 'norm' referenced before assignment")
+        self.norm_method = norm_method
+        self.convs = []      # (node) in creation order, for the xavier pass
+        self.layers = []     # flat description used by the engine: dicts
+
+    def conv(self, cin, cout, k):
+        n = _Node()
+        n.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        n.bias = nn.Parameter(torch.empty(cout))
+        # torch.nn.Conv2d.reset_parameters
+        nn.init.kaiming_uniform_(n.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(cin * k * k)
+        nn.init.uniform_(n.bias, -bound, bound)
+        self.convs.append(n)
+        return n
+
+    def norm(self, c):
+        n = _Node()
+        n.weight = nn.Parameter(torch.ones(c))
+        n.bias = nn.Parameter(torch.zeros(c))
+        if self.norm_method == "batch":
+            n.register_buffer("running_mean", torch.zeros(c))
+            n.register_buffer("running_var", torch.ones(c))
+            n.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        return n
+
+    def seq(self, items):
+        """items: list of (index, node)."""
+        n = _Node()
+        for i, c in items:
+            n.add_module(str(i), c)
+        return n
+
+    def resblock(self, F, k):
+        # model.py:10-20: indices 0 norm, 2 conv1x1, 3 norm, 5 conv kxk, 6 norm, 8 conv1x1
+        n = _Node()
+        n.conv = self.seq([(0, self.norm(F)), (2, self.conv(F, F // 2, 1)), (3, self.norm(F // 2)),
+                           (5, self.conv(F // 2, F // 2, k)), (6, self.norm(F // 2)), (8, self.conv(F // 2, F, 1))])
+        return n
+
+    def hourglass(self, F, level, k):
+        n = _Node()
+        n.input_conv = self.resblock(F, k)
+        n.inner = self.hourglass(F, level - 1, k) if level > 0 else self.resblock(F, k)
+        n.output_conv = self.resblock(F, k)
+        return n
+
+    def head(self, F, J, k):
+        return self.seq([(0, self.conv(F, F, k)), (1, self.norm(F)), (3, self.conv(F, F, k)), (4, self.norm(F)),
+                         (6, self.conv(F, F, k)), (7, self.norm(F)), (9, self.conv(F, J, k))])
+
+    def xavier(self):
+        for n in self.convs:           # utils.py:339-342 via self.apply (model.py:198)
+            nn.init.xavier_normal_(n.weight.data)
+
+
+class PixelwiseRegression(nn.Module):
+    def __init__(self, joints, stage=2, label_size=64, features=256, level=4, kernel_size=3, norm_method='batch',
+                 heatmap_method='softmax'):
+        super().__init__()
+        self.joints, self.stage, self.label_size = int(joints), int(stage), int(label_size)
+        self.features, self.level, self.kernel_size = int(features), int(level), int(kernel_size)
+        self.norm_method, self.heatmap_method = norm_method, heatmap_method
+        b = _Builder(norm_method)
+        F_, J, k = self.features, self.joints, self.kernel_size
+        # ---- stem (model.py:164-187)
+        items, idx, c = [(0, b.conv(1, 32, k)), (1, b.norm(32))], 3, 32
+        while c < F_:
+            nxt = min(2 * c, F_)
+            items += [(idx, b.conv(c, nxt, k)), (idx + 1, b.norm(nxt))]
+            idx, c = idx + 3, nxt
+        items += [(idx, b.conv(F_, F_, k)), (idx + 1, b.norm(F_))]
+        self.conv = b.seq(items)
+        self.n_stem = len(items) // 2
+        # ---- stages (model.py:189-196)
+        stages = []
+        for s in range(self.stage):
+            blk = _Node()
+            blk.conv = b.conv(F_ if s == 0 else 2 * J + 1, F_, 1)
+            blk.hourglass = b.hourglass(F_, self.level, 3)       # model.py:139: kernel_size not forwarded
+            pr = _Node()
+            pr.conv = b.head(F_, J, k)
+            pr.register_buffer("filter", com_grid(self.label_size))
+            if heatmap_method == 'softmax':
+                pr.register_parameter("w", nn.Parameter(torch.ones(J, 1)))
+            blk.plane_regression = pr
+            dr = _Node()
+            dr.conv = b.head(F_, J, k)
+            blk.depth_regression = dr
+            stages.append(blk)
+        self.stages = nn.ModuleList(stages)
+        b.xavier()
+        self._precision = os.environ.get("PWR_PRECISION", "fp32")
+        self._backend = os.environ.get("PWR_BACKEND", "hip")
+        self._flat = None
+        self._flat_grad = None
+        self._engine = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _flatten(self):
+        """(Re)pack all parameters into one contiguous fp32 buffer and make them views of it."""
+        params = [p for _, p in self.named_parameters()]
+        if not params:
+            return
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        self._offsets = OrderedDict()
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = None
+                self._offsets[name] = (off, tuple(p.shape))
+                off += n
+        self._flat = flat
+        self._flat_grad = None
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._flatten()
+        return r
+
+    def flat_parameters(self):
+        return self._flat
+
+    def flat_grad(self):
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def set_precision(self, precision):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._precision = precision
+        return self
+
+    def set_backend(self, backend):
+        """'hip' (default, the product) or 'aten' (PyTorch-ROCm library ops; A/B and debugging only --
+        it still needs a GPU and still uses the HIP decoder)."""
+        if backend not in ("hip", "aten"):
+            raise ValueError(backend)
+        self._backend = backend
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img, label_img, mask):
+        if not img.is_cuda:
+            from ._lib import PwrError
+            raise PwrError("PixelwiseRegression (MI355X build) runs on the GPU only; move the module and the "
+                           "inputs to 'cuda'. There is no CPU fallback.")
+        if self._backend == "aten":
+            from ._aten_backend import aten_forward
+            return aten_forward(self, img, label_img, mask)
+        from .engine import engine_forward
+        return engine_forward(self, img, label_img, mask)

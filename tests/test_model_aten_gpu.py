@@ -1,0 +1,36 @@
+"""GPU: the A/B 'aten' backend (PyTorch-ROCm conv stack + HIP decoder) against the reference's golden
+vectors.  This pins the boundary wiring (state_dict -> forward) independently of the native conv engine."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["tiny_instance_softmax.npz", "tiny_instance_sum.npz", "tiny_batch_softmax.npz"])
+def test_aten_backend_tiny_golden(golden_dir, name):
+    from pixelwiseregression_amd import PixelwiseRegression
+    g = np.load(os.path.join(golden_dir, name))
+    dev = torch.device("cuda:0")
+    m = PixelwiseRegression(int(g["cfg_joints"]), stage=int(g["cfg_stage"]), label_size=int(g["cfg_label_size"]),
+                            features=int(g["cfg_features"]), level=int(g["cfg_level"]), kernel_size=int(g["cfg_kernel_size"]),
+                            norm_method=str(g["cfg_norm_method"]), heatmap_method=str(g["cfg_heatmap_method"]))
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
+    m = m.to(dev).set_backend("aten")
+    batch = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    res = m(batch["img"], batch["label_img"], batch["mask"])
+    loss = 0
+    for s, (p, D, uvd) in enumerate(res):
+        np.testing.assert_allclose(uvd.detach().cpu().numpy(), g["a100_s%d_uvd" % s], atol=1e-4)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g["a100_s%d_p" % s], atol=1e-4)
+        loss = loss + torch.mean(torch.sum((uvd - batch["uvd"]) ** 2, dim=2))
+    loss.backward()
+    assert abs(loss.item() - float(g["a100_loss"])) < 1e-4
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = g["a100_grad_" + k]
+        got = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        worst = max(worst, float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())))
+    assert worst < 2e-4, worst

@@ -1,0 +1,131 @@
+"""CPU: the oracle (oracle/*.py) against vectors produced by the reference itself.
+
+These are the pins that make the oracle trustworthy; the GPU parity tests then compare the HIP
+path with the oracle / the same vectors.  Tolerances: fp64 vectors 1e-12, fp32 vectors 2e-6
+(different summation order than ATen), full model 1e-4 (BASELINE.json north_star).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref, metric_ref, model_ref
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("method", ["softmax", "sum"])
+@pytest.mark.parametrize("P", [16, 64])
+def test_grid_bits(golden_dir, method, P):
+    g = _load(golden_dir, "decoder_%s_P%d.npz" % (method, P))
+    assert np.array_equal(decoder_ref.com_grid(P, np.float32), g["grid"])
+
+
+@pytest.mark.parametrize("method", ["softmax", "sum"])
+@pytest.mark.parametrize("P", [16, 64])
+@pytest.mark.parametrize("mask", ["bin", "soft"])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_decoder_oracle_vs_reference(golden_dir, method, P, mask, prec):
+    g = _load(golden_dir, "decoder_%s_P%d.npz" % (method, P))
+    dt = np.float64 if prec == "f64" else np.float32
+    tol = 1e-12 if prec == "f64" else 2e-6
+    m = g["m_" + mask]
+    key = "%s_%s_" % (prec, mask)
+    p, uvd = decoder_ref.decode_forward(g["z"], g["D"], g["L"], m, g["w"], method, dtype=dt)
+    np.testing.assert_allclose(p, g[key + "p"], rtol=0, atol=tol)
+    np.testing.assert_allclose(uvd, g[key + "uvd"], rtol=0, atol=tol * 10)
+    gz, gD, gw = decoder_ref.decode_backward(g["z"], g["D"], g["L"], m, g["w"], g["gH"], g["gD"], g["gU"],
+                                             method, dtype=dt)
+    scale = 1e3 if prec == "f32" else 1.0   # fp32 grads: atol on values O(1..10)
+    np.testing.assert_allclose(gz, g[key + "gz"], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(gD, g[key + "gD"], rtol=0, atol=tol * scale)
+    if method == "softmax":
+        np.testing.assert_allclose(gw, g[key + "gw"], rtol=0, atol=tol * scale * 10)
+
+
+def _tiny(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = model_ref.RefConfig(int(g["cfg_joints"]), int(g["cfg_stage"]), int(g["cfg_label_size"]),
+                              int(g["cfg_features"]), int(g["cfg_level"]), int(g["cfg_kernel_size"]),
+                              str(g["cfg_norm_method"]), str(g["cfg_heatmap_method"]))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    batch = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    return g, cfg, sd, batch
+
+
+@pytest.mark.parametrize("name", ["tiny_instance_softmax.npz", "tiny_instance_sum.npz", "tiny_batch_softmax.npz"])
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_model_oracle_vs_reference(golden_dir, name, alpha):
+    g, cfg, sd, batch = _tiny(golden_dir, name)
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "filter" not in k)
+              for k, v in sd.items()}
+    bu = {}
+    res = model_ref.forward(params, cfg, batch["img"], batch["label_img"], batch["mask"], training=True,
+                            bn_updates=bu)
+    tag = "a%03d_" % int(alpha * 100)
+    for s, (p, D, uvd) in enumerate(res):
+        np.testing.assert_allclose(p.detach().numpy(), g[tag + "s%d_p" % s], atol=1e-5)
+        np.testing.assert_allclose(D.detach().numpy(), g[tag + "s%d_D" % s], atol=1e-4)
+        np.testing.assert_allclose(uvd.detach().numpy(), g[tag + "s%d_uvd" % s], atol=1e-5)
+    loss = model_ref.train_loss(res, batch["uvd"], batch["heatmaps"], batch["depthmaps"], alpha=alpha)
+    assert abs(loss.item() - float(g[tag + "loss"])) < 1e-5
+    loss.backward()
+    n = 0
+    for k, v in params.items():
+        if not v.requires_grad:
+            continue
+        ref = g[tag + "grad_" + k]
+        got = v.grad.numpy() if v.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+        n += 1
+    assert n > 50
+    if cfg.norm_method == "batch" and alpha == 1.0:
+        for prefix, (rm, rv) in bu.items():
+            np.testing.assert_allclose(rm.numpy(), g["after_" + prefix + ".running_mean"], atol=1e-6)
+            np.testing.assert_allclose(rv.numpy(), g["after_" + prefix + ".running_var"], atol=1e-5)
+
+
+def test_model_oracle_eval_batchnorm(golden_dir):
+    g, cfg, sd, batch = _tiny(golden_dir, "tiny_batch_softmax.npz")
+    with torch.no_grad():
+        res = model_ref.forward(sd, cfg, batch["img"], batch["label_img"], batch["mask"], training=False)
+    for s, (p, D, uvd) in enumerate(res):
+        np.testing.assert_allclose(uvd.numpy(), g["eval_s%d_uvd" % s], atol=1e-5)
+        np.testing.assert_allclose(p.numpy(), g["eval_s%d_p" % s], atol=1e-5)
+
+
+def test_c1_full_size_forward(golden_dir):
+    """BASELINE config C1: ICVL 16-joint, 128x128, batch 1, forward+decode on the CPU."""
+    from weights_util import fill_state_dict
+    g = _load(golden_dir, "c1_full.npz")
+    cfg = model_ref.RefConfig(16, 2, 64, 128, 4, 3, "instance", "softmax")
+    shapes = {}
+    # shapes come from the build's own module (its state_dict contract is tested elsewhere)
+    from pixelwiseregression_amd.model import PixelwiseRegression
+    m = PixelwiseRegression(16, stage=2, label_size=64, features=128, level=4, kernel_size=3,
+                            norm_method="instance", heatmap_method="softmax")
+    sd = fill_state_dict(m.state_dict(), seed=int(g["weights_seed"]))
+    with torch.no_grad():
+        res = model_ref.forward(sd, cfg, torch.from_numpy(g["in_img"]), torch.from_numpy(g["in_label_img"]),
+                                torch.from_numpy(g["in_mask"]), training=False)
+    for s, (p, D, uvd) in enumerate(res):
+        np.testing.assert_allclose(uvd.numpy(), g["s%d_uvd" % s], atol=1e-4)
+        np.testing.assert_allclose(p.numpy()[:, :, ::8, ::8], g["s%d_p_sample" % s], atol=1e-5)
+        np.testing.assert_allclose(D.numpy()[:, :, ::8, ::8], g["s%d_D_sample" % s], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["MSRA", "ICVL", "NYU", "HAND17"])
+def test_metric_tail(golden_dir, name):
+    g = _load(golden_dir, "metric.npz")
+    fx, fy, hu, hv = metric_ref.INTRINSICS[name]
+    uvd = g[name + "_uvd"].copy()
+    rec = metric_ref.recover_uvd(uvd, g[name + "_box"], g[name + "_com"], g[name + "_cube"])
+    assert np.array_equal(uvd, g[name + "_uvd"]), "oracle must not mutate its input"
+    np.testing.assert_allclose(rec, g[name + "_rec"], rtol=1e-6, atol=1e-4)
+    xyz = metric_ref.uvd2xyz(rec, fx, fy, hu, hv)
+    np.testing.assert_allclose(xyz, g[name + "_xyz"], rtol=1e-5, atol=1e-3)
+    err = metric_ref.mean_joint_error(xyz, g[name + "_xyz_gt"])
+    np.testing.assert_allclose(err, g[name + "_err"], rtol=1e-5, atol=1e-3)
