@@ -60,6 +60,92 @@ int pwr_decode_bwd(const float* p, const float* z, const float* D, const float* 
 /* gw[j] (+)= sum_b gw_part[b*J+j], fixed summation order. */
 int pwr_decode_gw_reduce(const float* gw_part, float* gw, int B, int J, int accumulate, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolutions on the matrix cores (SURVEY.md section 8 a-C): every torch.nn.Conv2d of model.py with
+ * Cin % 4 == 0 -- stem :171-185, stage input :137 (stage 0), ResBlock :13-19, heads :54-65 / :103-114.
+ * Activations NHWC in `dtype`; weights come from the flat fp32 parameter buffer re-packed by
+ * pwr_pack_weights (one launch for all layers).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Output channels are padded to the N tile of the kernel (32 / 64 / 128). */
+int pwr_conv_out_pad(int cout);
+
+/* Bytes of one packed weight tensor. kind: 0 forward, 1 data-gradient of a stride-1 conv (taps flipped,
+ * in/out swapped), 2 data-gradient of a stride-2 conv (gather form). */
+size_t pwr_conv_pack_bytes(int cout, int cin, int ksize, int kind, int dtype);
+
+/* descs_dev: device array of n_desc records {int64 src_off (floats into flat_params), int64 dst_off (bytes
+ * into packs), int32 Cout, Cin, ksize, kind, rows_pad, KCH, dtype, pad}.  rows_pad = pwr_conv_out_pad(rows),
+ * KCH = ceil(kdim / (dtype==PWR_BF16 ? 32 : 16)) with rows/kdim = (Cout,Cin) for kind 0, (Cin,Cout) else. */
+int pwr_pack_weights(const float* flat_params, void* packs, const void* descs_dev, int n_desc, void* stream);
+
+/* y = conv(NR(x)) + bias (+ residual).  NR(x) = relu_in ? max(0, x*in_scale[b,c]+in_shift[b,c]) : x*in_scale+in_shift,
+ * skipped when in_scale == NULL: the InstanceNorm/BatchNorm + ReLU that precedes the conv in model.py, fused
+ * into the operand load.  x: [B,H,W,Cin]; y: [B,Ho,Wo,Cout] (NULL to skip); y_nchw: fp32 [B,Cout,Ho,Wo] (NULL to
+ * skip; used by the heads' last conv, model.py:64/:113).  ksize in {1,3}, pad = ksize/2, stride in {1,2}.
+ * mode 0: convolution.  mode 1: data-gradient of a stride-2 conv: x is dy [B,H,W,Cin], y is [B,2H,2W,Cout],
+ * wpack of kind 2.  The data-gradient of a stride-1 conv is mode 0 with a kind-1 pack. */
+int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_scale, const float* in_shift,
+                 int relu_in, const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout,
+                 int ksize, int stride, int mode, int dtype, void* stream);
+
+size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
+
+/* dw[cout_real][Cin][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
+ * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout] (Cout may include zero-padded channels beyond cout_real);
+ * slab: workspace of pwr_conv_wgrad_slab_bytes; `splits` partitions the pixel (K) dimension over workgroups. */
+int pwr_conv_wgrad(const void* x, const void* dy, const float* in_scale, const float* in_shift, int relu_in, float* slab,
+                   float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int cout_real, int ksize, int stride,
+                   int splits, int dtype, void* stream);
+
+/* Stem conv with Cin = 1 (model.py:165).  img: fp32 [B,S,S]; w: OIHW fp32 [C0,1,k,k]; y: [B,S,S,C0]. */
+int pwr_stem_conv_fwd(const float* img, const float* w, const float* bias, void* y, int B, int S, int C0, int ksize,
+                      int dtype, void* stream);
+int pwr_stem_conv_wgrad_blocks(int B, int S); /* slab floats = blocks * C0 * k * k */
+int pwr_stem_conv_wgrad(const float* img, const void* dy, float* slab, float* dw, int accumulate, int B, int S, int C0,
+                        int ksize, int dtype, void* stream);
+int pwr_slab_reduce(const float* slab, float* out, int S, int n, int accumulate, void* stream);
+
+/* Stage-input 1x1 conv of stages >= 1 (model.py:137) fused with the concat of model.py:208: reads
+ * heatmaps [B,J,N], depthmaps [B,J,N], label_img [B,1,N] (fp32 NCHW, N = P*P), writes y [B,N,F].  w: [F,2J+1]. */
+int pwr_catconv_fwd(const float* pmap, const float* dmap, const float* label, const float* w, const float* bias, void* y,
+                    int B, int N, int J, int F, int dtype, void* stream);
+/* gradients w.r.t. heatmaps (gp) and depthmaps (gd), fp32 [B,J,N], overwritten */
+int pwr_catconv_dgrad(const void* dy, const float* w, float* gp, float* gd, int B, int N, int J, int F, int dtype,
+                      void* stream);
+int pwr_catconv_wgrad_blocks(int B, int N); /* slab floats = blocks * (2J+2) * F */
+int pwr_catconv_wgrad(const float* pmap, const float* dmap, const float* label, const void* dy, float* slab, float* dw,
+                      float* db, int accumulate, int B, int N, int J, int F, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Norm + ReLU (model.py: every `norm(...)`, ReLU pair).  mode: 0 InstanceNorm2d, 1 BatchNorm2d training,
+ * 2 BatchNorm2d eval (running statistics).  Outputs are per-(b,c) arrays [B,C]:
+ * scale = gamma*rstd, shift = beta - mean*scale (consumed by pwr_conv_fwd / pwr_conv_wgrad), mean, rstd.
+ * ------------------------------------------------------------------------------------------- */
+int pwr_norm_chunks(int B, int HW);
+size_t pwr_norm_partial_bytes(int B, int HW, int C);
+int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float* partial, float* mean, float* rstd, float* scale, float* shift, int B, int HW, int C, int mode,
+                   float eps, float momentum, int dtype, void* stream);
+/* dy = d/dy relu(norm(y)) applied to g (+ addend); dgamma/dbeta [C] (+)=.  S1,S2: [B,C] scratch. */
+int pwr_norm_bwd(const void* g, const void* y, const float* mean, const float* rstd, const float* scale,
+                 const float* shift, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
+                 float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hourglass plumbing (model.py:40, :45-47), NHWC.
+ * ------------------------------------------------------------------------------------------- */
+int pwr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int pwr_maxpool_bwd(const void* x, const void* dh, const void* addend, void* dx, int B, int H, int W, int C, int dtype,
+                    void* stream);
+int pwr_upsample_add_fwd(const void* h, const void* skip, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                         int dtype, void* stream);
+int pwr_upsample_bwd(const void* dout, void* dh, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
+/* fp32 [B,J,N] -> `dtype` [B,N,Jp] with channels >= J zero (feeds decoder gradients to the head convs) */
+int pwr_nchw_to_nhwc_pad(const float* src, void* dst, int B, int J, int N, int Jp, int dtype, void* stream);
+int pwr_add_inplace(const void* x, void* y, long long n, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

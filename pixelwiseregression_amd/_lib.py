@@ -12,17 +12,32 @@ ABI_VERSION = 1
 
 _lib = None
 
-c_f32p = ctypes.c_void_p
-c_int = ctypes.c_int
-c_vp = ctypes.c_void_p
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong,
+           "void": None}
 
-# name -> argtypes (restype is always int); mirrors include/pwr.h one to one
-SIGNATURES = {
-    "pwr_abi_version": [],
-    "pwr_decode_fwd": [c_vp] * 7 + [c_int] * 4 + [c_vp],
-    "pwr_decode_bwd": [c_vp] * 13 + [c_int] * 4 + [c_vp],
-    "pwr_decode_gw_reduce": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
-}
+
+def _parse_header():
+    """name -> (restype, [argtypes]) parsed from include/pwr.h, so the binding cannot drift from the header."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "pwr.h")
+    txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\b(int|size_t|void)\s+(pwr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    t = a.replace("const ", "").rsplit(" ", 1)[0].strip()
+                    argtypes.append(_CTYPES[t])
+        sigs[name] = (_CTYPES[ret], argtypes)
+    return sigs
+
+
+SIGNATURES = _parse_header()
 
 
 class PwrError(RuntimeError):
@@ -36,10 +51,10 @@ def lib():
             raise PwrError("libpwr_hip.so not built (%s). Run `python -m pixelwiseregression_amd.build` "
                            "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
+        for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(l, name)       # AttributeError if the symbol is missing -> loud
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = restype
         if l.pwr_abi_version() != ABI_VERSION:
             raise PwrError("libpwr_hip.so ABI %d != binding %d: rebuild" % (l.pwr_abi_version(), ABI_VERSION))
         _lib = l

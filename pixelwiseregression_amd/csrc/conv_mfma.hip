@@ -1,0 +1,561 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores: forward / data-gradient / weight-gradient.
+//
+// Replaces every torch.nn.Conv2d with Cin % 4 == 0 of /root/reference/model.py (stem :171-185, stage
+// input :137, ResBlock :13-19, heads :54-65 and :103-114) and what autograd derives for them.
+//
+// Data layout: activations NHWC in T = bf16 or fp32; weights re-packed per (tap, 64-byte
+// K-chunk) as rows of 64 bytes so that both MFMA operands are staged as [rows][64 B] LDS tiles with an
+// XOR swizzle of the four 16-byte slots (conflict-free ds_read_b128 for the 32x32 MFMA row pattern).
+//   bf16: v_mfma_f32_32x32x16_bf16, 32 k per 64-byte row;  fp32: v_mfma_f32_32x32x2_f32 (exact fp32
+//   FMA chain, the parity mode), 16 k per row.
+// The previous layer's InstanceNorm/BatchNorm + ReLU is applied while the A operand is staged
+// ("NR prologue": v = max(0, v*scale[b,c] + shift[b,c])), so a normalised tensor is never written.
+// Workgroup = 256 threads = 4 waves; tile = 128 GEMM rows x {32,64,128} columns; fp32 accumulate.
+#include "pwr_common.h"
+#include "pwr.h"
+
+namespace pwr {
+
+struct ConvParams {
+  const void* x;          // [B,H,W,Cin] T   (forward: input; dgrad: dy)
+  const void* w;          // packed weights, see pack_weights kernel
+  const float* bias;      // [Cout] or null
+  const float* in_scale;  // [B,Cin] or null: NR prologue
+  const float* in_shift;
+  const void* residual;   // [B,Ho,Wo,Cout] T or null (added in the epilogue)
+  void* y;                // [B,Ho,Wo,Cout] T or null
+  float* y_nchw;          // [B,Cout,Ho,Wo] fp32 or null
+  int B, H, W, Cin, Ho, Wo, Cout, CoutPad;
+  int ksize, stride, pad, mode, relu_in, KCH, M;
+};
+
+struct WgradParams {
+  const void* x;          // [B,H,W,Cin] T  forward input (pre-NR)
+  const void* dy;         // [B,Ho,Wo,Cout] T
+  const float* in_scale;  // NR prologue of the forward conv (or null)
+  const float* in_shift;
+  float* slab;            // [S][taps][CinPad128][CoutPad] fp32 partials
+  int B, H, W, Cin, Ho, Wo, Cout, CoutPad, CinPad;
+  int ksize, stride, pad, relu_in, M, S, steps_per_split;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> { static constexpr int KE = 32; static constexpr int EP = 8; };
+template <> struct Mma<float> { static constexpr int KE = 16; static constexpr int EP = 4; };
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
+
+template <typename T, int MR, int NR>
+__device__ __forceinline__ void mma_tile(const char* lA, const char* lB, int a_row0, int b_row0, int lane,
+                                         f32x16 (&acc)[MR][NR]) {
+  typedef typename Vec16<T>::type V;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) {
+    V a[MR], b[NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) a[i] = *reinterpret_cast<const V*>(lA + lds_off(a_row0 + i * 32 + r, 2 * ss + h));
+#pragma unroll
+    for (int j = 0; j < NR; ++j) b[j] = *reinterpret_cast<const V*>(lB + lds_off(b_row0 + j * 32 + r, 2 * ss + h));
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        if constexpr (sizeof(T) == 2) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+      }
+  }
+}
+
+// v = relu?(v*scale + shift) on one 16-byte vector; sc/sh point at the vector's first channel
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type nr_transform(typename Vec16<T>::type v, const float* sc,
+                                                                const float* sh, int relu) {
+  constexpr int EP = Mma<T>::EP;
+  typename Vec16<T>::type o;
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    float f = fmaf(Elem<T>::to_f(v[e]), sc[e], sh[e]);
+    if (relu) f = fmaxf(f, 0.f);
+    o[e] = Elem<T>::from_f(f);
+  }
+  return o;
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  // give each XCD (blocks b, b+8, ... share one) a contiguous range of tiles: neighbours share halo rows in L2
+  const int q = n >> 3, r = n & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad
+// ---------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
+  typedef typename Vec16<T>::type V;
+  constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
+  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  static_assert(BM == 128, "tile");
+  constexpr int NB = (BN * 4 + 255) / 256;       // 16-byte B slots per thread
+  constexpr int EROWS = 64, EPITCH = BN + 4;
+  constexpr int STAGE_BYTES = 2 * (BM + BN) * 64;
+  constexpr int EPI_BYTES = EROWS * EPITCH * 4;
+  __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int mt = xcd_remap(blockIdx.x, gridDim.x), nt = blockIdx.y;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+  const int HoWo = p.Ho * p.Wo;
+
+  // ---- per-thread A rows: (tid>>2) and (tid>>2)+64, slot q = tid&3
+  const int q = tid & 3;
+  int ab[2], aoy[2], aox[2];
+  bool amv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    amv[i] = m < p.M;
+    const int mm = amv[i] ? m : 0;
+    ab[i] = mm / HoWo;
+    const int rem = mm - ab[i] * HoWo;
+    aoy[i] = rem / p.Wo;
+    aox[i] = rem - aoy[i] * p.Wo;
+  }
+  const int taps = p.ksize * p.ksize;
+  const int iters = taps * p.KCH;
+
+  V ra[2], rb[NB];
+  bool av[2];
+  int cur_c0 = 0;
+
+  auto load_global = [&](int it) {
+    const int tap = it / p.KCH, kch = it - tap * p.KCH;
+    const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+    const int c0 = kch * KE + q * EP;
+    cur_c0 = c0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int iy, ix;
+      bool ok = amv[i] && c0 < p.Cin;
+      if (p.mode == 0) {
+        iy = aoy[i] * p.stride + ky - p.pad;
+        ix = aox[i] * p.stride + kx - p.pad;
+      } else {  // gather form of the stride-2 transposed conv (dgrad of a stride-2 conv)
+        const int sy = aoy[i] + p.pad - ky, sx = aox[i] + p.pad - kx;
+        ok = ok && ((sy & 1) == 0) && ((sx & 1) == 0);
+        iy = sy >> 1; ix = sx >> 1;
+      }
+      ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      av[i] = ok;
+      V v = {};
+      if (ok) v = *reinterpret_cast<const V*>(x + ((size_t)(ab[i] * p.H + iy) * p.W + ix) * p.Cin + c0);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int s = tid + 256 * i;
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) {
+        const int row = s >> 2, qq = s & 3;
+        rb[i] = *reinterpret_cast<const V*>(w + ((size_t)(tap * p.KCH + kch) * p.CoutPad + n0 + row) * KE + qq * EP);
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* lA = smem + buf * (BM + BN) * 64;
+    char* lB = lA + BM * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      V v = ra[i];
+      if (p.in_scale && av[i]) {
+        const float* sc = p.in_scale + (size_t)ab[i] * p.Cin + cur_c0;
+        const float* sh = p.in_shift + (size_t)ab[i] * p.Cin + cur_c0;
+        v = nr_transform<T>(v, sc, sh, p.relu_in);
+      }
+      *reinterpret_cast<V*>(lA + lds_off((tid >> 2) + 64 * i, q)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int s = tid + 256 * i;
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(lB + lds_off(s >> 2, s & 3)) = rb[i];
+    }
+  };
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < iters) load_global(it + 1);
+    const char* lA = smem + buf * (BM + BN) * 64;
+    mma_tile<T, MR, NR>(lA, lA + BM * 64, wm * MR * 32, wn * NR * 32, lane, acc);
+    if (it + 1 < iters) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time) -> coalesced 16-byte stores
+  float* E = reinterpret_cast<float*>(smem);
+  constexpr int PASSES = BM / EROWS;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int wrow0 = wm * MR * 32;  // first tile row of this wave
+    if (wrow0 / EROWS == ps) {
+      const int er0 = wrow0 - ps * EROWS;
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = er0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            E[row * EPITCH + wn * NR * 32 + j * 32 + r] = acc[i][j][e];
+          }
+    }
+    __syncthreads();
+    if (p.y) {
+      T* __restrict__ y = reinterpret_cast<T*>(p.y);
+      const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+      constexpr int CPR = BN / EP;               // 16-byte chunks per row
+      for (int c = tid; c < EROWS * CPR; c += 256) {
+        const int row = c / CPR, cc = (c - row * CPR) * EP;
+        const int m = m0 + ps * EROWS + row, n = n0 + cc;
+        if (m < p.M && n < p.Cout) {
+          float v[EP];
+#pragma unroll
+          for (int e = 0; e < EP; ++e) v[e] = E[row * EPITCH + cc + e];
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) v[e] += p.bias[n + e];
+          }
+          if (res) {
+            V rv = *reinterpret_cast<const V*>(res + (size_t)m * p.Cout + n);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) v[e] += Elem<T>::to_f(rv[e]);
+          }
+          V o;
+#pragma unroll
+          for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(v[e]);
+          *reinterpret_cast<V*>(y + (size_t)m * p.Cout + n) = o;
+        }
+      }
+    }
+    if (p.y_nchw) {
+      for (int c = tid; c < EROWS * BN; c += 256) {
+        const int col = c / EROWS, row = c - col * EROWS;
+        const int m = m0 + ps * EROWS + row, n = n0 + col;
+        if (m < p.M && n < p.Cout) {
+          float v = E[row * EPITCH + col];
+          if (p.bias) v += p.bias[n];
+          const int b = m / HoWo, pix = m - b * HoWo;
+          p.y_nchw[((size_t)b * p.Cout + n) * HoWo + pix] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  slab[s][tap][ci][co] = sum_{m in split s} NR(x)[m@tap][ci] * dy[m][co]
+// GEMM rows = ci (A operand, transposed while staged), cols = co, K = pixels.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+  typedef typename Vec16<T>::type V;
+  constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;   // KE pixels per K step
+  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  constexpr int ACH = BM / EP;                      // 16-byte channel chunks per pixel (A side)
+  constexpr int BCH = BN / EP;
+  constexpr int NA = (KE * ACH + 255) / 256, NBL = (KE * BCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tap = blockIdx.x, ky = tap / p.ksize, kx = tap - ky * p.ksize;
+  const int ntn = p.CoutPad / BN;
+  const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
+  const int ci0 = mtile * BM, co0 = ntile * BN;
+  const int split = blockIdx.z;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const int HoWo = p.Ho * p.Wo;
+  const int step0 = split * p.steps_per_split;
+  const int total_steps = (p.M + KE - 1) / KE;
+  int nsteps = total_steps - step0;
+  if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+
+  V ra[NA], rb[NBL];
+  bool av[NA];
+  int abatch[NA];
+
+  auto load_global = [&](int st) {
+    const int mbase = (step0 + st) * KE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      const int pix = c % KE, cq = c / KE;
+      V v = {};
+      bool ok = false;
+      int b = 0;
+      if (c < KE * ACH) {
+        const int m = mbase + pix, ci = ci0 + cq * EP;
+        if (m < p.M && ci < p.Cin) {
+          b = m / HoWo;
+          const int rem = m - b * HoWo;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            ok = true;
+            v = *reinterpret_cast<const V*>(x + ((size_t)(b * p.H + iy) * p.W + ix) * p.Cin + ci);
+          }
+        }
+      }
+      ra[i] = v; av[i] = ok; abatch[i] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int c = tid + 256 * i;
+      const int pix = c % KE, cq = c / KE;
+      V v = {};
+      if (c < KE * BCH) {
+        const int m = mbase + pix, co = co0 + cq * EP;
+        if (m < p.M && co < p.Cout) v = *reinterpret_cast<const V*>(dy + (size_t)m * p.Cout + co);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* lA = smem + buf * (BM + BN) * 64;
+    char* lB = lA + BM * 64;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      if (c < KE * ACH) {
+        const int pix = c % KE, cq = c / KE;
+        V v = ra[i];
+        if (p.in_scale && av[i]) {
+          const int ci = ci0 + cq * EP;
+          v = nr_transform<T>(v, p.in_scale + (size_t)abatch[i] * p.Cin + ci, p.in_shift + (size_t)abatch[i] * p.Cin + ci,
+                              p.relu_in);
+        }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          const int row = cq * EP + e;
+          *reinterpret_cast<T*>(lA + lds_off(row, pix / EP) + (pix % EP) * sizeof(T)) = v[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int c = tid + 256 * i;
+      if (c < KE * BCH) {
+        const int pix = c % KE, cq = c / KE;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          const int row = cq * EP + e;
+          *reinterpret_cast<T*>(lB + lds_off(row, pix / EP) + (pix % EP) * sizeof(T)) = rb[i][e];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nsteps > 0) {
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < nsteps) load_global(st + 1);
+      const char* lA = smem + buf * (BM + BN) * 64;
+      mma_tile<T, MR, NR>(lA, lA + BM * 64, wm * MR * 32, wn * NR * 32, lane, acc);
+      if (st + 1 < nsteps) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // D layout: col = lane&31 -> co (contiguous), row -> ci
+  const int r = lane & 31, h = lane >> 5;
+  const int taps = p.ksize * p.ksize;
+  float* __restrict__ out = p.slab + ((size_t)(split * taps + tap) * p.CinPad) * p.CoutPad;
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * MR * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int co = co0 + wn * NR * 32 + j * 32 + r;
+        out[(size_t)ci * p.CoutPad + co] = acc[i][j][e];
+      }
+}
+
+// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cin,
+                                    int Cout, int CinPad, int CoutPad, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over co*Cin*taps (OIHW order)
+  const int total = Cout * Cin * taps;
+  if (idx >= total) return;
+  const int tap = idx % taps, ci = (idx / taps) % Cin, co = idx / (taps * Cin);
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += slab[((size_t)(k * taps + tap) * CinPad + ci) * CoutPad + co];
+  dw[idx] = accumulate ? dw[idx] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 -> [tap][kch][RowsPad][KE] T
+//   kind 0 (forward): rows = cout, k = cin            value = W[row][k][ky][kx]
+//   kind 1 (dgrad of a stride-1 conv): rows = cin, k = cout, taps flipped   value = W[k][row][K-1-ky][K-1-kx]
+//   kind 2 (dgrad of a stride-2 conv, gather form): rows = cin, k = cout    value = W[k][row][ky][kx]
+// ---------------------------------------------------------------------------------------------
+struct PackDesc {
+  long long src_off;   // floats into the flat parameter buffer
+  long long dst_off;   // bytes into the pack buffer
+  int Cout, Cin, ksize, kind, rows_pad, KCH, dtype, pad_;
+};
+
+__global__ void pack_weights_kernel(const float* __restrict__ flat, char* __restrict__ packs,
+                                    const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const int KE = d.dtype == PWR_BF16 ? 32 : 16;
+  const int taps = d.ksize * d.ksize;
+  const long long total = (long long)taps * d.KCH * d.rows_pad * KE;
+  const float* W = flat + d.src_off;
+  const int rows = d.kind == 0 ? d.Cout : d.Cin;
+  const int kdim = d.kind == 0 ? d.Cin : d.Cout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % KE);
+    const int row = (int)((i / KE) % d.rows_pad);
+    const int kch = (int)((i / ((long long)KE * d.rows_pad)) % d.KCH);
+    const int tap = (int)(i / ((long long)KE * d.rows_pad * d.KCH));
+    const int k = kch * KE + e;
+    float v = 0.f;
+    if (row < rows && k < kdim) {
+      int ky = tap / d.ksize, kx = tap % d.ksize;
+      if (d.kind == 1) { ky = d.ksize - 1 - ky; kx = d.ksize - 1 - kx; }
+      const int co = d.kind == 0 ? row : k, ci = d.kind == 0 ? k : row;
+      v = W[(((size_t)co * d.Cin + ci) * d.ksize + ky) * d.ksize + kx];
+    }
+    if (d.dtype == PWR_BF16) reinterpret_cast<bf16_t*>(packs + d.dst_off)[i] = (bf16_t)v;
+    else reinterpret_cast<float*>(packs + d.dst_off)[i] = v;
+  }
+}
+
+static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
+
+template <typename T>
+static int launch_conv(const ConvParams& p, hipStream_t s) {
+  const int bn = pick_bn(p.Cout);
+  if (p.CoutPad % bn) return PWR_EINVAL;
+  dim3 grid((p.M + 127) / 128, p.CoutPad / bn), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, 2, 2, 2>), grid, block, 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, 2, 2, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv_fwd_kernel<T, 4, 1, 1, 1>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_wgrad(const WgradParams& p, hipStream_t s) {
+  const int bn = pick_bn(p.Cout);
+  if (p.CoutPad % bn || p.CinPad % 128) return PWR_EINVAL;
+  const int taps = p.ksize * p.ksize;
+  dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 2, 2, 2, 2>), grid, block, 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 2, 2, 2, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 4, 1, 1, 1>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pwr
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int pwr_conv_out_pad(int cout) { int bn = pwr::pick_bn(cout); return (cout + bn - 1) / bn * bn; }
+
+extern "C" size_t pwr_conv_pack_bytes(int cout, int cin, int ksize, int kind, int dtype) {
+  const int KE = dtype == PWR_BF16 ? 32 : 16, esz = dtype == PWR_BF16 ? 2 : 4;
+  const int rows = kind == 0 ? cout : cin, kdim = kind == 0 ? cin : cout;
+  const int rows_pad = pwr_conv_out_pad(rows), KCH = (kdim + KE - 1) / KE;
+  return (size_t)ksize * ksize * KCH * rows_pad * KE * esz;
+}
+
+extern "C" int pwr_pack_weights(const float* flat_params, void* packs, const void* descs_dev, int n_desc, void* stream) {
+  if (n_desc <= 0) return 0;
+  hipLaunchKernelGGL(pwr::pack_weights_kernel, dim3(32, n_desc), dim3(256), 0, (hipStream_t)stream, flat_params,
+                     (char*)packs, (const pwr::PackDesc*)descs_dev);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_scale,
+                            const float* in_shift, int relu_in, const void* residual, void* y, float* y_nchw, int B,
+                            int H, int W, int Cin, int Cout, int ksize, int stride, int mode, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
+  if (Cin % EP || (y && Cout % EP) || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return PWR_EUNSUPPORTED;
+  pwr::ConvParams p;
+  p.x = x; p.w = wpack; p.bias = bias; p.in_scale = in_scale; p.in_shift = in_shift; p.residual = residual;
+  p.y = y; p.y_nchw = y_nchw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.ksize = ksize; p.pad = ksize / 2; p.mode = mode; p.relu_in = relu_in;
+  if (mode == 0) {
+    p.stride = stride;
+    p.Ho = (H + 2 * p.pad - ksize) / stride + 1; p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
+  } else {  // transposed stride-2: x is dy [B,H,W,Cin], output is [B,2H,2W,Cout] (even sizes, pad = k/2)
+    p.stride = 1; p.Ho = 2 * H; p.Wo = 2 * W;
+  }
+  p.CoutPad = pwr_conv_out_pad(Cout);
+  p.KCH = (Cin + KE - 1) / KE;
+  p.M = B * p.Ho * p.Wo;
+  return dtype == PWR_BF16 ? pwr::launch_conv<bf16_t>(p, (hipStream_t)stream) : pwr::launch_conv<float>(p, (hipStream_t)stream);
+}
+
+extern "C" size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits) {
+  const int cinpad = (cin + 127) / 128 * 128;
+  return (size_t)splits * ksize * ksize * cinpad * pwr_conv_out_pad(cout) * sizeof(float);
+}
+
+extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_scale, const float* in_shift, int relu_in,
+                              float* slab, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int cout_real,
+                              int ksize, int stride, int splits, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
+  if (Cin % EP || Cout % EP || (ksize != 1 && ksize != 3) || splits < 1) return PWR_EUNSUPPORTED;
+  pwr::WgradParams p;
+  p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.slab = slab;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ksize = ksize; p.stride = stride; p.pad = ksize / 2;
+  p.Ho = (H + 2 * p.pad - ksize) / stride + 1; p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
+  p.CoutPad = pwr_conv_out_pad(Cout); p.CinPad = (Cin + 127) / 128 * 128;
+  p.relu_in = relu_in; p.M = B * p.Ho * p.Wo;
+  const int total_steps = (p.M + KE - 1) / KE;
+  p.steps_per_split = (total_steps + splits - 1) / splits;
+  p.S = (total_steps + p.steps_per_split - 1) / p.steps_per_split;   // effective splits (<= requested)
+  hipStream_t s = (hipStream_t)stream;
+  int rc = dtype == PWR_BF16 ? pwr::launch_wgrad<bf16_t>(p, s) : pwr::launch_wgrad<float>(p, s);
+  if (rc) return rc;
+  if (cout_real <= 0 || cout_real > Cout) return PWR_EINVAL;
+  const int total = cout_real * Cin * ksize * ksize;
+  hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slab, dw, p.S, ksize * ksize,
+                     Cin, cout_real, p.CinPad, p.CoutPad, accumulate);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,318 @@
+// InstanceNorm2d / BatchNorm2d (affine) + ReLU, forward statistics and backward, on NHWC activations.
+//
+// Replaces the `norm(...)` + ReLU pairs of /root/reference/model.py (stem :166-185, ResBlock :11-18, heads
+// :55-63/:104-112).  The normalised tensor is never written: the forward only produces per-(b,c)
+// scale = gamma*rstd and shift = beta - mean*scale, which the consuming conv applies while staging its A
+// operand (conv_mfma.hip, "NR prologue").  HBM traffic: forward reads y once; backward reads (g, y) once
+// for the two reductions and once more for the element-wise apply, writes dy once.
+//
+// Statistics use shifted sums (shift k[c] = first pixel of the sample / batch) so that
+// var = E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically; partials per pixel chunk are written to a
+// slab and combined in a fixed order (deterministic, no atomics).
+#include "pwr_common.h"
+#include "pwr.h"
+
+namespace pwr {
+
+// partial[((b*nchunks + chunk)*2 + {0,1})*C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__ y, float* __restrict__ partial, int HW,
+                                                           int C, int nchunks, int batch_mode) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];  // [pl][2][C]
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const T* base = y + (size_t)b * HW * C;
+  const T* kb = batch_mode ? y : base;   // shift source: pixel 0 of sample b (instance) / of sample 0 (batch)
+  float s1[EP], s2[EP], k[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (pj < pl) {
+    V kv = *reinterpret_cast<const V*>(kb + cq * EP);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) k[e] = Elem<T>::to_f(kv[e]);
+    for (int pp = p0 + pj; pp < p1; pp += pl) {
+      V v = *reinterpret_cast<const V*>(base + (size_t)pp * C + cq * EP);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float d = Elem<T>::to_f(v[e]) - k[e];
+        s1[e] += d;
+        s2[e] = fmaf(d, d, s2[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      red[(pj * 2 + 0) * C + cq * EP + e] = s1[e];
+      red[(pj * 2 + 1) * C + cq * EP + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < pl; ++j) s += red[j * 2 * C + i];
+    partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+  }
+}
+
+// One thread per (b,c) [instance] or per c [batch].  Writes mean/rstd/scale/shift [B,C].
+template <typename T>
+__global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __restrict__ partial,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ scale_o,
+                                     float* __restrict__ shift_o, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, int B, int HW, int C, int nchunks, int batch_mode,
+                                     float eps, float momentum) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!batch_mode) {
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+      s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
+      s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
+    }
+    const float n = (float)HW;
+    const float kk = Elem<T>::to_f(y[(size_t)b * HW * C + c]);
+    const float m1 = s1 / n;
+    const float var = fmaxf(s2 / n - m1 * m1, 0.f);
+    const float mean = kk + m1, rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    mean_o[idx] = mean; rstd_o[idx] = rstd; scale_o[idx] = sc; shift_o[idx] = beta[c] - mean * sc;
+  } else {
+    if (idx >= C) return;
+    const int c = idx;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < B * nchunks; ++k) {
+      s1 += partial[((size_t)k * 2 + 0) * C + c];
+      s2 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    const float n = (float)B * (float)HW;
+    const float kk = Elem<T>::to_f(y[c]);
+    const float m1 = s1 / n;
+    const float var = fmaxf(s2 / n - m1 * m1, 0.f);
+    const float mean = kk + m1, rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd, sh = beta[c] - mean * sc;
+    for (int b = 0; b < B; ++b) {
+      mean_o[b * C + c] = mean; rstd_o[b * C + c] = rstd; scale_o[b * C + c] = sc; shift_o[b * C + c] = sh;
+    }
+    if (running_mean) {  // torch.nn.BatchNorm2d: unbiased variance in the running estimate
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+  }
+}
+
+// eval-mode BatchNorm: scale/shift from the running statistics
+__global__ void norm_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                 float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ scale_o,
+                                 float* __restrict__ shift_o, int B, int C, float eps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int c = idx % C;
+  const float rstd = 1.f / sqrtf(running_var[c] + eps), sc = gamma[c] * rstd;
+  mean_o[idx] = running_mean[c]; rstd_o[idx] = rstd; scale_o[idx] = sc; shift_o[idx] = beta[c] - running_mean[c] * sc;
+}
+
+// ---- backward ----
+// g = dL/d relu(norm(y));  gm = g * [norm(y) > 0];  xn = (y - mean)*rstd
+// partial sums per chunk: s1 = sum gm, s2 = sum gm*xn
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               float* __restrict__ partial, int HW, int C, int nchunks,
+                                                               int relu) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const size_t base = (size_t)b * HW * C;
+  float s1[EP], s2[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (pj < pl) {
+    float mu[EP], rs[EP], sc[EP], sh[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const int c = b * C + cq * EP + e;
+      mu[e] = mean[c]; rs[e] = rstd[c]; sc[e] = scale[c]; sh[e] = shift[c];
+    }
+    for (int pp = p0 + pj; pp < p1; pp += pl) {
+      V gv = *reinterpret_cast<const V*>(g + base + (size_t)pp * C + cq * EP);
+      V yv = *reinterpret_cast<const V*>(y + base + (size_t)pp * C + cq * EP);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float yy = Elem<T>::to_f(yv[e]);
+        float gg = Elem<T>::to_f(gv[e]);
+        if (relu && !(fmaf(yy, sc[e], sh[e]) > 0.f)) gg = 0.f;
+        s1[e] += gg;
+        s2[e] = fmaf(gg, (yy - mu[e]) * rs[e], s2[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      red[(pj * 2 + 0) * C + cq * EP + e] = s1[e];
+      red[(pj * 2 + 1) * C + cq * EP + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < pl; ++j) s += red[j * 2 * C + i];
+    partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+  }
+}
+
+// S1,S2 [B,C] (already divided by N); instance: per (b,c); batch: summed over b and broadcast.
+// dgamma[c] (+)= sum_b sum gm*xn ; dbeta[c] (+)= sum_b sum gm  -- done by one thread per c.
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ S1, float* __restrict__ S2,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int HW, int C,
+                                         int nchunks, int batch_mode, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+      s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
+      s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
+    }
+    t1 += s1; t2 += s2;
+    if (!batch_mode) { S1[b * C + c] = s1 / (float)HW; S2[b * C + c] = s2 / (float)HW; }
+  }
+  if (batch_mode) {
+    const float n = (float)B * (float)HW;
+    for (int b = 0; b < B; ++b) { S1[b * C + c] = t1 / n; S2[b * C + c] = t2 / n; }
+  }
+  dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
+  dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
+}
+
+// dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ S1, const float* __restrict__ S2,
+                                                             const T* __restrict__ addend, T* __restrict__ dy, int HW, int C,
+                                                             long long total_chunks, int relu) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int cpp = C / EP;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256) {
+    const int cq = (int)(i % cpp);
+    const long long pix = i / cpp;
+    const int b = (int)(pix / HW);
+    const size_t off = (size_t)pix * C + cq * EP;
+    V gv = *reinterpret_cast<const V*>(g + off);
+    V yv = *reinterpret_cast<const V*>(y + off);
+    V av = {};
+    if (addend) av = *reinterpret_cast<const V*>(addend + off);
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const int c = b * C + cq * EP + e;
+      const float yy = Elem<T>::to_f(yv[e]);
+      float gg = Elem<T>::to_f(gv[e]);
+      const float sc = scale[c];
+      if (relu && !(fmaf(yy, sc, shift[c]) > 0.f)) gg = 0.f;
+      const float xn = (yy - mean[c]) * rstd[c];
+      float r = sc * (gg - S1[c] - xn * S2[c]);     // scale = gamma*rstd
+      if (addend) r += Elem<T>::to_f(av[e]);
+      o[e] = Elem<T>::from_f(r);
+    }
+    *reinterpret_cast<V*>(dy + off) = o;
+  }
+}
+
+static inline int norm_chunks(int B, int HW) {
+  int n = (1024 + B - 1) / B;
+  int maxc = (HW + 31) / 32;
+  if (n > maxc) n = maxc;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return n;
+}
+
+}  // namespace pwr
+
+using namespace pwr;
+
+extern "C" int pwr_norm_chunks(int B, int HW) { return norm_chunks(B, HW); }
+
+extern "C" size_t pwr_norm_partial_bytes(int B, int HW, int C) { return (size_t)B * norm_chunks(B, HW) * 2 * C * sizeof(float); }
+
+// mode: 0 instance, 1 batch (training statistics), 2 batch eval (running statistics)
+extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float* partial, float* mean, float* rstd, float* scale, float* shift, int B, int HW, int C,
+                              int mode, float eps, float momentum, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 2) {
+    hipLaunchKernelGGL(norm_eval_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, gamma, beta, running_mean, running_var,
+                       mean, rstd, scale, shift, B, C, eps);
+    return (int)hipGetLastError();
+  }
+  const int nch = norm_chunks(B, HW);
+  const int pl = 256 / (C / EP);
+  const size_t sh = (size_t)pl * 2 * C * 4;
+  const int n = mode == 1 ? C : B * C;
+  if (dtype == PWR_BF16) {
+    hipLaunchKernelGGL((norm_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)y, partial, HW, C, nch, mode);
+    hipLaunchKernelGGL((norm_finalize_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)y, partial, gamma,
+                       beta, mean, rstd, scale, shift, running_mean, running_var, B, HW, C, nch, mode, eps, momentum);
+  } else {
+    hipLaunchKernelGGL((norm_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)y, partial, HW, C, nch, mode);
+    hipLaunchKernelGGL((norm_finalize_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)y, partial, gamma,
+                       beta, mean, rstd, scale, shift, running_mean, running_var, B, HW, C, nch, mode, eps, momentum);
+  }
+  return (int)hipGetLastError();
+}
+
+// Backward of relu(norm(y)) (relu optional).  g: upstream gradient; dy out (may alias g); addend optional (same
+// shape, added to the result: the skip branch of a ResBlock).  S1,S2: [B,C] scratch.  dgamma/dbeta: [C].
+// mode 2 (eval-mode batch norm) treats the statistics as constants.
+extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* mean, const float* rstd, const float* scale,
+                            const float* shift, float* partial, float* S1, float* S2, const void* addend, void* dy,
+                            float* dgamma, float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype,
+                            void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = norm_chunks(B, HW);
+  const int pl = 256 / (C / EP);
+  const size_t sh = (size_t)pl * 2 * C * 4;
+  const long long total = (long long)B * HW * (C / EP);
+  int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (dtype == PWR_BF16) {
+    hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y,
+                       mean, rstd, scale, shift, partial, HW, C, nch, relu);
+  } else {
+    hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, mean,
+                       rstd, scale, shift, partial, HW, C, nch, relu);
+  }
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, S1, S2, dgamma, dbeta, B, HW, C, nch,
+                     mode == 1 ? 1 : 0, accumulate);
+  if (mode == 2) {  // statistics are constants: dy = scale * gm
+    hipMemsetAsync(S1, 0, (size_t)B * C * 4, s);
+    hipMemsetAsync(S2, 0, (size_t)B * C * 4, s);
+  }
+  if (dtype == PWR_BF16) {
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, mean, rstd,
+                       scale, shift, S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, total, relu);
+  } else {
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)y, mean, rstd,
+                       scale, shift, S1, S2, (const float*)addend, (float*)dy, HW, C, total, relu);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,245 @@
+// Hourglass plumbing on NHWC activations (all HBM-bound, 16-byte vectors per lane):
+//   MaxPool2d(2, stride=2)                                   model.py:29,40
+//   F.interpolate(h, size=x.shape[2:]) (nearest) + skip add   model.py:45-47
+// and their gradients; plus the NCHW fp32 -> NHWC T (zero-padded channels) transpose that feeds the
+// decoder's logits/depth gradients into the head convolutions' backward.
+#include "pwr_common.h"
+#include "pwr.h"
+
+namespace pwr {
+
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  // ATen nearest_neighbor_compute_source_index with scale = (float)in/out
+  const float scale = (float)in / (float)out;
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int Ho = H / 2, Wo = W / 2, cpp = C / EP;
+  const long long total = (long long)B * Ho * Wo * cpp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cq = (int)(i % cpp);
+    long long r = i / cpp;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const T* p = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + cq * EP;
+    V v00 = *reinterpret_cast<const V*>(p), v01 = *reinterpret_cast<const V*>(p + C);
+    V v10 = *reinterpret_cast<const V*>(p + (size_t)W * C), v11 = *reinterpret_cast<const V*>(p + (size_t)W * C + C);
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const float m = fmaxf(fmaxf(Elem<T>::to_f(v00[e]), Elem<T>::to_f(v01[e])), fmaxf(Elem<T>::to_f(v10[e]), Elem<T>::to_f(v11[e])));
+      o[e] = Elem<T>::from_f(m);
+    }
+    *reinterpret_cast<V*>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + cq * EP) = o;
+  }
+}
+
+// dx = addend + route(dh): the gradient goes to the first maximum of each 2x2 window in scan order
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dh,
+                                                          const T* __restrict__ addend, T* __restrict__ dx, int B, int H, int W,
+                                                          int C) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int Ho = H / 2, Wo = W / 2, cpp = C / EP;
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;   // windows incl. the ragged edge (which has no pool output)
+  const long long total = (long long)B * Hc * Wc * cpp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cq = (int)(i % cpp);
+    long long r = i / cpp;
+    const int ox = (int)(r % Wc); r /= Wc;
+    const int oy = (int)(r % Hc);
+    const int b = (int)(r / Hc);
+    const bool pooled = oy < Ho && ox < Wo;
+    V xv[4], ov[4];
+    bool ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int yy = 2 * oy + (t >> 1), xx = 2 * ox + (t & 1);
+      ok[t] = yy < H && xx < W;
+      const size_t off = (((size_t)b * H + yy) * W + xx) * C + cq * EP;
+      if (ok[t]) {
+        xv[t] = *reinterpret_cast<const V*>(x + off);
+        if (addend) ov[t] = *reinterpret_cast<const V*>(addend + off);
+        else ov[t] = V{};
+      }
+    }
+    if (pooled) {
+      V g = *reinterpret_cast<const V*>(dh + (((size_t)b * Ho + oy) * Wo + ox) * C + cq * EP);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        int best = 0;
+        float bv = Elem<T>::to_f(xv[0][e]);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+          const float v = Elem<T>::to_f(xv[t][e]);
+          if (v > bv) { bv = v; best = t; }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t == best) ov[t][e] = Elem<T>::from_f(Elem<T>::to_f(ov[t][e]) + Elem<T>::to_f(g[e]));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int yy = 2 * oy + (t >> 1), xx = 2 * ox + (t & 1);
+      if (ok[t]) *reinterpret_cast<V*>(dx + (((size_t)b * H + yy) * W + xx) * C + cq * EP) = ov[t];
+    }
+  }
+}
+
+// out[b,y,x,:] = skip[b,y,x,:] + h[b,sy(y),sx(x),:]
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_kernel(const T* __restrict__ h, const T* __restrict__ skip, T* __restrict__ out,
+                                                           int B, int Hi, int Wi, int Ho, int Wo, int C) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int cpp = C / EP;
+  const long long total = (long long)B * Ho * Wo * cpp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cq = (int)(i % cpp);
+    long long r = i / cpp;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const int sy = nearest_src(oy, Hi, Ho), sx = nearest_src(ox, Wi, Wo);
+    V hv = *reinterpret_cast<const V*>(h + (((size_t)b * Hi + sy) * Wi + sx) * C + cq * EP);
+    const size_t off = (((size_t)b * Ho + oy) * Wo + ox) * C + cq * EP;
+    V sv = *reinterpret_cast<const V*>(skip + off);
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(Elem<T>::to_f(hv[e]) + Elem<T>::to_f(sv[e]));
+    *reinterpret_cast<V*>(out + off) = o;
+  }
+}
+
+// dh[b,hy,hx,:] = sum over the output pixels that read (hy,hx)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dh, int B, int Hi, int Wi,
+                                                           int Ho, int Wo, int C) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int cpp = C / EP;
+  const long long total = (long long)B * Hi * Wi * cpp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cq = (int)(i % cpp);
+    long long r = i / cpp;
+    const int hx = (int)(r % Wi); r /= Wi;
+    const int hy = (int)(r % Hi);
+    const int b = (int)(r / Hi);
+    float a[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) a[e] = 0.f;
+    const int y0 = max(0, (int)((long long)hy * Ho / Hi) - 1), y1 = min(Ho - 1, (int)((long long)(hy + 1) * Ho / Hi) + 1);
+    const int x0 = max(0, (int)((long long)hx * Wo / Wi) - 1), x1 = min(Wo - 1, (int)((long long)(hx + 1) * Wo / Wi) + 1);
+    for (int yy = y0; yy <= y1; ++yy) {
+      if (nearest_src(yy, Hi, Ho) != hy) continue;
+      for (int xx = x0; xx <= x1; ++xx) {
+        if (nearest_src(xx, Wi, Wo) != hx) continue;
+        V v = *reinterpret_cast<const V*>(dout + (((size_t)b * Ho + yy) * Wo + xx) * C + cq * EP);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) a[e] += Elem<T>::to_f(v[e]);
+      }
+    }
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(a[e]);
+    *reinterpret_cast<V*>(dh + (((size_t)b * Hi + hy) * Wi + hx) * C + cq * EP) = o;
+  }
+}
+
+// src [B,J,N] fp32 (optionally + src2) -> dst [B,N,Jp] T with channels >= J zeroed
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int J, int N,
+                                                               int Jp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y, p0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int j = i / 64, pp = i % 64;
+    float v = 0.f;
+    if (j < J && p0 + pp < N) v = src[((size_t)b * J + j) * N + p0 + pp];
+    if (j < Jp) tile[j][pp] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * Jp; i += 256) {
+    const int pp = i / Jp, j = i % Jp;
+    if (p0 + pp < N) dst[((size_t)b * N + p0 + pp) * Jp + j] = Elem<T>::from_f(tile[j][pp]);
+  }
+}
+
+template <typename T>
+__global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {  // y += x
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = Elem<T>::from_f(Elem<T>::to_f(y[i]) + Elem<T>::to_f(x[i]));
+}
+
+static inline int grid_for(long long total) { long long g = (total + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+}  // namespace pwr
+
+using namespace pwr;
+
+#define PWR_DISPATCH_T(KERNEL, GRID, ...)                                                                       \
+  do {                                                                                                          \
+    if (dtype == PWR_BF16) hipLaunchKernelGGL((KERNEL<bf16_t>), dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<float>), dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);      \
+  } while (0)
+
+extern "C" int pwr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP) return PWR_EUNSUPPORTED;
+  const int g = grid_for((long long)B * (H / 2) * (W / 2) * (C / EP));
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_maxpool_bwd(const void* x, const void* dh, const void* addend, void* dx, int B, int H, int W, int C, int dtype,
+                               void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP) return PWR_EUNSUPPORTED;
+  const int g = grid_for((long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / EP));
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dh, (const bf16_t*)addend, (bf16_t*)dx, B, H, W, C);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dh, (const float*)addend, (float*)dx, B, H, W, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_upsample_add_fwd(const void* h, const void* skip, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                    int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP) return PWR_EUNSUPPORTED;
+  const int g = grid_for((long long)B * Ho * Wo * (C / EP));
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((upsample_add_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (const bf16_t*)skip, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C);
+  else hipLaunchKernelGGL((upsample_add_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)h, (const float*)skip, (float*)out, B, Hi, Wi, Ho, Wo, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_upsample_bwd(const void* dout, void* dh, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP) return PWR_EUNSUPPORTED;
+  const int g = grid_for((long long)B * Hi * Wi * (C / EP));
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((upsample_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, (bf16_t*)dh, B, Hi, Wi, Ho, Wo, C);
+  else hipLaunchKernelGGL((upsample_bwd_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (float*)dh, B, Hi, Wi, Ho, Wo, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_nchw_to_nhwc_pad(const float* src, void* dst, int B, int J, int N, int Jp, int dtype, void* stream) {
+  if (Jp > 64 || J > Jp) return PWR_EUNSUPPORTED;
+  dim3 grid((N + 63) / 64, B);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, B, J, N, Jp);
+  else hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, B, J, N, Jp);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_add_inplace(const void* x, void* y, long long n, int dtype, void* stream) {
+  const int g = grid_for(n);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((axpy_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n);
+  else hipLaunchKernelGGL((axpy_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n);
+  return (int)hipGetLastError();
+}

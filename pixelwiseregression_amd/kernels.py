@@ -1,0 +1,208 @@
+"""Thin tensor-level wrappers over the C ABI (include/pwr.h), one per kernel entry point.
+
+Used by the op-level parity tests and for debugging; the network engine (csrc/engine.cpp) calls the
+same entry points from C++ without going through Python.  Activations are NHWC torch tensors
+([B,H,W,C], float32 or bfloat16); everything must live on the GPU.
+"""
+import struct
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("activations must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _s(t):
+    return _lib.stream_ptr(t.device)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.PwrError("pwr kernels need GPU tensors")
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+def pack_descs(entries, device):
+    """entries: list of (src_off_floats, dst_off_bytes, Cout, Cin, ksize, kind, dtype) -> device tensor."""
+    l = _lib.lib()
+    buf = bytearray()
+    for (src, dst, cout, cin, k, kind, dtype) in entries:
+        rows, kdim = (cout, cin) if kind == 0 else (cin, cout)
+        ke = 32 if dtype == BF16 else 16
+        buf += struct.pack("<qqiiiiiiii", src, dst, cout, cin, k, kind, l.pwr_conv_out_pad(rows), (kdim + ke - 1) // ke,
+                           dtype, 0)
+    return torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
+
+
+def pack_conv(weight, kind, dtype):
+    """weight: OIHW fp32 cuda tensor -> packed uint8 buffer for pwr_conv_fwd."""
+    l = _lib.lib()
+    cout, cin, k, _ = weight.shape
+    nbytes = l.pwr_conv_pack_bytes(cout, cin, k, kind, dtype)
+    packs = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    flat = weight.contiguous().float().view(-1)
+    descs = pack_descs([(0, 0, cout, cin, k, kind, dtype)], weight.device)
+    _lib.check(l.pwr_pack_weights(_p(flat), _p(packs), _p(descs), 1, _s(weight)), "pwr_pack_weights")
+    return packs
+
+
+def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, scale=None, shift=None, relu_in=True, residual=None, mode=0,
+             nhwc_out=True, nchw_out=False):
+    l = _lib.lib()
+    B, H, W, Cin = x.shape
+    pad = ksize // 2
+    if mode == 0:
+        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    else:
+        Ho, Wo = 2 * H, 2 * W
+    y = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device) if nhwc_out else None
+    yn = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device) if nchw_out else None
+    _lib.check(l.pwr_conv_fwd(_p(x), _p(wpack), _p(bias), _p(scale), _p(shift), int(relu_in), _p(residual), _p(y), _p(yn),
+                              B, H, W, Cin, cout, ksize, stride, mode, _dt(x), _s(x)), "pwr_conv_fwd")
+    return y, yn
+
+
+def conv_wgrad(x, dy, cout_real, ksize, stride=1, scale=None, shift=None, relu_in=True, splits=8, dw=None):
+    l = _lib.lib()
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    slab = torch.empty(l.pwr_conv_wgrad_slab_bytes(Cout, Cin, ksize, splits) // 4, dtype=torch.float32, device=x.device)
+    acc = dw is not None
+    if dw is None:
+        dw = torch.empty(cout_real, Cin, ksize, ksize, dtype=torch.float32, device=x.device)
+    _lib.check(l.pwr_conv_wgrad(_p(x), _p(dy), _p(scale), _p(shift), int(relu_in), _p(slab), _p(dw), int(acc), B, H, W, Cin,
+                                Cout, cout_real, ksize, stride, splits, _dt(x), _s(x)), "pwr_conv_wgrad")
+    return dw
+
+
+def stem_conv_fwd(img, w, bias, dtype):
+    l = _lib.lib()
+    B, S = img.shape[0], img.shape[-1]
+    C0, k = w.shape[0], w.shape[-1]
+    y = torch.empty(B, S, S, C0, dtype=dtype, device=img.device)
+    _lib.check(l.pwr_stem_conv_fwd(_p(img), _p(w), _p(bias), _p(y), B, S, C0, k, _dt(y), _s(img)), "pwr_stem_conv_fwd")
+    return y
+
+
+def stem_conv_wgrad(img, dy, ksize):
+    l = _lib.lib()
+    B, S, _, C0 = dy.shape
+    nb = l.pwr_stem_conv_wgrad_blocks(B, S)
+    slab = torch.empty(nb * C0 * ksize * ksize, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(C0, 1, ksize, ksize, dtype=torch.float32, device=dy.device)
+    _lib.check(l.pwr_stem_conv_wgrad(_p(img), _p(dy), _p(slab), _p(dw), 0, B, S, C0, ksize, _dt(dy), _s(dy)),
+               "pwr_stem_conv_wgrad")
+    return dw
+
+
+def catconv_fwd(pmap, dmap, label, w, bias, dtype):
+    l = _lib.lib()
+    B, J, P, _ = pmap.shape
+    Fo = w.shape[0]
+    y = torch.empty(B, P, P, Fo, dtype=dtype, device=pmap.device)
+    _lib.check(l.pwr_catconv_fwd(_p(pmap), _p(dmap), _p(label), _p(w), _p(bias), _p(y), B, P * P, J, Fo, _dt(y), _s(y)),
+               "pwr_catconv_fwd")
+    return y
+
+
+def catconv_dgrad(dy, w, J):
+    l = _lib.lib()
+    B, P, _, Fo = dy.shape
+    gp = torch.empty(B, J, P, P, dtype=torch.float32, device=dy.device)
+    gd = torch.empty_like(gp)
+    _lib.check(l.pwr_catconv_dgrad(_p(dy), _p(w), _p(gp), _p(gd), B, P * P, J, Fo, _dt(dy), _s(dy)), "pwr_catconv_dgrad")
+    return gp, gd
+
+
+def catconv_wgrad(pmap, dmap, label, dy):
+    l = _lib.lib()
+    B, J, P, _ = pmap.shape
+    Fo = dy.shape[-1]
+    nb = l.pwr_catconv_wgrad_blocks(B, P * P)
+    slab = torch.empty(nb * (2 * J + 2) * Fo, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(Fo, 2 * J + 1, 1, 1, dtype=torch.float32, device=dy.device)
+    db = torch.empty(Fo, dtype=torch.float32, device=dy.device)
+    _lib.check(l.pwr_catconv_wgrad(_p(pmap), _p(dmap), _p(label), _p(dy), _p(slab), _p(dw), _p(db), 0, B, P * P, J, Fo,
+                                   _dt(dy), _s(dy)), "pwr_catconv_wgrad")
+    return dw, db
+
+
+def norm_stats(y, gamma, beta, mode=0, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    dev = y.device
+    partial = torch.empty(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=dev)
+    out = [torch.empty(B, C, dtype=torch.float32, device=dev) for _ in range(4)]
+    _lib.check(l.pwr_norm_stats(_p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(partial), _p(out[0]),
+                                _p(out[1]), _p(out[2]), _p(out[3]), B, H * W, C, mode, eps, momentum, _dt(y), _s(y)),
+               "pwr_norm_stats")
+    return tuple(out)   # mean, rstd, scale, shift
+
+
+def norm_bwd(g, y, mean, rstd, scale, shift, relu=True, addend=None, mode=0):
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    dev = y.device
+    partial = torch.empty(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=dev)
+    S1 = torch.empty(B, C, dtype=torch.float32, device=dev)
+    S2 = torch.empty_like(S1)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    _lib.check(l.pwr_norm_bwd(_p(g), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(S1), _p(S2),
+                              _p(addend), _p(dy), _p(dgamma), _p(dbeta), 0, int(relu), B, H * W, C, mode, _dt(y), _s(y)),
+               "pwr_norm_bwd")
+    return dy, dgamma, dbeta
+
+
+def maxpool_fwd(x):
+    l = _lib.lib()
+    B, H, W, C = x.shape
+    y = torch.empty(B, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
+    _lib.check(l.pwr_maxpool_fwd(_p(x), _p(y), B, H, W, C, _dt(x), _s(x)), "pwr_maxpool_fwd")
+    return y
+
+
+def maxpool_bwd(x, dh, addend=None):
+    l = _lib.lib()
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(l.pwr_maxpool_bwd(_p(x), _p(dh), _p(addend), _p(dx), B, H, W, C, _dt(x), _s(x)), "pwr_maxpool_bwd")
+    return dx
+
+
+def upsample_add(h, skip):
+    l = _lib.lib()
+    B, Hi, Wi, C = h.shape
+    _, Ho, Wo, _ = skip.shape
+    out = torch.empty_like(skip)
+    _lib.check(l.pwr_upsample_add_fwd(_p(h), _p(skip), _p(out), B, Hi, Wi, Ho, Wo, C, _dt(h), _s(h)), "pwr_upsample_add_fwd")
+    return out
+
+
+def upsample_bwd(dout, Hi, Wi):
+    l = _lib.lib()
+    B, Ho, Wo, C = dout.shape
+    dh = torch.empty(B, Hi, Wi, C, dtype=dout.dtype, device=dout.device)
+    _lib.check(l.pwr_upsample_bwd(_p(dout), _p(dh), B, Hi, Wi, Ho, Wo, C, _dt(dout), _s(dout)), "pwr_upsample_bwd")
+    return dh
+
+
+def nchw_to_nhwc_pad(src, Jp, dtype):
+    l = _lib.lib()
+    B, J, P, _ = src.shape
+    dst = torch.empty(B, P, P, Jp, dtype=dtype, device=src.device)
+    _lib.check(l.pwr_nchw_to_nhwc_pad(_p(src), _p(dst), B, J, P * P, Jp, _dt(dst), _s(src)), "pwr_nchw_to_nhwc_pad")
+    return dst

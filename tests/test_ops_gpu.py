@@ -1,0 +1,294 @@
+"""GPU parity of every kernel entry point of include/pwr.h (through kernels.py -> ctypes -> C ABI) against the
+same op evaluated with plain torch ops in float64 on the CPU -- the per-op restatement of what
+/root/reference/model.py composes (Conv2d, InstanceNorm2d/BatchNorm2d+ReLU, MaxPool2d, nearest interpolate).
+
+Tolerances (relative to max|ref|): fp32 path 2e-5 (exact-fp32 MFMA, different summation order);
+bf16 path 1.5e-2 with the reference fed the same bf16-rounded operands (accumulation is fp32).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.5e-2
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def q(x, dtype):
+    """value actually seen by the kernel for a tensor stored in `dtype` (float64 carrier)."""
+    return x.to(dtype).double()
+
+
+def nhwc(x, dtype):   # NCHW float64 -> NHWC device tensor of dtype
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def nchw(y):          # NHWC device -> NCHW float64 cpu
+    return y.double().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def assert_close(got, ref, rel, what=""):
+    err = (got - ref).abs().max().item()
+    den = max(ref.abs().max().item(), 1e-6)
+    assert err <= rel * den, "%s: max err %.3e vs max|ref| %.3e (rel %.2e > %.1e)" % (what, err, den, err / den, rel)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride
+    (2, 16, 16, 32, 32, 3, 1),
+    (1, 8, 8, 16, 16, 3, 1),
+    (2, 64, 64, 128, 128, 3, 1),
+    (3, 5, 7, 64, 64, 3, 1),
+    (2, 32, 32, 128, 128, 3, 2),
+    (2, 16, 16, 128, 64, 1, 1),
+    (2, 16, 16, 64, 128, 1, 1),
+    (1, 2, 2, 64, 64, 3, 1),
+    (1, 16, 16, 64, 256, 3, 1),
+    (2, 128, 128, 32, 64, 3, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv_forward(case, dtype, prologue):
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, k, stride = case
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bias = rnd(Cout, seed=3, scale=0.1)
+    res = rnd(B, Cout, (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1, seed=4)
+    xin = q(x, dtype)
+    sc = sh = None
+    if prologue:
+        sc, sh = 1 + 0.2 * rnd(B, Cin, seed=5), 0.3 * rnd(B, Cin, seed=6)
+        xin = q(torch.relu(xin * sc.float().double()[:, :, None, None] + sh.float().double()[:, :, None, None]), dtype)
+    ref = F.conv2d(xin, q(w, dtype), bias.float().double(), stride=stride, padding=k // 2) + q(res, dtype)
+    pack = K.pack_conv(w.float().to(DEV), 0, K.BF16 if dtype == torch.bfloat16 else K.F32)
+    y, _ = K.conv_fwd(nhwc(x, dtype), pack, Cout, k, stride, bias=bias.float().to(DEV),
+                      scale=sc.float().to(DEV) if prologue else None, shift=sh.float().to(DEV) if prologue else None,
+                      relu_in=True, residual=nhwc(res, dtype))
+    assert_close(nchw(y), ref, tol(dtype), "conv fwd %s" % (case,))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("J", [14, 4, 21])
+def test_conv_forward_nchw_out(dtype, J):
+    from pixelwiseregression_amd import kernels as K
+    B, H, Cin = 2, 32, 64
+    x, w, bias = rnd(B, Cin, H, H, seed=1), rnd(J, Cin, 3, 3, seed=2, scale=0.05), rnd(J, seed=3)
+    ref = F.conv2d(q(x, dtype), q(w, dtype), bias.float().double(), padding=1)
+    pack = K.pack_conv(w.float().to(DEV), 0, K.BF16 if dtype == torch.bfloat16 else K.F32)
+    _, yn = K.conv_fwd(nhwc(x, dtype), pack, J, 3, 1, bias=bias.float().to(DEV), nhwc_out=False, nchw_out=True)
+    assert_close(yn.double().cpu(), ref, tol(dtype) if dtype == torch.float32 else 5e-3, "conv nchw out")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3), (2, 64, 64, 128, 128, 3), (3, 5, 7, 64, 128, 3),
+                                  (2, 16, 16, 128, 64, 1), (1, 4, 4, 16, 16, 3), (2, 32, 32, 128, 16, 3)])
+def test_conv_dgrad_stride1(case, dtype):
+    """data gradient = pwr_conv_fwd on dy with the kind-1 (flipped, transposed) weight pack."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, k = case
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    dy = rnd(B, Cout, H, W, seed=7)
+    x = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, q(w, dtype), None, padding=k // 2).backward(q(dy, dtype))
+    pack = K.pack_conv(w.float().to(DEV), 1, K.BF16 if dtype == torch.bfloat16 else K.F32)
+    dx, _ = K.conv_fwd(nhwc(dy, dtype), pack, Cin, k, 1)
+    assert_close(nchw(dx), x.grad, tol(dtype), "dgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_dgrad_stride2(dtype):
+    from pixelwiseregression_amd import kernels as K
+    B, H, Cin, Cout, k = 2, 32, 64, 128, 3
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    dy = rnd(B, Cout, H // 2, H // 2, seed=7)
+    x = torch.zeros(B, Cin, H, H, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, q(w, dtype), None, stride=2, padding=1).backward(q(dy, dtype))
+    pack = K.pack_conv(w.float().to(DEV), 2, K.BF16 if dtype == torch.bfloat16 else K.F32)
+    dx, _ = K.conv_fwd(nhwc(dy, dtype), pack, Cin, k, 1, mode=1)
+    assert_close(nchw(dx), x.grad, tol(dtype), "dgrad stride 2")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3, 1, 4), (2, 64, 64, 128, 128, 3, 1, 16), (3, 5, 7, 64, 64, 3, 1, 3),
+                                  (2, 16, 16, 128, 64, 1, 1, 2), (2, 32, 32, 64, 128, 3, 2, 8), (1, 2, 2, 16, 16, 3, 1, 1),
+                                  (2, 8, 8, 256, 32, 3, 1, 2)])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv_wgrad(case, dtype, prologue):
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, k, stride, splits = case
+    x = rnd(B, Cin, H, W, seed=1)
+    xin = q(x, dtype)
+    sc = sh = None
+    if prologue:
+        sc, sh = 1 + 0.2 * rnd(B, Cin, seed=5), 0.3 * rnd(B, Cin, seed=6)
+        xin = q(torch.relu(xin * sc.float().double()[:, :, None, None] + sh.float().double()[:, :, None, None]), dtype)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    dy = rnd(B, Cout, Ho, Wo, seed=7)
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w, None, stride=stride, padding=k // 2).backward(q(dy, dtype))
+    dw = K.conv_wgrad(nhwc(x, dtype), nhwc(dy, dtype), Cout, k, stride, scale=sc.float().to(DEV) if prologue else None,
+                      shift=sh.float().to(DEV) if prologue else None, relu_in=True, splits=splits)
+    assert_close(dw.double().cpu(), w.grad, tol(dtype), "wgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_wgrad_padded_dy(dtype):
+    """head's last conv: dy arrives as [B,P,P,Jp] with Jp > J zero-padded channels"""
+    from pixelwiseregression_amd import kernels as K
+    B, P, Cin, J, Jp = 2, 16, 64, 14, 16
+    x, g = rnd(B, Cin, P, P, seed=1), rnd(B, J, P, P, seed=2)
+    w = torch.zeros(J, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(q(x, dtype), w, None, padding=1).backward(q(g, dtype))
+    dyp = K.nchw_to_nhwc_pad(g.float().to(DEV), Jp, dtype)
+    assert dyp.shape == (B, P, P, Jp) and float(dyp[..., J:].abs().max()) == 0.0
+    assert_close(dyp[..., :J].double().cpu().permute(0, 3, 1, 2), q(g.float().double(), dtype), 1e-7, "transpose")
+    dw = K.conv_wgrad(nhwc(x, dtype), dyp, J, 3, 1, splits=4)
+    assert_close(dw.double().cpu(), w.grad, tol(dtype), "wgrad padded")
+    # and the matching data gradient: K dimension = Jp with a pack built from the J real channels
+    wt = rnd(J, Cin, 3, 3, seed=9, scale=0.05)
+    xg = torch.zeros(B, Cin, P, P, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xg, q(wt, dtype), None, padding=1).backward(q(g, dtype))
+    pack = K.pack_conv(wt.float().to(DEV), 1, K.BF16 if dtype == torch.bfloat16 else K.F32)
+    dx, _ = K.conv_fwd(dyp, pack, Cin, 3, 1)
+    assert_close(nchw(dx), xg.grad, tol(dtype), "dgrad padded")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S", [32, 128])
+def test_stem_conv(dtype, S):
+    from pixelwiseregression_amd import kernels as K
+    B, C0 = 3, 32
+    img, w, b = rnd(B, 1, S, S, seed=1), rnd(C0, 1, 3, 3, seed=2), rnd(C0, seed=3)
+    ref = F.conv2d(img.float().double(), w.float().double(), b.float().double(), padding=1)
+    y = K.stem_conv_fwd(img.float().to(DEV), w.float().to(DEV), b.float().to(DEV), dtype)
+    assert_close(nchw(y), ref, 1e-6 if dtype == torch.float32 else 5e-3, "stem fwd")
+    dy = rnd(B, C0, S, S, seed=4)
+    wz = torch.zeros(C0, 1, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(img.float().double(), wz, None, padding=1).backward(q(dy, dtype))
+    dw = K.stem_conv_wgrad(img.float().to(DEV), nhwc(dy, dtype), 3)
+    assert_close(dw.double().cpu(), wz.grad, 2e-5, "stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("J,P,Fo", [(14, 64, 128), (4, 16, 32), (21, 10, 64)])
+def test_catconv(dtype, J, P, Fo):
+    from pixelwiseregression_amd import kernels as K
+    B = 2
+    pm, dm, lb = rnd(B, J, P, P, seed=1).abs(), rnd(B, J, P, P, seed=2), rnd(B, 1, P, P, seed=3)
+    w, b = rnd(Fo, 2 * J + 1, 1, 1, seed=4, scale=0.2), rnd(Fo, seed=5)
+    cat = torch.cat([pm, dm, lb], 1).float().double().requires_grad_()
+    wd = w.float().double().requires_grad_()
+    bd = b.float().double().requires_grad_()
+    ref = F.conv2d(cat, wd, bd)
+    y = K.catconv_fwd(pm.float().to(DEV), dm.float().to(DEV), lb.float().to(DEV), w.float().view(Fo, -1).contiguous().to(DEV),
+                      b.float().to(DEV), dtype)
+    assert_close(nchw(y), ref.detach(), 1e-5 if dtype == torch.float32 else 5e-3, "catconv fwd")
+    dy = rnd(B, Fo, P, P, seed=6)
+    ref.backward(q(dy, dtype))
+    gp, gd = K.catconv_dgrad(nhwc(dy, dtype), w.float().view(Fo, -1).contiguous().to(DEV), J)
+    assert_close(gp.double().cpu(), cat.grad[:, :J], 2e-5, "catconv dgrad p")
+    assert_close(gd.double().cpu(), cat.grad[:, J:2 * J], 2e-5, "catconv dgrad d")
+    dw, db = K.catconv_wgrad(pm.float().to(DEV), dm.float().to(DEV), lb.float().to(DEV), nhwc(dy, dtype))
+    assert_close(dw.double().cpu(), wd.grad, 2e-5, "catconv wgrad")
+    assert_close(db.double().cpu(), bd.grad, 2e-5, "catconv bgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 128), (3, 2, 2, 64), (1, 128, 128, 32), (2, 5, 7, 16), (32, 4, 4, 64)])
+def test_instance_norm_stats_and_backward(dtype, B, H, W, C):
+    from pixelwiseregression_amd import kernels as K
+    y = rnd(B, C, H, W, seed=1) * (1 + rnd(1, C, 1, 1, seed=2).abs()) + 3 * rnd(1, C, 1, 1, seed=3)   # offsets >> std
+    gamma, beta = 1 + 0.2 * rnd(C, seed=4), 0.3 * rnd(C, seed=5)
+    yq = q(y, dtype).requires_grad_()
+    gd, bd = gamma.float().double().requires_grad_(), beta.float().double().requires_grad_()
+    out = torch.relu(F.instance_norm(yq, None, None, gd, bd, True, 0.1, 1e-5))
+    yd = nhwc(y, dtype)
+    mean, rstd, scale, shift = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=0)
+    mref = yq.detach().mean(dim=(2, 3))
+    vref = yq.detach().var(dim=(2, 3), unbiased=False)
+    assert_close(mean.double().cpu(), mref, 1e-5, "mean")
+    assert_close(rstd.double().cpu(), (vref + 1e-5).rsqrt(), 2e-5, "rstd")
+    # applying scale/shift reproduces relu(norm(y))
+    app = torch.relu(yq.detach() * scale.double().cpu()[:, :, None, None] + shift.double().cpu()[:, :, None, None])
+    assert_close(app, out.detach(), 2e-5, "apply")
+    g = rnd(B, C, H, W, seed=6)
+    add = rnd(B, C, H, W, seed=7)
+    out.backward(q(g, dtype))
+    dy, dgam, dbet = K.norm_bwd(nhwc(g, dtype), yd, mean, rstd, scale, shift, relu=True, addend=nhwc(add, dtype))
+    t = 5e-5 if dtype == torch.float32 else 2e-2
+    assert_close(nchw(dy), yq.grad + q(add, dtype), t, "norm bwd dy")
+    assert_close(dgam.double().cpu(), gd.grad, t, "dgamma")
+    assert_close(dbet.double().cpu(), bd.grad, t, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batch_norm_train_and_eval(dtype):
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, C = 4, 16, 16, 64
+    y = rnd(B, C, H, W, seed=1) + 2 * rnd(1, C, 1, 1, seed=3)
+    gamma, beta = 1 + 0.2 * rnd(C, seed=4), 0.3 * rnd(C, seed=5)
+    rm, rv = 0.1 * rnd(C, seed=8), 1 + 0.1 * rnd(C, seed=9).abs()
+    yq = q(y, dtype).requires_grad_()
+    gd, bd = gamma.float().double().requires_grad_(), beta.float().double().requires_grad_()
+    rm_ref, rv_ref = rm.float().double().clone(), rv.float().double().clone()
+    out = torch.relu(F.batch_norm(yq, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5))
+    yd = nhwc(y, dtype)
+    rmd, rvd = rm.float().to(DEV), rv.float().to(DEV)
+    mean, rstd, scale, shift = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=1, running_mean=rmd,
+                                            running_var=rvd)
+    assert_close(rmd.double().cpu(), rm_ref, 1e-5, "running_mean")
+    assert_close(rvd.double().cpu(), rv_ref, 1e-5, "running_var")
+    app = torch.relu(yq.detach() * scale.double().cpu()[:, :, None, None] + shift.double().cpu()[:, :, None, None])
+    assert_close(app, out.detach(), 2e-5, "bn apply")
+    g = rnd(B, C, H, W, seed=6)
+    out.backward(q(g, dtype))
+    dy, dgam, dbet = K.norm_bwd(nhwc(g, dtype), yd, mean, rstd, scale, shift, relu=True, mode=1)
+    t = 5e-5 if dtype == torch.float32 else 2e-2
+    assert_close(nchw(dy), yq.grad, t, "bn bwd dy")
+    assert_close(dgam.double().cpu(), gd.grad, t, "bn dgamma")
+    # eval mode
+    ref_eval = torch.relu(F.batch_norm(q(y, dtype), rm.float().double(), rv.float().double(), gamma.float().double(),
+                                       beta.float().double(), False, 0.1, 1e-5))
+    _, _, sc2, sh2 = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=2, running_mean=rm.float().to(DEV),
+                                  running_var=rv.float().to(DEV))
+    app = torch.relu(q(y, dtype) * sc2.double().cpu()[:, :, None, None] + sh2.double().cpu()[:, :, None, None])
+    assert_close(app, ref_eval, 2e-5, "bn eval apply")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 128), (2, 5, 7, 16), (3, 2, 2, 64)])
+def test_maxpool_and_upsample(dtype, B, H, W, C):
+    from pixelwiseregression_amd import kernels as K
+    x = q(rnd(B, C, H, W, seed=1), dtype).requires_grad_()
+    h = F.max_pool2d(x, 2, stride=2)
+    xd = nhwc(x.detach(), dtype)
+    hd = K.maxpool_fwd(xd)
+    assert_close(nchw(hd), h.detach(), 1e-7, "maxpool fwd")
+    h2 = q(rnd(*h.shape, seed=2), dtype).requires_grad_()
+    up = F.interpolate(h2, size=(H, W)) + x
+    upd = K.upsample_add(nhwc(h2.detach(), dtype), xd)
+    assert_close(nchw(upd), q(up.detach(), dtype), 1e-7 if dtype == torch.float32 else 8e-3, "upsample add")
+    g = q(rnd(B, C, H, W, seed=3), dtype)
+    gh = q(rnd(*h.shape, seed=4), dtype)
+    (up * g).sum().backward()
+    dh = K.upsample_bwd(nhwc(g, dtype), h.shape[2], h.shape[3])
+    assert_close(nchw(dh), h2.grad, 1e-6 if dtype == torch.float32 else 8e-3, "upsample bwd")
+    x.grad = None
+    (h * gh).sum().backward()
+    dx = K.maxpool_bwd(xd, nhwc(gh, dtype), addend=nhwc(g, dtype))
+    assert_close(nchw(dx), q(x.grad + g, dtype), 1e-6 if dtype == torch.float32 else 8e-3, "maxpool bwd")
