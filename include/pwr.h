@@ -145,6 +145,45 @@ int pwr_upsample_bwd(const void* dout, void* dh, int B, int Hi, int Wi, int Ho, 
 /* fp32 [B,J,N] -> `dtype` [B,N,Jp] with channels >= J zero (feeds decoder gradients to the head convs) */
 int pwr_nchw_to_nhwc_pad(const float* src, void* dst, int B, int J, int N, int Jp, int dtype, void* stream);
 int pwr_add_inplace(const void* x, void* y, long long n, int dtype, void* stream);
+/* bias gradients: out[c] (+)= sum_m x[m][c] for NHWC [M,C] (slab: pwr_colsum_blocks(M)*C floats); and
+ * out[j] (+)= sum_{b,n} x[b][j][n] for fp32 NCHW planes */
+int pwr_colsum_blocks(long long M);
+int pwr_colsum_nhwc(const void* x, float* slab, float* out, long long M, int C, int accumulate, int dtype, void* stream);
+int pwr_planesum_nchw(const float* x, float* out, int B, int J, int N, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Network engine: PixelwiseRegression.forward (model.py:200-210) and its backward as ONE static launch plan
+ * per (config, batch, dtype, training).  Python makes one call per forward / backward segment.
+ * ------------------------------------------------------------------------------------------- */
+const char* pwr_last_error(void);
+
+/* cfg: 8 ints {joints, stage, label_size, features, level, kernel_size, norm (0 instance, 1 batch),
+ * heatmap_method}.  param_off/param_numel: offset (floats into the flat parameter buffer) and element count of
+ * every parameter in the reference's named_parameters() order.  buffer_off: offsets (floats into the flat
+ * buffer of BatchNorm running statistics) of running_mean, running_var per norm layer in module order
+ * (NULL / 0 for instance norm).  Host pointers.  Returns NULL on error (see pwr_last_error). */
+void* pwr_engine_create(const int* cfg, int B, int dtype, int training, const long long* param_off,
+                        const long long* param_numel, int n_params, const long long* buffer_off, int n_buffers);
+void pwr_engine_destroy(void* engine);
+size_t pwr_engine_arena_bytes(void* engine);   /* activation + gradient + scratch arena the caller must provide */
+size_t pwr_engine_pack_bytes(void* engine);    /* packed-weight buffer (includes the descriptor table) */
+size_t pwr_engine_desc_offset(void* engine);   /* where in the pack buffer the descriptor table must be uploaded */
+size_t pwr_engine_desc_bytes(void* engine);
+int pwr_engine_get_descs(void* engine, void* host_dst);
+int pwr_engine_num_segments(void* engine);     /* backward segments: stage S-1, ..., stage 0, stem */
+int pwr_engine_num_launch_ops(void* engine, int which); /* 0 forward, 1 backward: number of fused launch groups */
+/* arena, packs, flat params, flat grads, flat BN buffers (device pointers, owned by the caller) */
+int pwr_engine_bind(void* engine, void* arena, void* packs, const float* params, float* grads, float* buffers);
+int pwr_engine_pack(void* engine, void* stream);
+/* img [B,1,S,S], label_img / mask [B,1,P,P] fp32.  outs: HOST array of 3*stage device pointers
+ * {heatmaps [B,J,P,P], depthmaps [B,J,P,P], uvd [B,J,3]} per stage (fp32), written by the call. */
+int pwr_engine_forward(void* engine, const float* img, const float* label, const float* mask, void* const* outs,
+                       int training, void* stream);
+long long pwr_engine_generation(void* engine);
+/* gouts: HOST array of 3*stage device pointers with the gradients of the outputs (NULL = zero).  Runs backward
+ * segment `seg`; segment 0 first zeroes grads[0:n_grad_floats].  Parameter gradients are written (not
+ * accumulated) into the bound flat gradient buffer, in the layout of the parameters. */
+int pwr_engine_backward(void* engine, const void* const* gouts, int seg, long long n_grad_floats, void* stream);
 
 #ifdef __cplusplus
 }

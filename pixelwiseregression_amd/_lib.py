@@ -13,7 +13,7 @@ ABI_VERSION = 1
 _lib = None
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong,
-           "void": None}
+           "void": None, "void*": ctypes.c_void_p, "const char*": ctypes.c_char_p}
 
 
 def _parse_header():
@@ -22,7 +22,7 @@ def _parse_header():
     hdr = os.path.join(os.path.dirname(_HERE), "include", "pwr.h")
     txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
     sigs = {}
-    for m in re.finditer(r"\b(int|size_t|void)\s+(pwr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+    for m in re.finditer(r"\b(int|size_t|void\*|void|long long|const char\*)\s+(pwr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != "void":
@@ -63,7 +63,12 @@ def lib():
 
 def check(code, what):
     if code != 0:
-        raise PwrError("%s failed with code %d" % (what, code))
+        msg = ""
+        try:
+            msg = (lib().pwr_last_error() or b"").decode()
+        except Exception:
+            pass
+        raise PwrError("%s failed with code %d %s" % (what, code, msg))
 
 
 def ptr(t):

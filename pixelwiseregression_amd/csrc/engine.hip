@@ -1,0 +1,614 @@
+// Network engine: the whole PixelwiseRegression forward / backward as one static launch plan.
+//
+// The reference's forward (model.py:200-210) is ~350 ATen calls issued from Python per step; here the
+// module's topology (stem -> stage x [1x1 -> hourglass -> plane/depth heads -> decoder]) is compiled
+// once per (config, batch, dtype, training) into a list of kernel launches over a pre-planned arena:
+// no allocation, no Python, no tracing compiler between kernels.  Activations stay resident in HBM
+// for the backward pass (288 GB: nothing is recomputed except the fused norm+ReLU on operand load).
+//
+// Parameter order contract: the `params` table passed to pwr_engine_create lists (offset, numel) of
+// every parameter in the reference's named_parameters() order; the builder
+// consumes it in the same traversal and verifies every numel.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "pwr.h"
+
+namespace {
+
+struct Ctx {
+  char* arena = nullptr;
+  char* packs = nullptr;
+  const float* params = nullptr;
+  float* grads = nullptr;
+  float* buffers = nullptr;  // BatchNorm running stats (flat)
+  const float* img = nullptr;
+  const float* label = nullptr;
+  const float* mask = nullptr;
+  float* out_p[8] = {};
+  float* out_D[8] = {};
+  float* out_uvd[8] = {};
+  const float* g_p[8] = {};
+  const float* g_D[8] = {};
+  const float* g_uvd[8] = {};
+  void* stream = nullptr;
+  int training = 1;
+};
+
+typedef std::function<int(Ctx&)> Op;
+
+struct Tn {  // NHWC activation in the arena
+  size_t off = 0, goff = 0;
+  int H = 0, W = 0, C = 0;
+};
+struct NormL {
+  size_t mean, rstd, scale, shift;
+  long long gamma, beta, rm = -1, rv = -1;
+  int C;
+};
+struct ConvL {
+  long long w, b;
+  size_t pack_f = 0, pack_d = 0;
+  int Cin, Cout, k, stride;
+};
+struct PackDescHost {
+  long long src_off, dst_off;
+  int Cout, Cin, ksize, kind, rows_pad, KCH, dtype, pad_;
+};
+
+struct Engine {
+  // config
+  int J, stages, P, F, level, ks, norm_mode, method;
+  int B, dtype, training;
+  int esz;
+  // parameter table
+  std::vector<long long> poff, pnum;
+  size_t pcur = 0;
+  std::vector<long long> boff;  // running stat buffers (rm, rv per norm) offsets
+  size_t bcur = 0;
+  // plan
+  size_t arena_bytes = 0, pack_bytes = 0;
+  std::vector<Op> fwd;
+  std::vector<std::vector<Op>> bwd;  // per segment, already in execution order
+  std::vector<Op> bwd_cur;           // segment being built (reverse order)
+  std::vector<PackDescHost> descs;
+  size_t desc_dev_off = 0;  // descs live at the start of the pack buffer
+  // shared scratch
+  size_t scr_partial = 0, scr_S1 = 0, scr_S2 = 0, scr_slab = 0, scr_slab_bytes = 0;
+  size_t need_partial = 0, need_sc = 0;
+  std::string err;
+  long long generation = 0;
+  Ctx ctx;
+
+  size_t alloc(size_t bytes) {
+    size_t o = arena_bytes;
+    arena_bytes += (bytes + 255) / 256 * 256;
+    return o;
+  }
+  size_t alloc_pack(size_t bytes) {
+    size_t o = pack_bytes;
+    pack_bytes += (bytes + 255) / 256 * 256;
+    return o;
+  }
+  Tn tensor(int H, int W, int C, bool grad) {
+    Tn t;
+    t.H = H; t.W = W; t.C = C;
+    t.off = alloc((size_t)B * H * W * C * esz);
+    if (grad) t.goff = alloc((size_t)B * H * W * C * esz);
+    return t;
+  }
+  long long take_param(long long numel) {
+    if (pcur >= poff.size()) { err = "parameter table too short"; return 0; }
+    if (pnum[pcur] != numel) {
+      char b[128];
+      snprintf(b, sizeof b, "parameter %zu: expected %lld elements, table has %lld", pcur, numel, pnum[pcur]);
+      err = b;
+    }
+    return poff[pcur++];
+  }
+  long long take_buffer() {
+    if (bcur >= boff.size()) { err = "buffer table too short"; return 0; }
+    return boff[bcur++];
+  }
+  void want_slab(size_t bytes) { if (bytes > scr_slab_bytes) scr_slab_bytes = bytes; }
+
+  // ---------------------------------------------------------------- layer constructors
+  ConvL conv_params(int cin, int cout, int k, int stride, bool mfma, bool need_dgrad) {
+    ConvL c;
+    c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride;
+    c.w = take_param((long long)cout * cin * k * k);
+    c.b = take_param(cout);
+    if (mfma) {
+      PackDescHost d;
+      const int KE = dtype == PWR_BF16 ? 32 : 16;
+      c.pack_f = alloc_pack(pwr_conv_pack_bytes(cout, cin, k, 0, dtype));
+      d = {c.w, (long long)c.pack_f, cout, cin, k, 0, pwr_conv_out_pad(cout), (cin + KE - 1) / KE, dtype, 0};
+      descs.push_back(d);
+      if (need_dgrad && training) {
+        const int kind = stride == 2 ? 2 : 1;
+        c.pack_d = alloc_pack(pwr_conv_pack_bytes(cout, cin, k, kind, dtype));
+        d = {c.w, (long long)c.pack_d, cout, cin, k, kind, pwr_conv_out_pad(cin), (cout + KE - 1) / KE, dtype, 0};
+        descs.push_back(d);
+      }
+    }
+    return c;
+  }
+  NormL norm_params(int C) {
+    NormL n;
+    n.C = C;
+    n.gamma = take_param(C);
+    n.beta = take_param(C);
+    if (norm_mode == 1) { n.rm = take_buffer(); n.rv = take_buffer(); }
+    n.mean = alloc((size_t)B * C * 4); n.rstd = alloc((size_t)B * C * 4);
+    n.scale = alloc((size_t)B * C * 4); n.shift = alloc((size_t)B * C * 4);
+    return n;
+  }
+  int splits_for(int M, int cin, int cout, int k) const {
+    const int KE = dtype == PWR_BF16 ? 32 : 16;
+    const int steps = (M + KE - 1) / KE;
+    const int tiles = k * k * ((cin + 127) / 128) * (pwr_conv_out_pad(cout) / (cout > 64 ? 128 : (cout > 32 ? 64 : 32)));
+    int s = (768 + tiles - 1) / tiles;
+    const int maxs = steps / 8 > 0 ? steps / 8 : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return s;
+  }
+
+  // ---- norm statistics of tensor t (forward) and its backward (g -> dy, in place in t.goff, + addend)
+  void norm_fwd(const Tn& t, const NormL& n) {
+    const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype;
+    const size_t pb = pwr_norm_partial_bytes(B, HW, C);
+    if (pb > need_partial) need_partial = pb;
+    if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
+    const int nm = norm_mode;
+    Engine* E = this;
+    fwd.push_back([=](Ctx& c) {
+      int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+      float* rm = n.rm >= 0 ? c.buffers + n.rm : nullptr;
+      float* rv = n.rv >= 0 ? c.buffers + n.rv : nullptr;
+      return pwr_norm_stats(c.arena + t.off, c.params + n.gamma, c.params + n.beta, rm, rv,
+                            (float*)(c.arena + E->scr_partial), (float*)(c.arena + n.mean), (float*)(c.arena + n.rstd),
+                            (float*)(c.arena + n.scale), (float*)(c.arena + n.shift), Bc, HW, C, mode, 1e-5f, 0.1f, dt, c.stream);
+    });
+  }
+  // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
+  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend) {
+    const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
+    Engine* E = this;
+    bwd_cur.push_back([=](Ctx& c) {
+      int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+      return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.mean), (float*)(c.arena + n.rstd),
+                          (float*)(c.arena + n.scale), (float*)(c.arena + n.shift), (float*)(c.arena + E->scr_partial),
+                          (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
+                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0,
+                          1, Bc, HW, C, mode, dt, c.stream);
+    });
+  }
+
+  // ---- MFMA conv: y = conv(NR(x)) + bias (+ residual)
+  Tn conv_fwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn* residual, bool grad) {
+    const int pad = cv.k / 2;
+    const int Ho = (x.H + 2 * pad - cv.k) / cv.stride + 1, Wo = (x.W + 2 * pad - cv.k) / cv.stride + 1;
+    Tn y = tensor(Ho, Wo, cv.Cout, grad);
+    const int Bc = B, dt = dtype;
+    const bool has_nr = nr != nullptr;
+    const NormL n = has_nr ? *nr : NormL{};
+    const bool has_res = residual != nullptr;
+    const size_t roff = has_res ? residual->off : 0;
+    fwd.push_back([=](Ctx& c) {
+      return pwr_conv_fwd(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.scale) : nullptr,
+                          has_nr ? (float*)(c.arena + n.shift) : nullptr, 1, has_res ? c.arena + roff : nullptr, c.arena + y.off,
+                          nullptr, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride, 0, dt, c.stream);
+    });
+    return y;
+  }
+  // backward of conv_fwd given y.goff complete.  Writes dW (and db if bias_grad), then dgrad into x.goff
+  // (accumulating onto x.goff when accumulate_dx).  The caller applies norm_bwd afterwards when nr != null.
+  void conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx) {
+    const int Bc = B, dt = dtype;
+    const bool has_nr = nr != nullptr;
+    const NormL n = has_nr ? *nr : NormL{};
+    const int M = B * y.H * y.W;
+    const int splits = splits_for(M, cv.Cin, cv.Cout, cv.k);
+    want_slab(pwr_conv_wgrad_slab_bytes(cv.Cout, cv.Cin, cv.k, splits));
+    want_slab((size_t)pwr_colsum_blocks(M) * cv.Cout * 4);
+    Engine* E = this;
+    bwd_cur.push_back([=](Ctx& c) {
+      int rc = pwr_conv_wgrad(c.arena + x.off, c.arena + y.goff, has_nr ? (float*)(c.arena + n.scale) : nullptr,
+                              has_nr ? (float*)(c.arena + n.shift) : nullptr, 1, (float*)(c.arena + E->scr_slab), c.grads + cv.w, 0,
+                              Bc, x.H, x.W, cv.Cin, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c.stream);
+      if (rc) return rc;
+      if (bias_grad || (E->norm_mode == 1 && !c.training))
+        rc = pwr_colsum_nhwc(c.arena + y.goff, (float*)(c.arena + E->scr_slab), c.grads + cv.b, (long long)M, cv.Cout, 0, dt, c.stream);
+      if (rc || !need_dx) return rc;
+      if (cv.stride == 1)
+        return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, nullptr, 0,
+                            accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k,
+                            1, 0, dt, c.stream);
+      return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, nullptr, 0,
+                          accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k, 1,
+                          1, dt, c.stream);
+    });
+  }
+
+  // ---- ResBlock (model.py:6-23)
+  struct ResB { NormL na, nb, nc; ConvL ca, cb, cc; Tn t1, t2; };
+  Tn resblock(const Tn& x) {
+    const bool tr = training;
+    ResB r;
+    const int Fh = x.C / 2;
+    r.na = norm_params(x.C);
+    r.ca = conv_params(x.C, Fh, 1, 1, true, true);
+    r.nb = norm_params(Fh);
+    r.cb = conv_params(Fh, Fh, 3, 1, true, true);
+    r.nc = norm_params(Fh);
+    r.cc = conv_params(Fh, x.C, 1, 1, true, true);
+    norm_fwd(x, r.na);
+    r.t1 = conv_fwd(x, &r.na, r.ca, nullptr, tr);
+    norm_fwd(r.t1, r.nb);
+    r.t2 = conv_fwd(r.t1, &r.nb, r.cb, nullptr, tr);
+    norm_fwd(r.t2, r.nc);
+    Tn out = conv_fwd(r.t2, &r.nc, r.cc, &x, tr);
+    if (tr) {
+      // reverse order: pushed first = executed last
+      std::vector<Op> blk;
+      std::swap(blk, bwd_cur);
+      conv_bwd(r.t2, &r.nc, r.cc, out, true, true, false);
+      norm_bwd(r.t2, r.nc, 0, false);
+      conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, true, false);
+      norm_bwd(r.t1, r.nb, 0, false);
+      conv_bwd(x, &r.na, r.ca, r.t1, false, true, false);
+      norm_bwd(x, r.na, out.goff, true);  // x.g = out.g (skip) + NRbwd(g)
+      append_block(blk);
+    }
+    return out;
+  }
+  // bwd_cur currently holds one block's ops in execution order; `prev` holds blocks built earlier (which must run
+  // AFTER this one).  Result: bwd_cur = this block followed by prev.
+  void append_block(std::vector<Op>& prev) {
+    bwd_cur.insert(bwd_cur.end(), prev.begin(), prev.end());
+  }
+
+  // ---- Hourglass (model.py:25-47)
+  Tn hourglass(const Tn& x, int lvl) {
+    const bool tr = training;
+    const int Bc = B, dt = dtype;
+    Tn a = resblock(x);
+    Tn h0 = tensor(a.H / 2, a.W / 2, a.C, tr);
+    fwd.push_back([=](Ctx& c) { return pwr_maxpool_fwd(c.arena + a.off, c.arena + h0.off, Bc, a.H, a.W, a.C, dt, c.stream); });
+    // the ops pushed by resblock(x) must run after everything below: take them out, put them back at the end
+    std::vector<Op> after_a;
+    std::swap(after_a, bwd_cur);
+    Tn h1 = lvl > 0 ? hourglass(h0, lvl - 1) : resblock(h0);
+    std::vector<Op> after_inner;
+    std::swap(after_inner, bwd_cur);
+    Tn h2 = resblock(h1);
+    std::vector<Op> after_h2;
+    std::swap(after_h2, bwd_cur);
+    Tn out = tensor(a.H, a.W, a.C, tr);
+    fwd.push_back([=](Ctx& c) {
+      return pwr_upsample_add_fwd(c.arena + h2.off, c.arena + a.off, c.arena + out.off, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream);
+    });
+    if (tr) {
+      bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
+      bwd_cur.insert(bwd_cur.end(), after_h2.begin(), after_h2.end());        // resblock h1 -> h2
+      bwd_cur.insert(bwd_cur.end(), after_inner.begin(), after_inner.end());  // inner
+      bwd_cur.push_back([=](Ctx& c) {
+        return pwr_maxpool_bwd(c.arena + a.off, c.arena + h0.goff, c.arena + out.goff, c.arena + a.goff, Bc, a.H, a.W, a.C, dt, c.stream);
+      });
+      bwd_cur.insert(bwd_cur.end(), after_a.begin(), after_a.end());          // resblock x -> a
+    }
+    return out;
+  }
+
+  // ---- one regression head (model.py:54-65 / 103-114) ending in an NCHW fp32 map
+  struct Head { ConvL c0, c1, c2, c3; NormL n0, n1, n2; Tn h1, h2, h3; size_t gT; };
+  // out_sel: 0 -> logits z in the arena (z_off), 1 -> external depthmaps output
+  Head head_fwd(const Tn& f, size_t z_off, int out_sel, int stage_idx) {
+    const bool tr = training;
+    const int Bc = B, dt = dtype, Jc = J;
+    Head h;
+    h.c0 = conv_params(F, F, ks, 1, true, true); h.n0 = norm_params(F);
+    h.c1 = conv_params(F, F, ks, 1, true, true); h.n1 = norm_params(F);
+    h.c2 = conv_params(F, F, ks, 1, true, true); h.n2 = norm_params(F);
+    h.c3 = conv_params(F, J, ks, 1, true, true);
+    h.h1 = conv_fwd(f, nullptr, h.c0, nullptr, tr); norm_fwd(h.h1, h.n0);
+    h.h2 = conv_fwd(h.h1, &h.n0, h.c1, nullptr, tr); norm_fwd(h.h2, h.n1);
+    h.h3 = conv_fwd(h.h2, &h.n1, h.c2, nullptr, tr); norm_fwd(h.h3, h.n2);
+    const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3;
+    fwd.push_back([=](Ctx& c) {
+      float* dst = out_sel == 0 ? (float*)(c.arena + z_off) : c.out_D[stage_idx];
+      return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.scale), (float*)(c.arena + n2.shift),
+                          1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
+    });
+    const int Jp = (J + 7) / 8 * 8;
+    h.gT = tr ? alloc((size_t)B * P * P * Jp * esz) : 0;
+    return h;
+  }
+  // g_nchw_off: arena offset of the fp32 [B,J,N] gradient of the head's output map
+  void head_bwd(const Tn& f, const Head& h, size_t g_nchw_off, bool accumulate_df) {
+    const int Bc = B, dt = dtype, Jc = J, Pc = P;
+    const int Jp = (J + 7) / 8 * 8;
+    const int M = B * P * P;
+    const int splits = splits_for(M, F, Jp, ks);
+    want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits));
+    Engine* E = this;
+    const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3; const size_t gT = h.gT;
+    bwd_cur.push_back([=](Ctx& c) {
+      int rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + g_nchw_off), c.arena + gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
+      if (rc) return rc;
+      rc = pwr_planesum_nchw((const float*)(c.arena + g_nchw_off), c.grads + c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
+      if (rc) return rc;
+      rc = pwr_conv_wgrad(c.arena + h3.off, c.arena + gT, (float*)(c.arena + n2.scale), (float*)(c.arena + n2.shift), 1,
+                          (float*)(c.arena + E->scr_slab), c.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c.stream);
+      if (rc) return rc;
+      return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
+                          Jp, c3.Cin, c3.k, 1, 0, dt, c.stream);
+    });
+    norm_bwd(h.h3, h.n2, 0, false);
+    conv_bwd(h.h2, &h.n1, h.c2, h.h3, false, true, false);
+    norm_bwd(h.h2, h.n1, 0, false);
+    conv_bwd(h.h1, &h.n0, h.c1, h.h2, false, true, false);
+    norm_bwd(h.h1, h.n0, 0, false);
+    conv_bwd(f, nullptr, h.c0, h.h1, false, true, accumulate_df);
+  }
+
+  // ---------------------------------------------------------------- whole network
+  bool build() {
+    const bool tr = training;
+    const int Bc = B, dt = dtype, Jc = J, Pc = P, Fc = F, S = 2 * P, N = P * P, meth = method;
+    if (F % 32 || F < 32) { err = "features must be a multiple of 32 for the MI355X engine"; return false; }
+    if (stages > 8) { err = "at most 8 stages"; return false; }
+    if (J > 47) { err = "at most 47 joints"; return false; }
+    Engine* E = this;
+    // ---- stem (model.py:164-187)
+    std::vector<ConvL> sc;
+    std::vector<NormL> sn;
+    std::vector<Tn> sy;
+    {
+      ConvL c0 = conv_params(1, 32, ks, 1, false, false);
+      NormL n0 = norm_params(32);
+      Tn y0 = tensor(S, S, 32, tr);
+      fwd.push_back([=](Ctx& c) { return pwr_stem_conv_fwd(c.img, c.params + c0.w, c.params + c0.b, c.arena + y0.off, Bc, S, 32, E->ks, dt, c.stream); });
+      norm_fwd(y0, n0);
+      sc.push_back(c0); sn.push_back(n0); sy.push_back(y0);
+      int cch = 32;
+      while (cch < F) {
+        const int nx = 2 * cch < F ? 2 * cch : F;
+        ConvL cv = conv_params(cch, nx, ks, 1, true, true);
+        NormL nn = norm_params(nx);
+        Tn y = conv_fwd(sy.back(), &sn.back(), cv, nullptr, tr);
+        norm_fwd(y, nn);
+        sc.push_back(cv); sn.push_back(nn); sy.push_back(y);
+        cch = nx;
+      }
+      ConvL cl = conv_params(F, F, ks, 2, true, true);
+      NormL nl = norm_params(F);
+      Tn yl = conv_fwd(sy.back(), &sn.back(), cl, nullptr, tr);
+      norm_fwd(yl, nl);
+      sc.push_back(cl); sn.push_back(nl); sy.push_back(yl);
+    }
+    std::vector<Op> stem_bwd;
+    if (tr) {
+      const int ns = (int)sc.size();
+      want_slab((size_t)pwr_stem_conv_wgrad_blocks(B, S) * 32 * ks * ks * 4);
+      for (int i = ns - 1; i >= 1; --i) {
+        norm_bwd(sy[i], sn[i], 0, false);
+        conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false);
+      }
+      norm_bwd(sy[0], sn[0], 0, false);
+      const Tn y0 = sy[0]; const ConvL c0 = sc[0];
+      bwd_cur.push_back([=](Ctx& c) {
+        return pwr_stem_conv_wgrad(c.img, c.arena + y0.goff, (float*)(c.arena + E->scr_slab), c.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c.stream);
+      });
+      std::swap(stem_bwd, bwd_cur);
+    }
+    // ---- stages
+    struct StageRec { size_t z, gz, gDt, gH, gD, gwp; long long w_off; };
+    std::vector<StageRec> recs(stages);
+    std::vector<std::vector<Op>> stage_bwd(stages);
+    const Tn ystem = sy.back();
+    const NormL nstem = sn.back();
+    for (int s = 0; s < stages; ++s) {
+      StageRec& R = recs[s];
+      Tn x0;
+      ConvL cin;
+      if (s == 0) {
+        cin = conv_params(F, F, 1, 1, true, true);
+      } else {
+        cin = conv_params(2 * J + 1, F, 1, 1, false, false);
+      }
+      // hourglass params come before the heads' in named_parameters order; plane_regression.w comes first in its module
+      if (s == 0) {
+        x0 = conv_fwd(ystem, &nstem, cin, nullptr, tr);
+      } else {
+        x0 = tensor(P, P, F, tr);
+        const int sp = s - 1;
+        fwd.push_back([=](Ctx& c) {
+          return pwr_catconv_fwd(c.out_p[sp], c.out_D[sp], c.label, c.params + cin.w, c.params + cin.b, c.arena + x0.off, Bc, N, Jc, Fc, dt, c.stream);
+        });
+      }
+      std::vector<Op> saved;
+      std::swap(saved, bwd_cur);  // (empty) -- keep bwd_cur clean for the hourglass
+      Tn f = hourglass(x0, level);
+      std::vector<Op> hg_bwd;
+      std::swap(hg_bwd, bwd_cur);
+      R.w_off = method == 0 ? take_param(J) : -1;
+      R.z = alloc((size_t)B * J * N * 4);
+      Head hp = head_fwd(f, R.z, 0, s);
+      Head hd = head_fwd(f, 0, 1, s);
+      const size_t zoff = R.z;
+      const long long woff = R.w_off;
+      fwd.push_back([=](Ctx& c) {
+        return pwr_decode_fwd((const float*)(c.arena + zoff), c.out_D[s], c.label, c.mask, woff >= 0 ? c.params + woff : nullptr, c.out_p[s],
+                              c.out_uvd[s], Bc, Jc, Pc, meth, c.stream);
+      });
+      if (tr) {
+        R.gz = alloc((size_t)B * J * N * 4); R.gDt = alloc((size_t)B * J * N * 4);
+        R.gH = alloc((size_t)B * J * N * 4); R.gD = alloc((size_t)B * J * N * 4);
+        R.gwp = alloc((size_t)B * J * 4);
+        const StageRec Rc = R;
+        const bool last = s == stages - 1;
+        const size_t zero_uvd = alloc((size_t)B * J * 3 * 4);
+        // decoder backward: coupling gradients (from stage s+1, already in gH/gD) + external gradients
+        bwd_cur.push_back([=](Ctx& c) {
+          const float* gH = nullptr; const float* gD = nullptr;
+          const long long n = (long long)Bc * Jc * N;
+          int rc = 0;
+          if (!last) {
+            gH = (const float*)(c.arena + Rc.gH); gD = (const float*)(c.arena + Rc.gD);
+            if (c.g_p[s]) rc = pwr_add_inplace(c.g_p[s], c.arena + Rc.gH, n, PWR_F32, c.stream);
+            if (!rc && c.g_D[s]) rc = pwr_add_inplace(c.g_D[s], c.arena + Rc.gD, n, PWR_F32, c.stream);
+            if (rc) return rc;
+          } else {
+            gH = c.g_p[s]; gD = c.g_D[s];
+          }
+          const float* gU = c.g_uvd[s];
+          if (!gU) {
+            hipMemsetAsync(c.arena + zero_uvd, 0, (size_t)Bc * Jc * 3 * 4, (hipStream_t)c.stream);
+            gU = (const float*)(c.arena + zero_uvd);
+          }
+          rc = pwr_decode_bwd(c.out_p[s], (const float*)(c.arena + Rc.z), c.out_D[s], c.label, c.mask, woff >= 0 ? c.params + woff : nullptr,
+                              c.out_uvd[s], gH, gD, gU, (float*)(c.arena + Rc.gz), (float*)(c.arena + Rc.gDt),
+                              woff >= 0 ? (float*)(c.arena + Rc.gwp) : nullptr, Bc, Jc, Pc, meth, c.stream);
+          if (rc || woff < 0) return rc;
+          return pwr_decode_gw_reduce((const float*)(c.arena + Rc.gwp), c.grads + woff, Bc, Jc, 0, c.stream);
+        });
+        head_bwd(f, hp, R.gz, false);
+        head_bwd(f, hd, R.gDt, true);
+        bwd_cur.insert(bwd_cur.end(), hg_bwd.begin(), hg_bwd.end());
+        // stage-input conv backward
+        if (s == 0) {
+          conv_bwd(ystem, &nstem, cin, x0, true, true, false);
+        } else {
+          const int sp = s - 1;
+          const StageRec Rp = recs[sp];
+          want_slab((size_t)pwr_catconv_wgrad_blocks(B, N) * (2 * J + 2) * F * 4);
+          bwd_cur.push_back([=](Ctx& c) {
+            int rc = pwr_catconv_wgrad(c.out_p[sp], c.out_D[sp], c.label, c.arena + x0.goff, (float*)(c.arena + E->scr_slab), c.grads + cin.w,
+                                       c.grads + cin.b, 0, Bc, N, Jc, Fc, dt, c.stream);
+            if (rc) return rc;
+            return pwr_catconv_dgrad(c.arena + x0.goff, c.params + cin.w, (float*)(c.arena + Rp.gH), (float*)(c.arena + Rp.gD), Bc, N, Jc, Fc, dt,
+                                     c.stream);
+          });
+        }
+        std::swap(stage_bwd[s], bwd_cur);
+      }
+    }
+    if (pcur != poff.size()) { err = "parameter table longer than the network"; return false; }
+    if (!err.empty()) return false;
+    // shared scratch
+    scr_partial = alloc(need_partial);
+    scr_S1 = alloc(need_sc); scr_S2 = alloc(need_sc);
+    scr_slab = alloc(scr_slab_bytes);
+    // segments in execution order: last stage first, stem last
+    if (tr) {
+      for (int s = stages - 1; s >= 0; --s) bwd.push_back(stage_bwd[s]);
+      bwd.push_back(stem_bwd);
+    }
+    // descriptor table lives in the pack buffer
+    desc_dev_off = alloc_pack(descs.size() * sizeof(PackDescHost));
+    return true;
+  }
+};
+
+thread_local std::string g_last_error;
+
+}  // namespace
+
+extern "C" const char* pwr_last_error(void) { return g_last_error.c_str(); }
+
+// cfg: {joints, stage, label_size, features, level, kernel_size, norm_mode (0 instance, 1 batch), heatmap_method}
+extern "C" void* pwr_engine_create(const int* cfg, int B, int dtype, int training, const long long* param_off,
+                                   const long long* param_numel, int n_params, const long long* buffer_off, int n_buffers) {
+  Engine* e = new Engine();
+  e->J = cfg[0]; e->stages = cfg[1]; e->P = cfg[2]; e->F = cfg[3]; e->level = cfg[4]; e->ks = cfg[5]; e->norm_mode = cfg[6];
+  e->method = cfg[7];
+  e->B = B; e->dtype = dtype; e->training = training; e->esz = dtype == PWR_BF16 ? 2 : 4;
+  e->poff.assign(param_off, param_off + n_params);
+  e->pnum.assign(param_numel, param_numel + n_params);
+  if (buffer_off) e->boff.assign(buffer_off, buffer_off + n_buffers);
+  if (!e->build()) {
+    g_last_error = e->err.empty() ? "engine build failed" : e->err;
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+extern "C" void pwr_engine_destroy(void* h) { delete (Engine*)h; }
+extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
+extern "C" size_t pwr_engine_pack_bytes(void* h) { return ((Engine*)h)->pack_bytes; }
+extern "C" int pwr_engine_num_segments(void* h) { return (int)((Engine*)h)->bwd.size(); }
+extern "C" int pwr_engine_num_launch_ops(void* h, int which) {
+  Engine* e = (Engine*)h;
+  if (which == 0) return (int)e->fwd.size();
+  int n = 0;
+  for (auto& s : e->bwd) n += (int)s.size();
+  return n;
+}
+extern "C" size_t pwr_engine_desc_offset(void* h) { return ((Engine*)h)->desc_dev_off; }
+extern "C" size_t pwr_engine_desc_bytes(void* h) { return ((Engine*)h)->descs.size() * sizeof(PackDescHost); }
+extern "C" int pwr_engine_get_descs(void* h, void* host_dst) {
+  Engine* e = (Engine*)h;
+  memcpy(host_dst, e->descs.data(), e->descs.size() * sizeof(PackDescHost));
+  return 0;
+}
+
+extern "C" int pwr_engine_bind(void* h, void* arena, void* packs, const float* params, float* grads, float* buffers) {
+  Engine* e = (Engine*)h;
+  e->ctx.arena = (char*)arena; e->ctx.packs = (char*)packs; e->ctx.params = params; e->ctx.grads = grads; e->ctx.buffers = buffers;
+  return 0;
+}
+
+// Re-pack every conv weight from the flat fp32 parameters (one launch).  The descriptor table must have been
+// uploaded to packs + pwr_engine_desc_offset().
+extern "C" int pwr_engine_pack(void* h, void* stream) {
+  Engine* e = (Engine*)h;
+  return pwr_pack_weights(e->ctx.params, e->ctx.packs, e->ctx.packs + e->desc_dev_off, (int)e->descs.size(), stream);
+}
+
+// outs: host array of 3*stage device pointers {heatmaps_s, depthmaps_s, uvd_s}
+extern "C" int pwr_engine_forward(void* h, const float* img, const float* label, const float* mask, void* const* outs, int training,
+                                  void* stream) {
+  Engine* e = (Engine*)h;
+  Ctx& c = e->ctx;
+  c.img = img; c.label = label; c.mask = mask; c.stream = stream; c.training = training;
+  for (int s = 0; s < e->stages; ++s) {
+    c.out_p[s] = (float*)outs[3 * s]; c.out_D[s] = (float*)outs[3 * s + 1]; c.out_uvd[s] = (float*)outs[3 * s + 2];
+  }
+  e->generation++;
+  for (size_t i = 0; i < e->fwd.size(); ++i) {
+    int rc = e->fwd[i](c);
+    if (rc) { char b[96]; snprintf(b, sizeof b, "forward op %zu failed with %d", i, rc); g_last_error = b; return rc; }
+  }
+  return 0;
+}
+extern "C" long long pwr_engine_generation(void* h) { return ((Engine*)h)->generation; }
+
+// gouts: host array of 3*stage device pointers (NULL = zero gradient).  Runs backward segment `seg`
+// (0 = last stage ... num_segments-1 = stem); segment 0 also zeroes the flat gradient buffer first.
+extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, long long n_grad_floats, void* stream) {
+  Engine* e = (Engine*)h;
+  Ctx& c = e->ctx;
+  if (!e->training || seg < 0 || seg >= (int)e->bwd.size()) return PWR_EINVAL;
+  c.stream = stream;
+  for (int s = 0; s < e->stages; ++s) {
+    c.g_p[s] = (const float*)gouts[3 * s]; c.g_D[s] = (const float*)gouts[3 * s + 1]; c.g_uvd[s] = (const float*)gouts[3 * s + 2];
+  }
+  if (seg == 0) {
+    hipError_t er = hipMemsetAsync(c.grads, 0, (size_t)n_grad_floats * 4, (hipStream_t)stream);
+    if (er != hipSuccess) return (int)er;
+  }
+  auto& ops = e->bwd[seg];
+  for (size_t i = 0; i < ops.size(); ++i) {
+    int rc = ops[i](c);
+    if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; return rc; }
+  }
+  return 0;
+}

@@ -243,3 +243,59 @@ extern "C" int pwr_add_inplace(const void* x, void* y, long long n, int dtype, v
   else hipLaunchKernelGGL((axpy_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n);
   return (int)hipGetLastError();
 }
+
+// ---- bias gradients: column sums ------------------------------------------------------------------
+namespace pwr {
+// NHWC [M][C] T -> slab[block][C]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ slab, long long M, int C,
+                                                             int rows_per_block) {
+  extern __shared__ float red[];   // [256/C' ...] sized 256 floats per row group
+  const int lanes_c = C < 256 ? C : 256;
+  const int pl = 256 / lanes_c;
+  const int pj = threadIdx.x / lanes_c, c0 = threadIdx.x % lanes_c;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  for (int c = c0; c < C; c += lanes_c) {
+    float s = 0.f;
+    if (pj < pl)
+      for (long long r = r0 + pj; r < r0 + rows_per_block && r < M; r += pl) s += Elem<T>::to_f(x[(size_t)r * C + c]);
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pj == 0) {
+      float t = 0.f;
+      for (int j = 0; j < pl; ++j) t += red[j * lanes_c + c0];
+      slab[(size_t)blockIdx.x * C + c] = t;
+    }
+  }
+}
+// NCHW fp32 [B][J][N] -> out[j] = sum_{b,n}
+__global__ __launch_bounds__(256) void planesum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int J, int N,
+                                                       int accumulate) {
+  __shared__ float red[4];
+  const int j = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int i = threadIdx.x; i < N; i += 256) s += x[((size_t)b * J + j) * N + i];
+  s = block_sum1(s, red);
+  if (threadIdx.x == 0) out[j] = accumulate ? out[j] + s : s;
+}
+}  // namespace pwr
+
+extern "C" int pwr_colsum_blocks(long long M) { long long nb = (M + 255) / 256; return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb)); }
+
+extern "C" int pwr_colsum_nhwc(const void* x, float* slab, float* out, long long M, int C, int accumulate, int dtype, void* stream) {
+  if (C > 256 && C % 256) return PWR_EUNSUPPORTED;
+  if (C < 256 && 256 % C) return PWR_EUNSUPPORTED;
+  const int nb = pwr_colsum_blocks(M);
+  const int rpb = (int)((M + nb - 1) / nb);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((pwr::colsum_partial_kernel<bf16_t>), dim3(nb), dim3(256), 1024, s, (const bf16_t*)x, slab, M, C, rpb);
+  else hipLaunchKernelGGL((pwr::colsum_partial_kernel<float>), dim3(nb), dim3(256), 1024, s, (const float*)x, slab, M, C, rpb);
+  return pwr_slab_reduce(slab, out, nb, C, accumulate, stream);
+}
+
+extern "C" int pwr_planesum_nchw(const float* x, float* out, int B, int J, int N, int accumulate, void* stream) {
+  hipLaunchKernelGGL(pwr::planesum_kernel, dim3(J), dim3(256), 0, (hipStream_t)stream, x, out, B, J, N, accumulate);
+  return (int)hipGetLastError();
+}

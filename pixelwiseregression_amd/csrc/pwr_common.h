@@ -50,6 +50,12 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
     v[i] = s;
   }
 }
+// block-wide sum of one value, 256 threads (4 waves); `red` needs 4 floats
+__device__ __forceinline__ float block_sum1(float v, float* red) {
+  float a[1] = {v};
+  block_sum<1, 4>(a, red);
+  return a[0];
+}
 template <int NWAVES>
 __device__ __forceinline__ float block_max(float v, float* red) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

@@ -1,2 +1,179 @@
+"""Python side of the network engine (csrc/engine.hip): plan cache, buffers, autograd glue.
+
+One ``_Plan`` per (batch, dtype, grad-enabled) holds the C++ launch plan, its activation arena and the
+packed weights.  A forward is ONE ctypes call; a backward is one call per segment (stage S-1 .. stage 0,
+stem) so that the flat gradient of a finished segment can be all-reduced (RCCL) while the next segment
+computes (ddp.py).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+
+
+class _Plan:
+    def __init__(self, model, B, dtype, need_grad):
+        l = _lib.lib()
+        self.model_ref = model
+        self.B, self.dtype, self.need_grad = B, dtype, need_grad
+        dev = model._flat.device
+        cfg = (ctypes.c_int * 8)(model.joints, model.stage, model.label_size, model.features, model.level, model.kernel_size,
+                                 0 if model.norm_method == "instance" else 1, 0 if model.heatmap_method == "softmax" else 1)
+        offs = [o for (o, _) in model._offsets.values()]
+        nums = [int(torch.Size(s).numel()) for (_, s) in model._offsets.values()]
+        n = len(offs)
+        poff = (ctypes.c_longlong * n)(*offs)
+        pnum = (ctypes.c_longlong * n)(*nums)
+        boffs = model._buffer_offsets
+        nb = len(boffs)
+        boff = (ctypes.c_longlong * max(nb, 1))(*boffs) if nb else None
+        self.h = l.pwr_engine_create(cfg, B, dtype, 1 if need_grad else 0, poff, pnum, n, boff, nb)
+        if not self.h:
+            raise _lib.PwrError("pwr_engine_create failed: %s" % (l.pwr_last_error() or b"").decode())
+        self.arena = torch.empty(l.pwr_engine_arena_bytes(self.h), dtype=torch.uint8, device=dev)
+        self.packs = torch.empty(l.pwr_engine_pack_bytes(self.h), dtype=torch.uint8, device=dev)
+        nd = l.pwr_engine_desc_bytes(self.h)
+        host = (ctypes.c_char * nd)()
+        l.pwr_engine_get_descs(self.h, host)
+        off = l.pwr_engine_desc_offset(self.h)
+        self.packs[off:off + nd].copy_(torch.frombuffer(bytearray(host.raw), dtype=torch.uint8))
+        self.n_seg = l.pwr_engine_num_segments(self.h)
+        self.packed_version = None
+        self.bound = None
+        self.outs_t = (ctypes.c_void_p * (3 * model.stage))
+
+    def bind(self, model, grads):
+        key = (model._flat.data_ptr(), grads.data_ptr() if grads is not None else 0,
+               model._flat_buf.data_ptr() if model._flat_buf is not None else 0)
+        if key != self.bound:
+            _lib.check(_lib.lib().pwr_engine_bind(self.h, self.arena.data_ptr(), self.packs.data_ptr(), key[0], key[1] or None,
+                                                  key[2] or None), "pwr_engine_bind")
+            self.bound = key
+            self.packed_version = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.lib().pwr_engine_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _get_plan(model, B, dtype, need_grad):
+    if model._engine is None:
+        model._engine = {}
+    key = (B, dtype, need_grad)
+    plan = model._engine.get(key)
+    if plan is None:
+        plan = _Plan(model, B, dtype, need_grad)
+        model._engine[key] = plan
+    return plan
+
+
+def _run_forward(model, plan, img, label_img, mask):
+    l = _lib.lib()
+    dev = img.device
+    B, J, P = plan.B, model.joints, model.label_size
+    plan.bind(model, model.flat_grad() if plan.need_grad else None)
+    stream = _lib.stream_ptr(dev)
+    ver = model._flat._version
+    if plan.packed_version != ver:
+        _lib.check(l.pwr_engine_pack(plan.h, stream), "pwr_engine_pack")
+        plan.packed_version = ver
+    outs = []
+    for _ in range(model.stage):
+        outs += [torch.empty(B, J, P, P, device=dev, dtype=torch.float32), torch.empty(B, J, P, P, device=dev, dtype=torch.float32),
+                 torch.empty(B, J, 3, device=dev, dtype=torch.float32)]
+    arr = plan.outs_t(*[t.data_ptr() for t in outs])
+    training = 1 if model.training else 0
+    _lib.check(l.pwr_engine_forward(plan.h, img.data_ptr(), label_img.data_ptr(), mask.data_ptr(), arr, training, stream),
+               "pwr_engine_forward")
+    if training and model._flat_nbt is not None:
+        model._flat_nbt += 1
+    return outs
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, trigger, model, plan, img, label_img, mask):
+        outs = _run_forward(model, plan, img, label_img, mask)
+        ctx.model, ctx.plan = model, plan
+        ctx.generation = _lib.lib().pwr_engine_generation(plan.h)
+        ctx.inputs = (img, label_img, mask)      # keep alive: the backward re-reads them
+        ctx.outs = outs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        model, plan = ctx.model, ctx.plan
+        l = _lib.lib()
+        if l.pwr_engine_generation(plan.h) != ctx.generation:
+            raise _lib.PwrError("backward() after another forward() of the same (batch, dtype) plan: the engine keeps one "
+                                "set of activations per plan. Call backward before the next training forward.")
+        dev = ctx.outs[0].device
+        stream = _lib.stream_ptr(dev)
+        keep = []
+        ptrs = []
+        for g, o in zip(gouts, ctx.outs):
+            if g is None:
+                ptrs.append(None)
+            else:
+                g = g.contiguous().float()
+                keep.append(g)
+                ptrs.append(g.data_ptr())
+        arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        # where do the gradients go?  Fresh (p.grad is None everywhere) -> straight into the flat buffer.
+        flat_grad = model.flat_grad()
+        views = model._grad_views()
+        params = model._param_list
+        fresh = all(p.grad is None for p in params)
+        target = flat_grad if fresh else model._grad_scratch()
+        plan.bind(model, target)
+        plan.packed_version = plan.packed_version  # packs unaffected by re-binding the gradient pointer
+        n = flat_grad.numel()
+        ddp = model._ddp
+        for seg in range(plan.n_seg):
+            _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
+            if ddp is not None and fresh:
+                ddp.segment_done(model, seg, plan.n_seg)
+        if fresh:
+            for p, v in zip(params, views):
+                if p.requires_grad:
+                    p.grad = v
+            if ddp is not None:
+                ddp.finish(model)
+        else:
+            sv = model._scratch_views()
+            for p, v, s in zip(params, views, sv):
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    v.copy_(s)
+                    p.grad = v
+                else:
+                    p.grad.add_(s)
+            if ddp is not None:
+                raise _lib.PwrError("gradient accumulation under the built-in data-parallel mode is not supported")
+        return (None,) * 6
+
+
 def engine_forward(model, img, label_img, mask):
-    raise NotImplementedError("native engine under construction")
+    B = img.shape[0]
+    S, P = 2 * model.label_size, model.label_size
+    if tuple(img.shape) != (B, 1, S, S) or tuple(label_img.shape) != (B, 1, P, P) or tuple(mask.shape) != (B, 1, P, P):
+        # the reference fails at .view(1,1,H,W) (model.py:92) when image side != 2*label_size
+        raise RuntimeError("expected img [B,1,%d,%d], label_img/mask [B,1,%d,%d]; got %s %s %s" %
+                           (S, S, P, P, tuple(img.shape), tuple(label_img.shape), tuple(mask.shape)))
+    model._check_flat()
+    img, label_img, mask = (t.contiguous().float() for t in (img, label_img, mask))
+    dtype = BF16 if (model._precision == "bf16" or torch.is_autocast_enabled()) else F32
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model._param_list)
+    plan = _get_plan(model, B, dtype, need_grad)
+    if need_grad:
+        outs = _EngineFn.apply(model._trigger(), model, plan, img, label_img, mask)
+    else:
+        outs = _run_forward(model, plan, img, label_img, mask)
+    return [(outs[3 * s], outs[3 * s + 1], outs[3 * s + 2]) for s in range(model.stage)]

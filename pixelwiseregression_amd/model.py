@@ -142,11 +142,13 @@ class PixelwiseRegression(nn.Module):
         self._flat = None
         self._flat_grad = None
         self._engine = None
+        self._ddp = None
         self._flatten()
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self):
-        """(Re)pack all parameters into one contiguous fp32 buffer and make them views of it."""
+        """(Re)pack all parameters into one contiguous fp32 buffer and make them views of it; same for the
+        BatchNorm running statistics (fp32) and num_batches_tracked (int64)."""
         params = [p for _, p in self.named_parameters()]
         if not params:
             return
@@ -163,14 +165,63 @@ class PixelwiseRegression(nn.Module):
                 p.grad = None
                 self._offsets[name] = (off, tuple(p.shape))
                 off += n
+            stats = [(k, b) for k, b in self.named_buffers() if k.endswith("running_mean") or k.endswith("running_var")]
+            nbts = [(k, b) for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
+            self._buffer_offsets = []
+            self._flat_buf = self._flat_nbt = None
+            if stats:
+                fb = torch.empty(sum(b.numel() for _, b in stats), dtype=torch.float32, device=dev)
+                off = 0
+                for k, b in stats:
+                    n = b.numel()
+                    fb[off:off + n].copy_(b.reshape(-1).float())
+                    self._set_buffer(k, fb[off:off + n].view(b.shape))
+                    self._buffer_offsets.append(off)
+                    off += n
+                self._flat_buf = fb
+                fn = torch.empty(len(nbts), dtype=torch.long, device=dev)
+                for i, (k, b) in enumerate(nbts):
+                    fn[i] = b
+                    self._set_buffer(k, fn[i])
+                self._flat_nbt = fn
         self._flat = flat
         self._flat_grad = None
+        self._scratch = None
+        self._gviews = None
+        self._sviews = None
+        self._trig = None
+        self._param_list = params
         self._engine = None
+
+    def _set_buffer(self, dotted, tensor):
+        mod = self
+        parts = dotted.split(".")
+        for q in parts[:-1]:
+            mod = getattr(mod, q)
+        mod._buffers[parts[-1]] = tensor
+
+    def _check_flat(self):
+        """Parameters must still alias the flat buffer (deepcopy / manual .data assignment break that)."""
+        ps = self._param_list
+        last_off = self._flat.numel() - ps[-1].numel()
+        if ps[0].data_ptr() != self._flat.data_ptr() or ps[-1].data_ptr() != self._flat.data_ptr() + 4 * last_off:
+            self._flatten()
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._flatten()
         return r
+
+    def __deepcopy__(self, memo):
+        new = PixelwiseRegression(self.joints, self.stage, self.label_size, self.features, self.level, self.kernel_size,
+                                  self.norm_method, self.heatmap_method)
+        new.load_state_dict(self.state_dict())
+        new = new.to(self._flat.device)
+        new.train(self.training)
+        new._precision, new._backend = self._precision, self._backend
+        for (_, a), (_, b) in zip(self.named_parameters(), new.named_parameters()):
+            b.requires_grad_(a.requires_grad)
+        return new
 
     def flat_parameters(self):
         return self._flat
@@ -178,7 +229,42 @@ class PixelwiseRegression(nn.Module):
     def flat_grad(self):
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
             self._flat_grad = torch.zeros_like(self._flat)
+            self._gviews = None
         return self._flat_grad
+
+    def _views_of(self, flat):
+        return [flat[o:o + int(torch.Size(s).numel())].view(s) for (o, s) in self._offsets.values()]
+
+    def _grad_views(self):
+        if self._gviews is None:
+            self._gviews = self._views_of(self.flat_grad())
+        return self._gviews
+
+    def _grad_scratch(self):
+        if self._scratch is None:
+            self._scratch = torch.zeros_like(self._flat)
+            self._sviews = None
+        return self._scratch
+
+    def _scratch_views(self):
+        if self._sviews is None:
+            self._sviews = self._views_of(self._grad_scratch())
+        return self._sviews
+
+    def _trigger(self):
+        if self._trig is None or self._trig.device != self._flat.device:
+            self._trig = torch.zeros(1, device=self._flat.device, requires_grad=True)
+        return self._trig
+
+    def segment_ranges(self):
+        """Flat [begin, end) float ranges in backward-completion order: stage S-1, ..., stage 0, stem."""
+        names = list(self._offsets.keys())
+        def rng(prefix):
+            ks = [k for k in names if k.startswith(prefix)]
+            o0 = self._offsets[ks[0]][0]
+            o1, s1 = self._offsets[ks[-1]]
+            return (o0, o1 + int(torch.Size(s1).numel()))
+        return [rng("stages.%d." % s) for s in range(self.stage - 1, -1, -1)] + [rng("conv.")]
 
     def set_precision(self, precision):
         if precision not in ("fp32", "bf16"):
