@@ -80,22 +80,22 @@ size_t pwr_conv_pack_bytes(int cout, int cin, int ksize, int kind, int dtype);
  * KCH = ceil(kdim / (dtype==PWR_BF16 ? 32 : 16)) with rows/kdim = (Cout,Cin) for kind 0, (Cin,Cout) else. */
 int pwr_pack_weights(const float* flat_params, void* packs, const void* descs_dev, int n_desc, void* stream);
 
-/* y = conv(NR(x)) + bias (+ residual).  NR(x) = relu_in ? max(0, x*in_scale[b,c]+in_shift[b,c]) : x*in_scale+in_shift,
- * skipped when in_scale == NULL: the InstanceNorm/BatchNorm + ReLU that precedes the conv in model.py, fused
- * into the operand load.  x: [B,H,W,Cin]; y: [B,Ho,Wo,Cout] (NULL to skip); y_nchw: fp32 [B,Cout,Ho,Wo] (NULL to
+/* y = conv(NR(x)) + bias (+ residual).  NR(x) = (x - mean[b,c]) * scale[b,c] + beta[b,c], then ReLU if relu_in;
+ * skipped when in_norm == NULL: the InstanceNorm/BatchNorm + ReLU that precedes the conv in model.py, fused
+ * into the operand load.  in_norm is the [4][B][Cin] state written by pwr_norm_stats.  x: [B,H,W,Cin]; y: [B,Ho,Wo,Cout] (NULL to skip); y_nchw: fp32 [B,Cout,Ho,Wo] (NULL to
  * skip; used by the heads' last conv, model.py:64/:113).  ksize in {1,3}, pad = ksize/2, stride in {1,2}.
  * mode 0: convolution.  mode 1: data-gradient of a stride-2 conv: x is dy [B,H,W,Cin], y is [B,2H,2W,Cout],
  * wpack of kind 2.  The data-gradient of a stride-1 conv is mode 0 with a kind-1 pack. */
-int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_scale, const float* in_shift,
-                 int relu_in, const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout,
-                 int ksize, int stride, int mode, int dtype, void* stream);
+int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
+                 const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                 int mode, int dtype, void* stream);
 
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 
 /* dw[cout_real][Cin][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
  * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout] (Cout may include zero-padded channels beyond cout_real);
  * slab: workspace of pwr_conv_wgrad_slab_bytes; `splits` partitions the pixel (K) dimension over workgroups. */
-int pwr_conv_wgrad(const void* x, const void* dy, const float* in_scale, const float* in_shift, int relu_in, float* slab,
+int pwr_conv_wgrad(const void* x, const void* dy, const float* in_norm, int relu_in, float* slab,
                    float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int cout_real, int ksize, int stride,
                    int splits, int dtype, void* stream);
 
@@ -120,17 +120,16 @@ int pwr_catconv_wgrad(const float* pmap, const float* dmap, const float* label, 
 
 /* ---------------------------------------------------------------------------------------------
  * Norm + ReLU (model.py: every `norm(...)`, ReLU pair).  mode: 0 InstanceNorm2d, 1 BatchNorm2d training,
- * 2 BatchNorm2d eval (running statistics).  Outputs are per-(b,c) arrays [B,C]:
- * scale = gamma*rstd, shift = beta - mean*scale (consumed by pwr_conv_fwd / pwr_conv_wgrad), mean, rstd.
+ * 2 BatchNorm2d eval (running statistics).  Output `state` is [4][B][C] fp32 = mean, rstd, scale = gamma*rstd, beta
+ * (consumed by pwr_conv_fwd / pwr_conv_wgrad / pwr_norm_bwd).
  * ------------------------------------------------------------------------------------------- */
 int pwr_norm_chunks(int B, int HW);
 size_t pwr_norm_partial_bytes(int B, int HW, int C);
 int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                   float* partial, float* mean, float* rstd, float* scale, float* shift, int B, int HW, int C, int mode,
-                   float eps, float momentum, int dtype, void* stream);
+                   float* partial, float* state, int B, int HW, int C, int mode, float eps, float momentum, int dtype,
+                   void* stream);
 /* dy = d/dy relu(norm(y)) applied to g (+ addend); dgamma/dbeta [C] (+)=.  S1,S2: [B,C] scratch. */
-int pwr_norm_bwd(const void* g, const void* y, const float* mean, const float* rstd, const float* scale,
-                 const float* shift, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
+int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

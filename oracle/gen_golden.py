@@ -102,10 +102,13 @@ def gen_decoder(ref_model):
             print("decoder", method, P)
 
 
-def _run_model(ref_model, cfg, sd, batch, alpha, train=True):
+def _run_model(ref_model, cfg, sd, batch, alpha, train=True, double=False):
     model = ref_model.PixelwiseRegression(cfg["joints"], **{k: v for k, v in cfg.items() if k != "joints"})
     model.load_state_dict(sd, strict=True)
     model.train(train)
+    if double:      # the reference evaluated in float64: the "truth" both fp32 implementations are measured against
+        model = model.double()
+        batch = {k: v.double() for k, v in batch.items()}
     res = model(batch["img"], batch["label_img"], batch["mask"])
     out = {}
     for s, (p, D, uvd) in enumerate(res):
@@ -147,6 +150,9 @@ def gen_tiny(ref_model):
                 tag = "a%03d_" % int(alpha * 100)
                 rec.update({tag + k: v for k, v in out.items()})
                 rec.update({tag + "grad_" + k: v for k, v in grads.items()})
+                out64, grads64, _ = _run_model(ref_model, cfg, sd, batch, alpha, train=True, double=True)
+                rec.update({tag + "f64_" + k: v for k, v in out64.items()})
+                rec.update({tag + "f64_grad_" + k: v.astype(np.float32) for k, v in grads64.items()})
                 if norm == "batch" and alpha == 1.0:
                     after = model.state_dict()
                     for k in after:
@@ -171,6 +177,7 @@ def gen_c1(ref_model):
     batch = make_batch(1, 16, S=128, seed=5)
     with torch.no_grad():
         out, _, _ = _run_model(ref_model, cfg, sd, batch, None, train=False)
+        out64, _, _ = _run_model(ref_model, cfg, sd, batch, None, train=False, double=True)
     rec = {"cfg_" + k: np.array(v) for k, v in cfg.items()}
     rec["weights_seed"] = np.array(11)
     rec["batch_seed"] = np.array(5)
@@ -186,6 +193,9 @@ def gen_c1(ref_model):
         rec["s%d_D_std" % s] = D.std(axis=(2, 3))
         rec["s%d_p_sample" % s] = p[:, :, ::8, ::8].copy()
         rec["s%d_D_sample" % s] = D[:, :, ::8, ::8].copy()
+        rec["s%d_uvd_f64" % s] = out64["s%d_uvd" % s]
+        rec["s%d_p_sample_f64" % s] = out64["s%d_p" % s][:, :, ::8, ::8].copy()
+        rec["s%d_D_sample_f64" % s] = out64["s%d_D" % s][:, :, ::8, ::8].copy()
     # parameter census: key names + shapes + element count (the state_dict contract)
     rec["sd_keys"] = np.array(list(sd.keys()))
     rec["sd_numel"] = np.array([v.numel() for v in sd.values()])

@@ -20,8 +20,7 @@ struct ConvParams {
   const void* x;          // [B,H,W,Cin] T   (forward: input; dgrad: dy)
   const void* w;          // packed weights, see pack_weights kernel
   const float* bias;      // [Cout] or null
-  const float* in_scale;  // [B,Cin] or null: NR prologue
-  const float* in_shift;
+  const float* in_norm;   // [4][B][Cin] = mean, rstd, scale, beta of the input's norm (or null): NR prologue
   const void* residual;   // [B,Ho,Wo,Cout] T or null (added in the epilogue)
   void* y;                // [B,Ho,Wo,Cout] T or null
   float* y_nchw;          // [B,Cout,Ho,Wo] fp32 or null
@@ -32,8 +31,7 @@ struct ConvParams {
 struct WgradParams {
   const void* x;          // [B,H,W,Cin] T  forward input (pre-NR)
   const void* dy;         // [B,Ho,Wo,Cout] T
-  const float* in_scale;  // NR prologue of the forward conv (or null)
-  const float* in_shift;
+  const float* in_norm;   // NR prologue of the forward conv (or null), [4][B][Cin]
   float* slab;            // [S][taps][CinPad128][CoutPad] fp32 partials
   int B, H, W, Cin, Ho, Wo, Cout, CoutPad, CinPad;
   int ksize, stride, pad, relu_in, M, S, steps_per_split;
@@ -72,15 +70,17 @@ __device__ __forceinline__ void mma_tile(const char* lA, const char* lB, int a_r
   }
 }
 
-// v = relu?(v*scale + shift) on one 16-byte vector; sc/sh point at the vector's first channel
+// v = relu?((v - mean)*scale + beta) on one 16-byte vector; st points at mean[b][c0] of a [4][B][C] norm state
+// (mean, rstd, scale = gamma*rstd, beta).  Subtracting the mean first keeps the cancellation exact-ish, like
+// ATen's (x - mean) * invstd * gamma + beta.
 template <typename T>
-__device__ __forceinline__ typename Vec16<T>::type nr_transform(typename Vec16<T>::type v, const float* sc,
-                                                                const float* sh, int relu) {
+__device__ __forceinline__ typename Vec16<T>::type nr_transform(typename Vec16<T>::type v, const float* st, size_t plane,
+                                                                int relu) {
   constexpr int EP = Mma<T>::EP;
   typename Vec16<T>::type o;
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
-    float f = fmaf(Elem<T>::to_f(v[e]), sc[e], sh[e]);
+    float f = fmaf(Elem<T>::to_f(v[e]) - st[e], st[2 * plane + e], st[3 * plane + e]);
     if (relu) f = fmaxf(f, 0.f);
     o[e] = Elem<T>::from_f(f);
   }
@@ -175,11 +175,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       V v = ra[i];
-      if (p.in_scale && av[i]) {
-        const float* sc = p.in_scale + (size_t)ab[i] * p.Cin + cur_c0;
-        const float* sh = p.in_shift + (size_t)ab[i] * p.Cin + cur_c0;
-        v = nr_transform<T>(v, sc, sh, p.relu_in);
-      }
+      if (p.in_norm && av[i])
+        v = nr_transform<T>(v, p.in_norm + (size_t)ab[i] * p.Cin + cur_c0, (size_t)p.B * p.Cin, p.relu_in);
       *reinterpret_cast<V*>(lA + lds_off((tid >> 2) + 64 * i, q)) = v;
     }
 #pragma unroll
@@ -197,6 +194,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // fp32 (parity) mode: two-level summation -- the MFMA chain is flushed into a second accumulator every 8 K-steps
+  // (128 products) so that the rounding error does not grow with the full K = taps*Cin chain.
+  constexpr bool kTwoLevel = sizeof(T) == 4;
+  f32x16 acc2[kTwoLevel ? MR : 1][kTwoLevel ? NR : 1];
+  if constexpr (kTwoLevel) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
   load_global(0);
   store_lds(0);
   __syncthreads();
@@ -205,8 +214,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     if (it + 1 < iters) load_global(it + 1);
     const char* lA = smem + buf * (BM + BN) * 64;
     mma_tile<T, MR, NR>(lA, lA + BM * 64, wm * MR * 32, wn * NR * 32, lane, acc);
+    if constexpr (kTwoLevel) {
+      if ((it & 7) == 7 || it + 1 == iters) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
+      }
+    }
     if (it + 1 < iters) store_lds(buf ^ 1);
     __syncthreads();
+  }
+  if constexpr (kTwoLevel) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) acc[i][j] = acc2[i][j];
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time) -> coalesced 16-byte stores
@@ -350,11 +373,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       if (c < KE * ACH) {
         const int pix = c % KE, cq = c / KE;
         V v = ra[i];
-        if (p.in_scale && av[i]) {
-          const int ci = ci0 + cq * EP;
-          v = nr_transform<T>(v, p.in_scale + (size_t)abatch[i] * p.Cin + ci, p.in_shift + (size_t)abatch[i] * p.Cin + ci,
-                              p.relu_in);
-        }
+        if (p.in_norm && av[i])
+          v = nr_transform<T>(v, p.in_norm + (size_t)abatch[i] * p.Cin + ci0 + cq * EP, (size_t)p.B * p.Cin, p.relu_in);
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
           const int row = cq * EP + e;
@@ -384,6 +404,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  constexpr bool kTwoLevel = sizeof(T) == 4;
+  f32x16 acc2[kTwoLevel ? MR : 1][kTwoLevel ? NR : 1];
+  if constexpr (kTwoLevel) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
   if (nsteps > 0) {
     load_global(0);
     store_lds(0);
@@ -393,9 +423,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       if (st + 1 < nsteps) load_global(st + 1);
       const char* lA = smem + buf * (BM + BN) * 64;
       mma_tile<T, MR, NR>(lA, lA + BM * 64, wm * MR * 32, wn * NR * 32, lane, acc);
+      if constexpr (kTwoLevel) {
+        if ((st & 7) == 7 || st + 1 == nsteps) {
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
+        }
+      }
       if (st + 1 < nsteps) store_lds(buf ^ 1);
       __syncthreads();
     }
+  }
+  if constexpr (kTwoLevel) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) acc[i][j] = acc2[i][j];
   }
   // D layout: col = lane&31 -> co (contiguous), row -> ci
   const int r = lane & 31, h = lane >> 5;
@@ -510,13 +554,13 @@ extern "C" int pwr_pack_weights(const float* flat_params, void* packs, const voi
   return (int)hipGetLastError();
 }
 
-extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_scale,
-                            const float* in_shift, int relu_in, const void* residual, void* y, float* y_nchw, int B,
-                            int H, int W, int Cin, int Cout, int ksize, int stride, int mode, int dtype, void* stream) {
+extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
+                            const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout, int ksize,
+                            int stride, int mode, int dtype, void* stream) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
   if (Cin % EP || (y && Cout % EP) || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return PWR_EUNSUPPORTED;
   pwr::ConvParams p;
-  p.x = x; p.w = wpack; p.bias = bias; p.in_scale = in_scale; p.in_shift = in_shift; p.residual = residual;
+  p.x = x; p.w = wpack; p.bias = bias; p.in_norm = in_norm; p.residual = residual;
   p.y = y; p.y_nchw = y_nchw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.ksize = ksize; p.pad = ksize / 2; p.mode = mode; p.relu_in = relu_in;
   if (mode == 0) {
@@ -536,13 +580,13 @@ extern "C" size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int sp
   return (size_t)splits * ksize * ksize * cinpad * pwr_conv_out_pad(cout) * sizeof(float);
 }
 
-extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_scale, const float* in_shift, int relu_in,
+extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_norm, int relu_in,
                               float* slab, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int cout_real,
                               int ksize, int stride, int splits, int dtype, void* stream) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
   if (Cin % EP || Cout % EP || (ksize != 1 && ksize != 3) || splits < 1) return PWR_EUNSUPPORTED;
   pwr::WgradParams p;
-  p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.slab = slab;
+  p.x = x; p.dy = dy; p.in_norm = in_norm; p.slab = slab;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ksize = ksize; p.stride = stride; p.pad = ksize / 2;
   p.Ho = (H + 2 * p.pad - ksize) / stride + 1; p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
   p.CoutPad = pwr_conv_out_pad(Cout); p.CinPad = (Cin + 127) / 128 * 128;

@@ -47,7 +47,7 @@ struct Tn {  // NHWC activation in the arena
   int H = 0, W = 0, C = 0;
 };
 struct NormL {
-  size_t mean, rstd, scale, shift;
+  size_t state;  // [4][B][C] fp32: mean, rstd, scale, beta
   long long gamma, beta, rm = -1, rv = -1;
   int C;
 };
@@ -144,8 +144,7 @@ struct Engine {
     n.gamma = take_param(C);
     n.beta = take_param(C);
     if (norm_mode == 1) { n.rm = take_buffer(); n.rv = take_buffer(); }
-    n.mean = alloc((size_t)B * C * 4); n.rstd = alloc((size_t)B * C * 4);
-    n.scale = alloc((size_t)B * C * 4); n.shift = alloc((size_t)B * C * 4);
+    n.state = alloc((size_t)4 * B * C * 4);
     return n;
   }
   int splits_for(int M, int cin, int cout, int k) const {
@@ -172,8 +171,8 @@ struct Engine {
       float* rm = n.rm >= 0 ? c.buffers + n.rm : nullptr;
       float* rv = n.rv >= 0 ? c.buffers + n.rv : nullptr;
       return pwr_norm_stats(c.arena + t.off, c.params + n.gamma, c.params + n.beta, rm, rv,
-                            (float*)(c.arena + E->scr_partial), (float*)(c.arena + n.mean), (float*)(c.arena + n.rstd),
-                            (float*)(c.arena + n.scale), (float*)(c.arena + n.shift), Bc, HW, C, mode, 1e-5f, 0.1f, dt, c.stream);
+                            (float*)(c.arena + E->scr_partial), (float*)(c.arena + n.state), Bc, HW, C, mode, 1e-5f, 0.1f, dt,
+                            c.stream);
     });
   }
   // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
@@ -182,8 +181,7 @@ struct Engine {
     Engine* E = this;
     bwd_cur.push_back([=](Ctx& c) {
       int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
-      return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.mean), (float*)(c.arena + n.rstd),
-                          (float*)(c.arena + n.scale), (float*)(c.arena + n.shift), (float*)(c.arena + E->scr_partial),
+      return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                           (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                           has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0,
                           1, Bc, HW, C, mode, dt, c.stream);
@@ -201,8 +199,8 @@ struct Engine {
     const bool has_res = residual != nullptr;
     const size_t roff = has_res ? residual->off : 0;
     fwd.push_back([=](Ctx& c) {
-      return pwr_conv_fwd(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.scale) : nullptr,
-                          has_nr ? (float*)(c.arena + n.shift) : nullptr, 1, has_res ? c.arena + roff : nullptr, c.arena + y.off,
+      return pwr_conv_fwd(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.state) : nullptr,
+                          1, has_res ? c.arena + roff : nullptr, c.arena + y.off,
                           nullptr, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride, 0, dt, c.stream);
     });
     return y;
@@ -219,18 +217,18 @@ struct Engine {
     want_slab((size_t)pwr_colsum_blocks(M) * cv.Cout * 4);
     Engine* E = this;
     bwd_cur.push_back([=](Ctx& c) {
-      int rc = pwr_conv_wgrad(c.arena + x.off, c.arena + y.goff, has_nr ? (float*)(c.arena + n.scale) : nullptr,
-                              has_nr ? (float*)(c.arena + n.shift) : nullptr, 1, (float*)(c.arena + E->scr_slab), c.grads + cv.w, 0,
+      int rc = pwr_conv_wgrad(c.arena + x.off, c.arena + y.goff, has_nr ? (float*)(c.arena + n.state) : nullptr,
+                              1, (float*)(c.arena + E->scr_slab), c.grads + cv.w, 0,
                               Bc, x.H, x.W, cv.Cin, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c.stream);
       if (rc) return rc;
       if (bias_grad || (E->norm_mode == 1 && !c.training))
         rc = pwr_colsum_nhwc(c.arena + y.goff, (float*)(c.arena + E->scr_slab), c.grads + cv.b, (long long)M, cv.Cout, 0, dt, c.stream);
       if (rc || !need_dx) return rc;
       if (cv.stride == 1)
-        return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, nullptr, 0,
+        return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0,
                             accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k,
                             1, 0, dt, c.stream);
-      return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, nullptr, 0,
+      return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0,
                           accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k, 1,
                           1, dt, c.stream);
     });
@@ -323,7 +321,7 @@ struct Engine {
     const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3;
     fwd.push_back([=](Ctx& c) {
       float* dst = out_sel == 0 ? (float*)(c.arena + z_off) : c.out_D[stage_idx];
-      return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.scale), (float*)(c.arena + n2.shift),
+      return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.state),
                           1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
     });
     const int Jp = (J + 7) / 8 * 8;
@@ -344,10 +342,10 @@ struct Engine {
       if (rc) return rc;
       rc = pwr_planesum_nchw((const float*)(c.arena + g_nchw_off), c.grads + c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
       if (rc) return rc;
-      rc = pwr_conv_wgrad(c.arena + h3.off, c.arena + gT, (float*)(c.arena + n2.scale), (float*)(c.arena + n2.shift), 1,
+      rc = pwr_conv_wgrad(c.arena + h3.off, c.arena + gT, (float*)(c.arena + n2.state), 1,
                           (float*)(c.arena + E->scr_slab), c.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c.stream);
       if (rc) return rc;
-      return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
+      return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
                           Jp, c3.Cin, c3.k, 1, 0, dt, c.stream);
     });
     norm_bwd(h.h3, h.n2, 0, false);

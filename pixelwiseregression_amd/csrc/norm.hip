@@ -62,11 +62,14 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
 template <typename T>
 __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __restrict__ partial,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ scale_o,
-                                     float* __restrict__ shift_o, float* __restrict__ running_mean,
+                                     float* __restrict__ state, float* __restrict__ running_mean,
                                      float* __restrict__ running_var, int B, int HW, int C, int nchunks, int batch_mode,
                                      float eps, float momentum) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  float* __restrict__ mean_o = state;                       // state: [4][B][C] = mean, rstd, scale, beta
+  float* __restrict__ rstd_o = state + (size_t)B * C;
+  float* __restrict__ scale_o = state + (size_t)2 * B * C;
+  float* __restrict__ shift_o = state + (size_t)3 * B * C;
   if (!batch_mode) {
     if (idx >= B * C) return;
     const int b = idx / C, c = idx - b * C;
@@ -81,7 +84,7 @@ __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __res
     const float var = fmaxf(s2 / n - m1 * m1, 0.f);
     const float mean = kk + m1, rstd = 1.f / sqrtf(var + eps);
     const float sc = gamma[c] * rstd;
-    mean_o[idx] = mean; rstd_o[idx] = rstd; scale_o[idx] = sc; shift_o[idx] = beta[c] - mean * sc;
+    mean_o[idx] = mean; rstd_o[idx] = rstd; scale_o[idx] = sc; shift_o[idx] = beta[c];
   } else {
     if (idx >= C) return;
     const int c = idx;
@@ -95,7 +98,7 @@ __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __res
     const float m1 = s1 / n;
     const float var = fmaxf(s2 / n - m1 * m1, 0.f);
     const float mean = kk + m1, rstd = 1.f / sqrtf(var + eps);
-    const float sc = gamma[c] * rstd, sh = beta[c] - mean * sc;
+    const float sc = gamma[c] * rstd, sh = beta[c];
     for (int b = 0; b < B; ++b) {
       mean_o[b * C + c] = mean; rstd_o[b * C + c] = rstd; scale_o[b * C + c] = sc; shift_o[b * C + c] = sh;
     }
@@ -109,13 +112,13 @@ __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __res
 // eval-mode BatchNorm: scale/shift from the running statistics
 __global__ void norm_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                  const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                 float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ scale_o,
-                                 float* __restrict__ shift_o, int B, int C, float eps) {
+                                 float* __restrict__ state, int B, int C, float eps) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * C) return;
   const int c = idx % C;
   const float rstd = 1.f / sqrtf(running_var[c] + eps), sc = gamma[c] * rstd;
-  mean_o[idx] = running_mean[c]; rstd_o[idx] = rstd; scale_o[idx] = sc; shift_o[idx] = beta[c] - running_mean[c] * sc;
+  state[idx] = running_mean[c]; state[(size_t)B * C + idx] = rstd; state[(size_t)2 * B * C + idx] = sc;
+  state[(size_t)3 * B * C + idx] = beta[c];
 }
 
 // ---- backward ----
@@ -123,10 +126,13 @@ __global__ void norm_eval_kernel(const float* __restrict__ gamma, const float* _
 // partial sums per chunk: s1 = sum gm, s2 = sum gm*xn
 template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restrict__ g, const T* __restrict__ y,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ state, int B,
                                                                float* __restrict__ partial, int HW, int C, int nchunks,
                                                                int relu) {
+  const float* __restrict__ mean = state;
+  const float* __restrict__ rstd = state + (size_t)B * C;
+  const float* __restrict__ scale = state + (size_t)2 * B * C;
+  const float* __restrict__ shift = state + (size_t)3 * B * C;
   constexpr int EP = Elem<T>::kPer16B;
   typedef typename Vec16<T>::type V;
   extern __shared__ float red[];
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restri
       for (int e = 0; e < EP; ++e) {
         const float yy = Elem<T>::to_f(yv[e]);
         float gg = Elem<T>::to_f(gv[e]);
-        if (relu && !(fmaf(yy, sc[e], sh[e]) > 0.f)) gg = 0.f;
+        if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
         s1[e] += gg;
         s2[e] = fmaf(gg, (yy - mu[e]) * rs[e], s2[e]);
       }
@@ -200,11 +206,14 @@ __global__ void norm_bwd_finalize_kernel(const float* __restrict__ partial, floa
 // dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend)
 template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
-                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ state, int B,
                                                              const float* __restrict__ S1, const float* __restrict__ S2,
                                                              const T* __restrict__ addend, T* __restrict__ dy, int HW, int C,
                                                              long long total_chunks, int relu) {
+  const float* __restrict__ mean = state;
+  const float* __restrict__ rstd = state + (size_t)B * C;
+  const float* __restrict__ scale = state + (size_t)2 * B * C;
+  const float* __restrict__ shift = state + (size_t)3 * B * C;
   constexpr int EP = Elem<T>::kPer16B;
   typedef typename Vec16<T>::type V;
   const int cpp = C / EP;
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
       const float yy = Elem<T>::to_f(yv[e]);
       float gg = Elem<T>::to_f(gv[e]);
       const float sc = scale[c];
-      if (relu && !(fmaf(yy, sc, shift[c]) > 0.f)) gg = 0.f;
+      if (relu && !(fmaf(yy - mean[c], sc, shift[c]) > 0.f)) gg = 0.f;
       const float xn = (yy - mean[c]) * rstd[c];
       float r = sc * (gg - S1[c] - xn * S2[c]);     // scale = gamma*rstd
       if (addend) r += Elem<T>::to_f(av[e]);
@@ -253,14 +262,14 @@ extern "C" size_t pwr_norm_partial_bytes(int B, int HW, int C) { return (size_t)
 
 // mode: 0 instance, 1 batch (training statistics), 2 batch eval (running statistics)
 extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                              float* partial, float* mean, float* rstd, float* scale, float* shift, int B, int HW, int C,
-                              int mode, float eps, float momentum, int dtype, void* stream) {
+                              float* partial, float* state, int B, int HW, int C, int mode, float eps, float momentum,
+                              int dtype, void* stream) {
   const int EP = dtype == PWR_BF16 ? 8 : 4;
   if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 2) {
     hipLaunchKernelGGL(norm_eval_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, gamma, beta, running_mean, running_var,
-                       mean, rstd, scale, shift, B, C, eps);
+                       state, B, C, eps);
     return (int)hipGetLastError();
   }
   const int nch = norm_chunks(B, HW);
@@ -270,11 +279,11 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   if (dtype == PWR_BF16) {
     hipLaunchKernelGGL((norm_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)y, partial, HW, C, nch, mode);
     hipLaunchKernelGGL((norm_finalize_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)y, partial, gamma,
-                       beta, mean, rstd, scale, shift, running_mean, running_var, B, HW, C, nch, mode, eps, momentum);
+                       beta, state, running_mean, running_var, B, HW, C, nch, mode, eps, momentum);
   } else {
     hipLaunchKernelGGL((norm_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)y, partial, HW, C, nch, mode);
     hipLaunchKernelGGL((norm_finalize_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)y, partial, gamma,
-                       beta, mean, rstd, scale, shift, running_mean, running_var, B, HW, C, nch, mode, eps, momentum);
+                       beta, state, running_mean, running_var, B, HW, C, nch, mode, eps, momentum);
   }
   return (int)hipGetLastError();
 }
@@ -282,8 +291,7 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
 // Backward of relu(norm(y)) (relu optional).  g: upstream gradient; dy out (may alias g); addend optional (same
 // shape, added to the result: the skip branch of a ResBlock).  S1,S2: [B,C] scratch.  dgamma/dbeta: [C].
 // mode 2 (eval-mode batch norm) treats the statistics as constants.
-extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* mean, const float* rstd, const float* scale,
-                            const float* shift, float* partial, float* S1, float* S2, const void* addend, void* dy,
+extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy,
                             float* dgamma, float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype,
                             void* stream) {
   const int EP = dtype == PWR_BF16 ? 8 : 4;
@@ -296,10 +304,10 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* mean, con
   int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == PWR_BF16) {
     hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y,
-                       mean, rstd, scale, shift, partial, HW, C, nch, relu);
+                       state, B, partial, HW, C, nch, relu);
   } else {
-    hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, mean,
-                       rstd, scale, shift, partial, HW, C, nch, relu);
+    hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state,
+                       B, partial, HW, C, nch, relu);
   }
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, S1, S2, dgamma, dbeta, B, HW, C, nch,
                      mode == 1 ? 1 : 0, accumulate);
@@ -308,11 +316,11 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* mean, con
     hipMemsetAsync(S2, 0, (size_t)B * C * 4, s);
   }
   if (dtype == PWR_BF16) {
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, mean, rstd,
-                       scale, shift, S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, total, relu);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
+                       S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, total, relu);
   } else {
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)y, mean, rstd,
-                       scale, shift, S1, S2, (const float*)addend, (float*)dy, HW, C, total, relu);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
+                       S1, S2, (const float*)addend, (float*)dy, HW, C, total, relu);
   }
   return (int)hipGetLastError();
 }

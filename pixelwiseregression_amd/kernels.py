@@ -58,8 +58,9 @@ def pack_conv(weight, kind, dtype):
     return packs
 
 
-def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, scale=None, shift=None, relu_in=True, residual=None, mode=0,
+def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_in=True, residual=None, mode=0,
              nhwc_out=True, nchw_out=False):
+    """norm: the [4,B,Cin] state tensor of norm_stats (mean, rstd, scale, beta) or None."""
     l = _lib.lib()
     B, H, W, Cin = x.shape
     pad = ksize // 2
@@ -69,12 +70,12 @@ def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, scale=None, shift=None,
         Ho, Wo = 2 * H, 2 * W
     y = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device) if nhwc_out else None
     yn = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device) if nchw_out else None
-    _lib.check(l.pwr_conv_fwd(_p(x), _p(wpack), _p(bias), _p(scale), _p(shift), int(relu_in), _p(residual), _p(y), _p(yn),
+    _lib.check(l.pwr_conv_fwd(_p(x), _p(wpack), _p(bias), _p(norm), int(relu_in), _p(residual), _p(y), _p(yn),
                               B, H, W, Cin, cout, ksize, stride, mode, _dt(x), _s(x)), "pwr_conv_fwd")
     return y, yn
 
 
-def conv_wgrad(x, dy, cout_real, ksize, stride=1, scale=None, shift=None, relu_in=True, splits=8, dw=None):
+def conv_wgrad(x, dy, cout_real, ksize, stride=1, norm=None, relu_in=True, splits=8, dw=None):
     l = _lib.lib()
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -82,7 +83,7 @@ def conv_wgrad(x, dy, cout_real, ksize, stride=1, scale=None, shift=None, relu_i
     acc = dw is not None
     if dw is None:
         dw = torch.empty(cout_real, Cin, ksize, ksize, dtype=torch.float32, device=x.device)
-    _lib.check(l.pwr_conv_wgrad(_p(x), _p(dy), _p(scale), _p(shift), int(relu_in), _p(slab), _p(dw), int(acc), B, H, W, Cin,
+    _lib.check(l.pwr_conv_wgrad(_p(x), _p(dy), _p(norm), int(relu_in), _p(slab), _p(dw), int(acc), B, H, W, Cin,
                                 Cout, cout_real, ksize, stride, splits, _dt(x), _s(x)), "pwr_conv_wgrad")
     return dw
 
@@ -144,14 +145,13 @@ def norm_stats(y, gamma, beta, mode=0, running_mean=None, running_var=None, eps=
     B, H, W, C = y.shape
     dev = y.device
     partial = torch.empty(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=dev)
-    out = [torch.empty(B, C, dtype=torch.float32, device=dev) for _ in range(4)]
-    _lib.check(l.pwr_norm_stats(_p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(partial), _p(out[0]),
-                                _p(out[1]), _p(out[2]), _p(out[3]), B, H * W, C, mode, eps, momentum, _dt(y), _s(y)),
-               "pwr_norm_stats")
-    return tuple(out)   # mean, rstd, scale, shift
+    state = torch.empty(4, B, C, dtype=torch.float32, device=dev)
+    _lib.check(l.pwr_norm_stats(_p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(partial), _p(state),
+                                B, H * W, C, mode, eps, momentum, _dt(y), _s(y)), "pwr_norm_stats")
+    return state   # [4,B,C]: mean, rstd, scale = gamma*rstd, beta
 
 
-def norm_bwd(g, y, mean, rstd, scale, shift, relu=True, addend=None, mode=0):
+def norm_bwd(g, y, state, relu=True, addend=None, mode=0):
     l = _lib.lib()
     B, H, W, C = y.shape
     dev = y.device
@@ -161,7 +161,7 @@ def norm_bwd(g, y, mean, rstd, scale, shift, relu=True, addend=None, mode=0):
     dy = torch.empty_like(y)
     dgamma = torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = torch.empty_like(dgamma)
-    _lib.check(l.pwr_norm_bwd(_p(g), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(S1), _p(S2),
+    _lib.check(l.pwr_norm_bwd(_p(g), _p(y), _p(state), _p(partial), _p(S1), _p(S2),
                               _p(addend), _p(dy), _p(dgamma), _p(dbeta), 0, int(relu), B, H * W, C, mode, _dt(y), _s(y)),
                "pwr_norm_bwd")
     return dy, dgamma, dbeta

@@ -38,6 +38,14 @@ def nchw(y):          # NHWC device -> NCHW float64 cpu
     return y.double().cpu().permute(0, 3, 1, 2).contiguous()
 
 
+def apply_nr(xin, B, C, dtype):
+    """random norm state [4,B,C] (mean, rstd, scale, beta) and the NR-transformed input the kernel should see"""
+    mean, sc, beta = 0.5 * rnd(B, C, seed=5), 1 + 0.2 * rnd(B, C, seed=6), 0.3 * rnd(B, C, seed=7)
+    st = torch.stack([mean, torch.ones(B, C, dtype=torch.float64), sc, beta]).float()
+    m, s_, b_ = (t.float().double()[:, :, None, None] for t in (mean, sc, beta))
+    return q(torch.relu((xin - m) * s_ + b_), dtype), st.contiguous().to(DEV)
+
+
 def assert_close(got, ref, rel, what=""):
     err = (got - ref).abs().max().item()
     den = max(ref.abs().max().item(), 1e-6)
@@ -70,15 +78,13 @@ def test_conv_forward(case, dtype, prologue):
     bias = rnd(Cout, seed=3, scale=0.1)
     res = rnd(B, Cout, (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1, seed=4)
     xin = q(x, dtype)
-    sc = sh = None
+    st = None
     if prologue:
-        sc, sh = 1 + 0.2 * rnd(B, Cin, seed=5), 0.3 * rnd(B, Cin, seed=6)
-        xin = q(torch.relu(xin * sc.float().double()[:, :, None, None] + sh.float().double()[:, :, None, None]), dtype)
+        xin, st = apply_nr(xin, B, Cin, dtype)
     ref = F.conv2d(xin, q(w, dtype), bias.float().double(), stride=stride, padding=k // 2) + q(res, dtype)
     pack = K.pack_conv(w.float().to(DEV), 0, K.BF16 if dtype == torch.bfloat16 else K.F32)
-    y, _ = K.conv_fwd(nhwc(x, dtype), pack, Cout, k, stride, bias=bias.float().to(DEV),
-                      scale=sc.float().to(DEV) if prologue else None, shift=sh.float().to(DEV) if prologue else None,
-                      relu_in=True, residual=nhwc(res, dtype))
+    y, _ = K.conv_fwd(nhwc(x, dtype), pack, Cout, k, stride, bias=bias.float().to(DEV), norm=st, relu_in=True,
+                      residual=nhwc(res, dtype))
     assert_close(nchw(y), ref, tol(dtype), "conv fwd %s" % (case,))
 
 
@@ -96,7 +102,8 @@ def test_conv_forward_nchw_out(dtype, J):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3), (2, 64, 64, 128, 128, 3), (3, 5, 7, 64, 128, 3),
-                                  (2, 16, 16, 128, 64, 1), (1, 4, 4, 16, 16, 3), (2, 32, 32, 128, 16, 3)])
+                                  (2, 16, 16, 128, 64, 1), (1, 4, 4, 16, 16, 3), (2, 32, 32, 128, 16, 3),
+                                  (3, 4, 4, 16, 16, 3), (3, 2, 2, 16, 16, 3), (3, 8, 8, 16, 16, 3), (3, 4, 4, 16, 32, 1)])
 def test_conv_dgrad_stride1(case, dtype):
     """data gradient = pwr_conv_fwd on dy with the kind-1 (flipped, transposed) weight pack."""
     from pixelwiseregression_amd import kernels as K
@@ -133,16 +140,14 @@ def test_conv_wgrad(case, dtype, prologue):
     B, H, W, Cin, Cout, k, stride, splits = case
     x = rnd(B, Cin, H, W, seed=1)
     xin = q(x, dtype)
-    sc = sh = None
+    st = None
     if prologue:
-        sc, sh = 1 + 0.2 * rnd(B, Cin, seed=5), 0.3 * rnd(B, Cin, seed=6)
-        xin = q(torch.relu(xin * sc.float().double()[:, :, None, None] + sh.float().double()[:, :, None, None]), dtype)
+        xin, st = apply_nr(xin, B, Cin, dtype)
     Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
     dy = rnd(B, Cout, Ho, Wo, seed=7)
     w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin, w, None, stride=stride, padding=k // 2).backward(q(dy, dtype))
-    dw = K.conv_wgrad(nhwc(x, dtype), nhwc(dy, dtype), Cout, k, stride, scale=sc.float().to(DEV) if prologue else None,
-                      shift=sh.float().to(DEV) if prologue else None, relu_in=True, splits=splits)
+    dw = K.conv_wgrad(nhwc(x, dtype), nhwc(dy, dtype), Cout, k, stride, norm=st, relu_in=True, splits=splits)
     assert_close(dw.double().cpu(), w.grad, tol(dtype), "wgrad %s" % (case,))
 
 
@@ -209,7 +214,8 @@ def test_catconv(dtype, J, P, Fo):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 128), (3, 2, 2, 64), (1, 128, 128, 32), (2, 5, 7, 16), (32, 4, 4, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 128), (3, 2, 2, 64), (1, 128, 128, 32), (2, 5, 7, 16), (32, 4, 4, 64),
+                                     (3, 4, 4, 16), (3, 2, 2, 16), (3, 8, 8, 32), (3, 16, 16, 16)])
 def test_instance_norm_stats_and_backward(dtype, B, H, W, C):
     from pixelwiseregression_amd import kernels as K
     y = rnd(B, C, H, W, seed=1) * (1 + rnd(1, C, 1, 1, seed=2).abs()) + 3 * rnd(1, C, 1, 1, seed=3)   # offsets >> std
@@ -218,18 +224,20 @@ def test_instance_norm_stats_and_backward(dtype, B, H, W, C):
     gd, bd = gamma.float().double().requires_grad_(), beta.float().double().requires_grad_()
     out = torch.relu(F.instance_norm(yq, None, None, gd, bd, True, 0.1, 1e-5))
     yd = nhwc(y, dtype)
-    mean, rstd, scale, shift = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=0)
+    state = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=0)
+    mean, rstd, scale, shift = state[0], state[1], state[2], state[3]
     mref = yq.detach().mean(dim=(2, 3))
     vref = yq.detach().var(dim=(2, 3), unbiased=False)
     assert_close(mean.double().cpu(), mref, 1e-5, "mean")
     assert_close(rstd.double().cpu(), (vref + 1e-5).rsqrt(), 2e-5, "rstd")
     # applying scale/shift reproduces relu(norm(y))
-    app = torch.relu(yq.detach() * scale.double().cpu()[:, :, None, None] + shift.double().cpu()[:, :, None, None])
+    app = torch.relu((yq.detach() - mean.double().cpu()[:, :, None, None]) * scale.double().cpu()[:, :, None, None]
+                     + shift.double().cpu()[:, :, None, None])
     assert_close(app, out.detach(), 2e-5, "apply")
     g = rnd(B, C, H, W, seed=6)
     add = rnd(B, C, H, W, seed=7)
     out.backward(q(g, dtype))
-    dy, dgam, dbet = K.norm_bwd(nhwc(g, dtype), yd, mean, rstd, scale, shift, relu=True, addend=nhwc(add, dtype))
+    dy, dgam, dbet = K.norm_bwd(nhwc(g, dtype), yd, state, relu=True, addend=nhwc(add, dtype))
     t = 5e-5 if dtype == torch.float32 else 2e-2
     assert_close(nchw(dy), yq.grad + q(add, dtype), t, "norm bwd dy")
     assert_close(dgam.double().cpu(), gd.grad, t, "dgamma")
@@ -249,24 +257,25 @@ def test_batch_norm_train_and_eval(dtype):
     out = torch.relu(F.batch_norm(yq, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5))
     yd = nhwc(y, dtype)
     rmd, rvd = rm.float().to(DEV), rv.float().to(DEV)
-    mean, rstd, scale, shift = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=1, running_mean=rmd,
-                                            running_var=rvd)
+    state = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=1, running_mean=rmd, running_var=rvd)
+    mean, scale, shift = state[0], state[2], state[3]
     assert_close(rmd.double().cpu(), rm_ref, 1e-5, "running_mean")
     assert_close(rvd.double().cpu(), rv_ref, 1e-5, "running_var")
-    app = torch.relu(yq.detach() * scale.double().cpu()[:, :, None, None] + shift.double().cpu()[:, :, None, None])
+    app = torch.relu((yq.detach() - mean.double().cpu()[:, :, None, None]) * scale.double().cpu()[:, :, None, None]
+                     + shift.double().cpu()[:, :, None, None])
     assert_close(app, out.detach(), 2e-5, "bn apply")
     g = rnd(B, C, H, W, seed=6)
     out.backward(q(g, dtype))
-    dy, dgam, dbet = K.norm_bwd(nhwc(g, dtype), yd, mean, rstd, scale, shift, relu=True, mode=1)
+    dy, dgam, dbet = K.norm_bwd(nhwc(g, dtype), yd, state, relu=True, mode=1)
     t = 5e-5 if dtype == torch.float32 else 2e-2
     assert_close(nchw(dy), yq.grad, t, "bn bwd dy")
     assert_close(dgam.double().cpu(), gd.grad, t, "bn dgamma")
     # eval mode
     ref_eval = torch.relu(F.batch_norm(q(y, dtype), rm.float().double(), rv.float().double(), gamma.float().double(),
                                        beta.float().double(), False, 0.1, 1e-5))
-    _, _, sc2, sh2 = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=2, running_mean=rm.float().to(DEV),
-                                  running_var=rv.float().to(DEV))
-    app = torch.relu(q(y, dtype) * sc2.double().cpu()[:, :, None, None] + sh2.double().cpu()[:, :, None, None])
+    st2 = K.norm_stats(yd, gamma.float().to(DEV), beta.float().to(DEV), mode=2, running_mean=rm.float().to(DEV),
+                       running_var=rv.float().to(DEV)).double().cpu()
+    app = torch.relu((q(y, dtype) - st2[0][:, :, None, None]) * st2[2][:, :, None, None] + st2[3][:, :, None, None])
     assert_close(app, ref_eval, 2e-5, "bn eval apply")
 
 
