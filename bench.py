@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- depth-frames/sec of the PixelwiseRegression hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one TRAINING step of BASELINE.json configs[1] (NYU shape: 14 joints, 128x128 crops, batch 32 per GPU,
+features 128, level 4, stage 2, instance norm, bf16 engine): forward + the 3-term loss of train.py:195-205
++ backward + AdamW(weight_decay=0) step (train.py:139-140), on seeded synthetic crops that are already
+resident in HBM.  Weak scaling: every rank processes its own 32-frame shard; gradients are all-reduced
+over RCCL per backward segment.  Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline      -- the dominant kernel (the 128->128 3x3 implicit-GEMM conv of the heads: 72 % of the conv
+                   FLOPs), timed live with HIP events at the workload's shape, against the dense bf16 MFMA peak
+  roofline_decoder -- the soft-argmax decoder (HBM bound) forward at the same batch, for reference
+  cpu_baseline  -- the CPU oracle ("port" of the reference's op sequence) timed on this host's cores
+  infer_frames_per_s -- forward+decode only (no_grad), same batch
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+J, S, P, F_, LEVEL, STAGE, B_PER_GPU = 14, 128, 64, 128, 4, 2, 32
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def train_loss(results, batch, alpha=1.0, lambda_h=1.0, lambda_d=0.01):
+    loss = 0
+    for (heat, depth, uvd) in results:                      # train.py:195-205
+        hl = lambda_h * torch.mean(torch.sum((heat - batch["heatmaps"]) ** 2, dim=(2, 3)))
+        dl = lambda_d * torch.mean(torch.sum((depth - batch["depthmaps"]) ** 2, dim=(2, 3)))
+        ul = torch.mean(torch.sum((uvd - batch["uvd"]) ** 2, dim=2))
+        loss = loss + alpha * ul + (1 - alpha) * (hl + dl)
+    return loss
+
+
+def time_head_conv(dev, B, iters=20):
+    """The dominant kernel at the workload's shape: x [B,64,64,128] bf16 -> conv3x3 128->128 (+ fused norm/ReLU prologue)."""
+    from pixelwiseregression_amd import kernels as K
+    x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
+    w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
+    pack = K.pack_conv(w, 0, K.BF16)
+    gamma, beta = torch.ones(F_, device=dev), torch.zeros(F_, device=dev)
+    st = K.norm_stats(x, gamma, beta, mode=0)
+    bias = torch.zeros(F_, device=dev)
+    for _ in range(3):
+        K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * B * P * P * F_ * F_ * 9
+    return t, flops
+
+
+def time_decoder(dev, B, iters=20):
+    from pixelwiseregression_amd import ops
+    z = torch.randn(B, J, P, P, device=dev)
+    D = torch.randn(B, J, P, P, device=dev)
+    m = (torch.rand(B, 1, P, P, device=dev) < 0.4).float()
+    L = torch.randn(B, 1, P, P, device=dev) * m
+    w = torch.ones(J, 1, device=dev)
+    for _ in range(3):
+        ops.decode_forward(z, D, L, m, w, "softmax")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.decode_forward(z, D, L, m, w, "softmax")
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    nbytes = 12.0 * B * J * P * P + 8.0 * B * P * P + 12.0 * B * J
+    return t, nbytes
+
+
+def cpu_baseline(Bc=4, iters=2):
+    """CPU oracle train step (fwd + loss + bwd + AdamW) on a bounded sample of the same workload."""
+    from oracle import model_ref
+    from pixelwiseregression_amd import PixelwiseRegression
+    from pixelwiseregression_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = PixelwiseRegression(J, stage=STAGE, label_size=P, features=F_, level=LEVEL, norm_method="instance")
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "filter" not in k) for k, v in m.state_dict().items()}
+    opt = torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=1e-4, weight_decay=0)
+    rc = model_ref.RefConfig(J, STAGE, P, F_, LEVEL, 3, "instance", "softmax")
+    batch = make_batch(Bc, J, S=S, seed=1234, dense_targets=True)
+
+    def step():
+        opt.zero_grad()
+        res = model_ref.forward(params, rc, batch["img"], batch["label_img"], batch["mask"], training=True)
+        loss = model_ref.train_loss(res, batch["uvd"], batch["heatmaps"], batch["depthmaps"], alpha=1.0)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": Bc / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps (fwd+loss+bwd+AdamW) of the CPU oracle at batch %d, same architecture and 128x128 crops, fp32, %d threads"
+                      % (iters, Bc, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default="hip", choices=["hip", "aten"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pixelwiseregression_amd import PixelwiseRegression
+    from pixelwiseregression_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    model = PixelwiseRegression(J, stage=STAGE, label_size=P, features=F_, level=LEVEL, norm_method="instance")
+    model = model.to(dev).set_precision(args.precision).set_backend(args.backend).train()
+    if world > 1:
+        from pixelwiseregression_amd.ddp import DataParallel
+        DataParallel(model)
+    if args.backend == "hip":
+        flat = torch.nn.Parameter(model.flat_parameters())
+        flat.grad = model.flat_grad()
+        opt = torch.optim.AdamW([flat], lr=1e-4, betas=(0.9, 0.999), weight_decay=0, fused=True)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0)
+    batch = make_batch(B_PER_GPU, J, S=S, seed=1234 + rank, device=dev, dense_targets=True)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        res = model(batch["img"], batch["label_img"], batch["mask"])
+        loss = train_loss(res, batch)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+
+    # inference (forward + decode), same batch
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            model(batch["img"], batch["label_img"], batch["mask"])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_inf = max(5, args.steps)
+        for _ in range(n_inf):
+            model(batch["img"], batch["label_img"], batch["mask"])
+        torch.cuda.synchronize()
+        dt_inf = (time.perf_counter() - t1) / n_inf
+
+    if rank == 0:
+        out = {
+            "metric": "depth-frames/sec (train step: fwd+loss+bwd+AdamW), NYU 14J 128x128",
+            "value": world * B_PER_GPU * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: NYU 14-joint, 128x128 depth crops, batch 32 per GPU, train (AdamW, %s), "
+                                   "features 128, level 4, stage 2, instance norm" % args.precision,
+                       "global_batch": world * B_PER_GPU, "backend": args.backend,
+                       "parallelism": "dp%d" % world if world > 1 else "single"},
+            "infer_frames_per_s": world * B_PER_GPU / dt_inf,
+            "final_loss": final_loss,
+        }
+        if args.backend == "hip":
+            t, flops = time_head_conv(dev, B_PER_GPU)
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<bf16,128x128 tile> 3x3 128->128 @64x64, B=%d" % B_PER_GPU,
+                               "achieved": flops / t / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": flops / t / 1e12 / PEAK_BF16_TFLOPS, "traffic": None, "us_per_launch": t * 1e6}
+            td, nb = time_decoder(dev, B_PER_GPU)
+            out["roofline_decoder"] = {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": td * 1e6}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""Data-parallel training across the GPUs of one node (new capability: the reference is single-GPU,
+SURVEY.md section 8e).  One process per GPU; the batch is sharded; every parameter gradient lives in ONE
+flat fp32 buffer whose layout follows the backward completion order, so the all-reduce is issued per
+backward segment (stage S-1, ..., stage 0, stem) on contiguous slices while the next segment still computes:
+
+    ddp = DataParallel(model)            # broadcasts rank 0's parameters, hooks the engine's backward
+    loss.backward()                      # RCCL all-reduce(SUM) of each finished segment overlaps the rest
+    optimizer.step()                     # gradients are already averaged
+
+3.3 M parameters = 13 MB fp32: on xGMI this is latency-bound, so three large slices beat per-tensor buckets.
+With instance norm samples are independent and the losses are batch means (train.py:197-199), hence the
+averaged shard gradients equal the single-GPU big-batch gradient.  With batch norm the statistics stay
+per replica (like torch DDP without SyncBatchNorm).
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, model, process_group=None, broadcast=True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.works = []
+        self.ranges = model.segment_ranges()
+        if broadcast:
+            dist.broadcast(model.flat_parameters(), src=0, group=process_group)
+            if getattr(model, "_flat_buf", None) is not None:
+                dist.broadcast(model._flat_buf, src=0, group=process_group)
+        model._ddp = self
+
+    def segment_done(self, model, seg, nseg):
+        b, e = self.ranges[seg]
+        self.works.append(dist.all_reduce(model.flat_grad()[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self, model):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        model.flat_grad().mul_(1.0 / self.world)

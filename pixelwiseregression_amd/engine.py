@@ -79,10 +79,10 @@ def _run_forward(model, plan, img, label_img, mask):
     B, J, P = plan.B, model.joints, model.label_size
     plan.bind(model, model.flat_grad() if plan.need_grad else None)
     stream = _lib.stream_ptr(dev)
-    ver = model._flat._version
-    if plan.packed_version != ver:
-        _lib.check(l.pwr_engine_pack(plan.h, stream), "pwr_engine_pack")
-        plan.packed_version = ver
+    # Re-pack the conv weights from the flat fp32 parameters on every forward (one launch, ~10 us): in-place updates
+    # through the per-parameter views (optimizers, load_state_dict) do not bump the flat buffer's version counter,
+    # so there is no cheap, reliable "unchanged" test -- and a stale pack would be silently wrong.
+    _lib.check(l.pwr_engine_pack(plan.h, stream), "pwr_engine_pack")
     outs = []
     for _ in range(model.stage):
         outs += [torch.empty(B, J, P, P, device=dev, dtype=torch.float32), torch.empty(B, J, P, P, device=dev, dtype=torch.float32),
@@ -132,7 +132,6 @@ class _EngineFn(torch.autograd.Function):
         fresh = all(p.grad is None for p in params)
         target = flat_grad if fresh else model._grad_scratch()
         plan.bind(model, target)
-        plan.packed_version = plan.packed_version  # packs unaffected by re-binding the gradient pointer
         n = flat_grad.numel()
         ddp = model._ddp
         for seg in range(plan.n_seg):
