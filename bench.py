@@ -86,12 +86,12 @@ def time_decoder(dev, B, iters=20):
     return t, nbytes
 
 
-def cpu_baseline(Bc=4, iters=2):
+def cpu_baseline(Bc=8, iters=2):
     """CPU oracle train step (fwd + loss + bwd + AdamW) on a bounded sample of the same workload."""
     from oracle import model_ref
     from pixelwiseregression_amd import PixelwiseRegression
     from pixelwiseregression_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # more threads than that only adds contention at this batch size
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = PixelwiseRegression(J, stage=STAGE, label_size=P, features=F_, level=LEVEL, norm_method="instance")

@@ -92,12 +92,13 @@ int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const floa
 
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 
-/* dw[cout_real][Cin][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
- * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout] (Cout may include zero-padded channels beyond cout_real);
+/* dw[cout_real][cin_real][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
+ * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout]; Cin / Cout may include zero-padded channels beyond cin_real /
+ * cout_real (the stage-input concat is padded 2J+1 -> multiple of 8, the heads' dy J -> multiple of 8);
  * slab: workspace of pwr_conv_wgrad_slab_bytes; `splits` partitions the pixel (K) dimension over workgroups. */
 int pwr_conv_wgrad(const void* x, const void* dy, const float* in_norm, int relu_in, float* slab,
-                   float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int cout_real, int ksize, int stride,
-                   int splits, int dtype, void* stream);
+                   float* dw, int accumulate, int B, int H, int W, int Cin, int cin_real, int Cout, int cout_real, int ksize,
+                   int stride, int splits, int dtype, void* stream);
 
 /* Stem conv with Cin = 1 (model.py:165).  img: fp32 [B,S,S]; w: OIHW fp32 [C0,1,k,k]; y: [B,S,S,C0]. */
 int pwr_stem_conv_fwd(const float* img, const float* w, const float* bias, void* y, int B, int S, int C0, int ksize,
@@ -148,7 +149,13 @@ int pwr_add_inplace(const void* x, void* y, long long n, int dtype, void* stream
  * out[j] (+)= sum_{b,n} x[b][j][n] for fp32 NCHW planes */
 int pwr_colsum_blocks(long long M);
 int pwr_colsum_nhwc(const void* x, float* slab, float* out, long long M, int C, int accumulate, int dtype, void* stream);
-int pwr_planesum_nchw(const float* x, float* out, int B, int J, int N, int accumulate, void* stream);
+int pwr_planesum_nchw(const float* x, float* part, float* out, int B, int J, int N, int accumulate, void* stream); /* part: B*J floats */
+/* The concat of model.py:208, cat[heatmaps(J), depthmaps(J), label_img(1)], as an NHWC tensor [B,N,Cp] (Cp = 2J+1 rounded up
+ * to a multiple of 8, extra channels zero) so that the stage-input 1x1 conv of stages >= 1 (model.py:137) runs on the matrix
+ * cores like every other conv; and the inverse for its gradient (gp / gd: fp32 [B,J,N], label channel dropped). */
+int pwr_cat_to_nhwc(const float* pmap, const float* dmap, const float* label, void* dst, int B, int J, int N, int Cp, int dtype,
+                    void* stream);
+int pwr_nhwc_to_cat_grad(const void* src, float* gp, float* gd, int B, int J, int N, int Cp, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Network engine: PixelwiseRegression.forward (model.py:200-210) and its backward as ONE static launch plan

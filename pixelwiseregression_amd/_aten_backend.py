@@ -45,6 +45,9 @@ def _head(m, seq, f):
 
 
 def aten_forward(m, img, label_img, mask):
+    if m._precision == "bf16" and not torch.is_autocast_enabled():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return aten_forward(m, img, label_img, mask)
     f = img
     for i in range(m.n_stem):
         f = _conv(getattr(m.conv, str(3 * i)), f, stride=2 if i == m.n_stem - 1 else 1)

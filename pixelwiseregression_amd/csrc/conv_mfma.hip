@@ -457,16 +457,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       }
 }
 
-// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic)
+// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  Threads run along co so the S
+// slab reads are coalesced; the (small) OIHW result is written with a stride.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cin,
-                                    int Cout, int CinPad, int CoutPad, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over co*Cin*taps (OIHW order)
+                                    int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over taps*Cin*Cout, co fastest
   const int total = Cout * Cin * taps;
   if (idx >= total) return;
-  const int tap = idx % taps, ci = (idx / taps) % Cin, co = idx / (taps * Cin);
+  const int co = idx % Cout, ci = (idx / Cout) % Cin, tap = idx / (Cout * Cin);
+  if (ci >= cin_real) return;
   float s = 0.f;
   for (int k = 0; k < S; ++k) s += slab[((size_t)(k * taps + tap) * CinPad + ci) * CoutPad + co];
-  dw[idx] = accumulate ? dw[idx] + s : s;
+  const size_t o = ((size_t)co * cin_real + ci) * taps + tap;
+  dw[o] = accumulate ? dw[o] + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,8 +584,8 @@ extern "C" size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int sp
 }
 
 extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_norm, int relu_in,
-                              float* slab, float* dw, int accumulate, int B, int H, int W, int Cin, int Cout, int cout_real,
-                              int ksize, int stride, int splits, int dtype, void* stream) {
+                              float* slab, float* dw, int accumulate, int B, int H, int W, int Cin, int cin_real, int Cout,
+                              int cout_real, int ksize, int stride, int splits, int dtype, void* stream) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
   if (Cin % EP || Cout % EP || (ksize != 1 && ksize != 3) || splits < 1) return PWR_EUNSUPPORTED;
   pwr::WgradParams p;
@@ -597,9 +600,9 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype == PWR_BF16 ? pwr::launch_wgrad<bf16_t>(p, s) : pwr::launch_wgrad<float>(p, s);
   if (rc) return rc;
-  if (cout_real <= 0 || cout_real > Cout) return PWR_EINVAL;
+  if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin) return PWR_EINVAL;
   const int total = cout_real * Cin * ksize * ksize;
   hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slab, dw, p.S, ksize * ksize,
-                     Cin, cout_real, p.CinPad, p.CoutPad, accumulate);
+                     Cin, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
   return (int)hipGetLastError();
 }

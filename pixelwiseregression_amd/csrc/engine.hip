@@ -55,6 +55,7 @@ struct ConvL {
   long long w, b;
   size_t pack_f = 0, pack_d = 0;
   int Cin, Cout, k, stride;
+  int cin_real = 0;  // < Cin when the input tensor carries zero-padded channels (stage-input concat)
 };
 struct PackDescHost {
   long long src_off, dst_off;
@@ -120,7 +121,7 @@ struct Engine {
   // ---------------------------------------------------------------- layer constructors
   ConvL conv_params(int cin, int cout, int k, int stride, bool mfma, bool need_dgrad) {
     ConvL c;
-    c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride;
+    c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.cin_real = cin;
     c.w = take_param((long long)cout * cin * k * k);
     c.b = take_param(cout);
     if (mfma) {
@@ -219,7 +220,7 @@ struct Engine {
     bwd_cur.push_back([=](Ctx& c) {
       int rc = pwr_conv_wgrad(c.arena + x.off, c.arena + y.goff, has_nr ? (float*)(c.arena + n.state) : nullptr,
                               1, (float*)(c.arena + E->scr_slab), c.grads + cv.w, 0,
-                              Bc, x.H, x.W, cv.Cin, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c.stream);
+                              Bc, x.H, x.W, cv.Cin, cv.cin_real, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c.stream);
       if (rc) return rc;
       if (bias_grad || (E->norm_mode == 1 && !c.training))
         rc = pwr_colsum_nhwc(c.arena + y.goff, (float*)(c.arena + E->scr_slab), c.grads + cv.b, (long long)M, cv.Cout, 0, dt, c.stream);
@@ -340,10 +341,10 @@ struct Engine {
     bwd_cur.push_back([=](Ctx& c) {
       int rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + g_nchw_off), c.arena + gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
       if (rc) return rc;
-      rc = pwr_planesum_nchw((const float*)(c.arena + g_nchw_off), c.grads + c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
+      rc = pwr_planesum_nchw((const float*)(c.arena + g_nchw_off), (float*)(c.arena + E->scr_S1), c.grads + c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
       if (rc) return rc;
       rc = pwr_conv_wgrad(c.arena + h3.off, c.arena + gT, (float*)(c.arena + n2.state), 1,
-                          (float*)(c.arena + E->scr_slab), c.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c.stream);
+                          (float*)(c.arena + E->scr_slab), c.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c.stream);
       if (rc) return rc;
       return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
                           Jp, c3.Cin, c3.k, 1, 0, dt, c.stream);
@@ -416,20 +417,23 @@ struct Engine {
       StageRec& R = recs[s];
       Tn x0;
       ConvL cin;
+      const int Cp = (2 * J + 1 + 7) / 8 * 8;
+      Tn xc;  // NHWC concat [B,P,P,Cp] for stages >= 1
       if (s == 0) {
         cin = conv_params(F, F, 1, 1, true, true);
       } else {
-        cin = conv_params(2 * J + 1, F, 1, 1, false, false);
+        cin = conv_params(2 * J + 1, F, 1, 1, true, true);   // packs are built from the 2J+1 real channels ...
+        cin.Cin = Cp;                                        // ... the tensor it reads has Cp (zero-padded) channels
       }
       // hourglass params come before the heads' in named_parameters order; plane_regression.w comes first in its module
       if (s == 0) {
         x0 = conv_fwd(ystem, &nstem, cin, nullptr, tr);
       } else {
-        x0 = tensor(P, P, F, tr);
+        xc = tensor(P, P, Cp, tr);
         const int sp = s - 1;
-        fwd.push_back([=](Ctx& c) {
-          return pwr_catconv_fwd(c.out_p[sp], c.out_D[sp], c.label, c.params + cin.w, c.params + cin.b, c.arena + x0.off, Bc, N, Jc, Fc, dt, c.stream);
-        });
+        const Tn xcc = xc;
+        fwd.push_back([=](Ctx& c) { return pwr_cat_to_nhwc(c.out_p[sp], c.out_D[sp], c.label, c.arena + xcc.off, Bc, Jc, N, Cp, dt, c.stream); });
+        x0 = conv_fwd(xc, nullptr, cin, nullptr, tr);
       }
       std::vector<Op> saved;
       std::swap(saved, bwd_cur);  // (empty) -- keep bwd_cur clean for the hourglass
@@ -486,13 +490,10 @@ struct Engine {
         } else {
           const int sp = s - 1;
           const StageRec Rp = recs[sp];
-          want_slab((size_t)pwr_catconv_wgrad_blocks(B, N) * (2 * J + 2) * F * 4);
+          const Tn xcc = xc;
+          conv_bwd(xc, nullptr, cin, x0, true, true, false);   // dW [F][2J+1], db, and d(concat) into xc.goff
           bwd_cur.push_back([=](Ctx& c) {
-            int rc = pwr_catconv_wgrad(c.out_p[sp], c.out_D[sp], c.label, c.arena + x0.goff, (float*)(c.arena + E->scr_slab), c.grads + cin.w,
-                                       c.grads + cin.b, 0, Bc, N, Jc, Fc, dt, c.stream);
-            if (rc) return rc;
-            return pwr_catconv_dgrad(c.arena + x0.goff, c.params + cin.w, (float*)(c.arena + Rp.gH), (float*)(c.arena + Rp.gD), Bc, N, Jc, Fc, dt,
-                                     c.stream);
+            return pwr_nhwc_to_cat_grad(c.arena + xcc.goff, (float*)(c.arena + Rp.gH), (float*)(c.arena + Rp.gD), Bc, Jc, N, Cp, dt, c.stream);
           });
         }
         std::swap(stage_bwd[s], bwd_cur);

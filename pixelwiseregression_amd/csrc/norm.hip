@@ -178,50 +178,64 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restri
   }
 }
 
-// S1,S2 [B,C] (already divided by N); instance: per (b,c); batch: summed over b and broadcast.
-// dgamma[c] (+)= sum_b sum gm*xn ; dbeta[c] (+)= sum_b sum gm  -- done by one thread per c.
-__global__ void norm_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ S1, float* __restrict__ S2,
-                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int HW, int C,
-                                         int nchunks, int batch_mode, int accumulate) {
+// Stage A: one thread per (b,c): T1,T2[b,c] = sums over the pixel chunks (fixed order).  S1,S2 = T/HW for instance norm.
+__global__ void norm_bwd_sum_kernel(const float* __restrict__ partial, float* __restrict__ S1, float* __restrict__ S2, int B, int HW,
+                                    int C, int nchunks, int batch_mode) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
+    s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
+  }
+  const float inv = batch_mode ? 1.f : 1.f / (float)HW;
+  S1[idx] = s1 * inv; S2[idx] = s2 * inv;
+}
+// Stage B: one thread per c: dgamma/dbeta (+)= sum over b; batch norm: S1,S2 <- total/(B*HW) broadcast to every b.
+__global__ void norm_bwd_param_kernel(float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int B, int HW, int C, int batch_mode, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float t1 = 0.f, t2 = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-      s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
-      s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
-    }
-    t1 += s1; t2 += s2;
-    if (!batch_mode) { S1[b * C + c] = s1 / (float)HW; S2[b * C + c] = s2 / (float)HW; }
-  }
+  for (int b = 0; b < B; ++b) { t1 += S1[b * C + c]; t2 += S2[b * C + c]; }
   if (batch_mode) {
     const float n = (float)B * (float)HW;
     for (int b = 0; b < B; ++b) { S1[b * C + c] = t1 / n; S2[b * C + c] = t2 / n; }
+  } else {
+    t1 *= (float)HW; t2 *= (float)HW;   // S held sums/HW
   }
   dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
   dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
 }
 
-// dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend)
+// dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend).  Same (chunk, b) decomposition as the partial kernels so that the
+// per-channel constants are loaded once per thread, not once per element.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                              const float* __restrict__ state, int B,
                                                              const float* __restrict__ S1, const float* __restrict__ S2,
                                                              const T* __restrict__ addend, T* __restrict__ dy, int HW, int C,
-                                                             long long total_chunks, int relu) {
-  const float* __restrict__ mean = state;
-  const float* __restrict__ rstd = state + (size_t)B * C;
-  const float* __restrict__ scale = state + (size_t)2 * B * C;
-  const float* __restrict__ shift = state + (size_t)3 * B * C;
+                                                             int nchunks, int relu) {
   constexpr int EP = Elem<T>::kPer16B;
   typedef typename Vec16<T>::type V;
-  const int cpp = C / EP;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256) {
-    const int cq = (int)(i % cpp);
-    const long long pix = i / cpp;
-    const int b = (int)(pix / HW);
-    const size_t off = (size_t)pix * C + cq * EP;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  if (pj >= pl) return;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const size_t base = (size_t)b * HW * C;
+  const size_t plane = (size_t)B * C;
+  float mu[EP], rs[EP], sc[EP], sh[EP], s1[EP], s2[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int c = b * C + cq * EP + e;
+    mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
+    s1[e] = S1[c]; s2[e] = S2[c];
+  }
+  for (int pp = p0 + pj; pp < p1; pp += pl) {
+    const size_t off = base + (size_t)pp * C + cq * EP;
     V gv = *reinterpret_cast<const V*>(g + off);
     V yv = *reinterpret_cast<const V*>(y + off);
     V av = {};
@@ -229,13 +243,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     V o;
 #pragma unroll
     for (int e = 0; e < EP; ++e) {
-      const int c = b * C + cq * EP + e;
       const float yy = Elem<T>::to_f(yv[e]);
       float gg = Elem<T>::to_f(gv[e]);
-      const float sc = scale[c];
-      if (relu && !(fmaf(yy - mean[c], sc, shift[c]) > 0.f)) gg = 0.f;
-      const float xn = (yy - mean[c]) * rstd[c];
-      float r = sc * (gg - S1[c] - xn * S2[c]);     // scale = gamma*rstd
+      if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
+      const float xn = (yy - mu[e]) * rs[e];
+      float r = sc[e] * (gg - s1[e] - xn * s2[e]);     // scale = gamma*rstd
       if (addend) r += Elem<T>::to_f(av[e]);
       o[e] = Elem<T>::from_f(r);
     }
@@ -300,8 +312,6 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
   const int nch = norm_chunks(B, HW);
   const int pl = 256 / (C / EP);
   const size_t sh = (size_t)pl * 2 * C * 4;
-  const long long total = (long long)B * HW * (C / EP);
-  int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dtype == PWR_BF16) {
     hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y,
                        state, B, partial, HW, C, nch, relu);
@@ -309,18 +319,19 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
     hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state,
                        B, partial, HW, C, nch, relu);
   }
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, S1, S2, dgamma, dbeta, B, HW, C, nch,
-                     mode == 1 ? 1 : 0, accumulate);
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, S1, S2, B, HW, C, nch, mode == 1 ? 1 : 0);
+  hipLaunchKernelGGL(norm_bwd_param_kernel, dim3((C + 63) / 64), dim3(64), 0, s, S1, S2, dgamma, dbeta, B, HW, C, mode == 1 ? 1 : 0,
+                     accumulate);
   if (mode == 2) {  // statistics are constants: dy = scale * gm
     hipMemsetAsync(S1, 0, (size_t)B * C * 4, s);
     hipMemsetAsync(S2, 0, (size_t)B * C * 4, s);
   }
   if (dtype == PWR_BF16) {
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
-                       S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, total, relu);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
+                       S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
   } else {
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
-                       S1, S2, (const float*)addend, (float*)dy, HW, C, total, relu);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
+                       S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
   }
   return (int)hipGetLastError();
 }

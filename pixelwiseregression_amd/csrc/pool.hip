@@ -173,6 +173,51 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __re
   }
 }
 
+// concat of model.py:208 as an NHWC tensor: channels [0,J) heatmaps, [J,2J) depthmaps, 2J label_img, rest zero.
+// pmap/dmap [B,J,N], label [B,1,N] fp32 -> dst [B,N,Cp] T.  grid (N/64, B, ceil(Cp/64)).
+template <typename T>
+__global__ __launch_bounds__(256) void cat_to_nhwc_kernel(const float* __restrict__ pmap, const float* __restrict__ dmap,
+                                                          const float* __restrict__ label, T* __restrict__ dst, int B, int J, int N, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y, p0 = blockIdx.x * 64, c0 = blockIdx.z * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cl = i / 64, pp = i % 64, c = c0 + cl;
+    float v = 0.f;
+    if (p0 + pp < N) {
+      if (c < J) v = pmap[((size_t)b * J + c) * N + p0 + pp];
+      else if (c < 2 * J) v = dmap[((size_t)b * J + (c - J)) * N + p0 + pp];
+      else if (c == 2 * J) v = label[(size_t)b * N + p0 + pp];
+    }
+    tile[cl][pp] = v;
+  }
+  __syncthreads();
+  const int cw = min(64, Cp - c0);
+  for (int i = threadIdx.x; i < 64 * cw; i += 256) {
+    const int pp = i / cw, cl = i % cw;
+    if (p0 + pp < N) dst[((size_t)b * N + p0 + pp) * Cp + c0 + cl] = Elem<T>::from_f(tile[cl][pp]);
+  }
+}
+// inverse for the gradients: src [B,N,Cp] T -> gp [B,J,N], gd [B,J,N] fp32 (channels >= 2J dropped)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_cat_grad_kernel(const T* __restrict__ src, float* __restrict__ gp, float* __restrict__ gd,
+                                                               int B, int J, int N, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y, p0 = blockIdx.x * 64, c0 = blockIdx.z * 64;
+  const int cw = min(64, Cp - c0);
+  for (int i = threadIdx.x; i < 64 * cw; i += 256) {
+    const int pp = i / cw, cl = i % cw;
+    tile[cl][pp] = (p0 + pp < N) ? Elem<T>::to_f(src[((size_t)b * N + p0 + pp) * Cp + c0 + cl]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cl = i / 64, pp = i % 64, c = c0 + cl;
+    if (cl < cw && p0 + pp < N) {
+      if (c < J) gp[((size_t)b * J + c) * N + p0 + pp] = tile[cl][pp];
+      else if (c < 2 * J) gd[((size_t)b * J + (c - J)) * N + p0 + pp] = tile[cl][pp];
+    }
+  }
+}
+
 template <typename T>
 __global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {  // y += x
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -269,16 +314,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     }
   }
 }
-// NCHW fp32 [B][J][N] -> out[j] = sum_{b,n}
-__global__ __launch_bounds__(256) void planesum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int J, int N,
-                                                       int accumulate) {
+// NCHW fp32 [B][J][N]: part[b][j] = sum_n  (grid (J,B)); then out[j] (+)= sum_b part[b][j]
+__global__ __launch_bounds__(256) void planesum_kernel(const float* __restrict__ x, float* __restrict__ part, int B, int J, int N) {
   __shared__ float red[4];
-  const int j = blockIdx.x;
+  const int j = blockIdx.x, b = blockIdx.y;
   float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int i = threadIdx.x; i < N; i += 256) s += x[((size_t)b * J + j) * N + i];
+  for (int i = threadIdx.x; i < N; i += 256) s += x[((size_t)b * J + j) * N + i];
   s = block_sum1(s, red);
-  if (threadIdx.x == 0) out[j] = accumulate ? out[j] + s : s;
+  if (threadIdx.x == 0) part[(size_t)b * J + j] = s;
 }
 }  // namespace pwr
 
@@ -295,7 +338,24 @@ extern "C" int pwr_colsum_nhwc(const void* x, float* slab, float* out, long long
   return pwr_slab_reduce(slab, out, nb, C, accumulate, stream);
 }
 
-extern "C" int pwr_planesum_nchw(const float* x, float* out, int B, int J, int N, int accumulate, void* stream) {
-  hipLaunchKernelGGL(pwr::planesum_kernel, dim3(J), dim3(256), 0, (hipStream_t)stream, x, out, B, J, N, accumulate);
+extern "C" int pwr_planesum_nchw(const float* x, float* part, float* out, int B, int J, int N, int accumulate, void* stream) {
+  hipLaunchKernelGGL(pwr::planesum_kernel, dim3(J, B), dim3(256), 0, (hipStream_t)stream, x, part, B, J, N);
+  return pwr_slab_reduce(part, out, B, J, accumulate, stream);
+}
+
+extern "C" int pwr_cat_to_nhwc(const float* pmap, const float* dmap, const float* label, void* dst, int B, int J, int N, int Cp, int dtype,
+                               void* stream) {
+  if (Cp < 2 * J + 1 || Cp % 8) return PWR_EINVAL;
+  dim3 grid((N + 63) / 64, B, (Cp + 63) / 64);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((pwr::cat_to_nhwc_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, pmap, dmap, label, (bf16_t*)dst, B, J, N, Cp);
+  else hipLaunchKernelGGL((pwr::cat_to_nhwc_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pmap, dmap, label, (float*)dst, B, J, N, Cp);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_nhwc_to_cat_grad(const void* src, float* gp, float* gd, int B, int J, int N, int Cp, int dtype, void* stream) {
+  if (Cp < 2 * J + 1 || Cp % 8) return PWR_EINVAL;
+  dim3 grid((N + 63) / 64, B, (Cp + 63) / 64);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((pwr::nhwc_to_cat_grad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, gp, gd, B, J, N, Cp);
+  else hipLaunchKernelGGL((pwr::nhwc_to_cat_grad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, gp, gd, B, J, N, Cp);
   return (int)hipGetLastError();
 }

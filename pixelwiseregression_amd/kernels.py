@@ -75,15 +75,16 @@ def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_in=True
     return y, yn
 
 
-def conv_wgrad(x, dy, cout_real, ksize, stride=1, norm=None, relu_in=True, splits=8, dw=None):
+def conv_wgrad(x, dy, cout_real, ksize, stride=1, norm=None, relu_in=True, splits=8, dw=None, cin_real=None):
     l = _lib.lib()
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
     slab = torch.empty(l.pwr_conv_wgrad_slab_bytes(Cout, Cin, ksize, splits) // 4, dtype=torch.float32, device=x.device)
     acc = dw is not None
+    cin_real = cin_real or Cin
     if dw is None:
-        dw = torch.empty(cout_real, Cin, ksize, ksize, dtype=torch.float32, device=x.device)
-    _lib.check(l.pwr_conv_wgrad(_p(x), _p(dy), _p(norm), int(relu_in), _p(slab), _p(dw), int(acc), B, H, W, Cin,
+        dw = torch.empty(cout_real, cin_real, ksize, ksize, dtype=torch.float32, device=x.device)
+    _lib.check(l.pwr_conv_wgrad(_p(x), _p(dy), _p(norm), int(relu_in), _p(slab), _p(dw), int(acc), B, H, W, Cin, cin_real,
                                 Cout, cout_real, ksize, stride, splits, _dt(x), _s(x)), "pwr_conv_wgrad")
     return dw
 
@@ -206,3 +207,40 @@ def nchw_to_nhwc_pad(src, Jp, dtype):
     dst = torch.empty(B, P, P, Jp, dtype=dtype, device=src.device)
     _lib.check(l.pwr_nchw_to_nhwc_pad(_p(src), _p(dst), B, J, P * P, Jp, _dt(dst), _s(src)), "pwr_nchw_to_nhwc_pad")
     return dst
+
+
+def cat_to_nhwc(pmap, dmap, label, dtype):
+    l = _lib.lib()
+    B, J, P, _ = pmap.shape
+    Cp = (2 * J + 1 + 7) // 8 * 8
+    dst = torch.empty(B, P, P, Cp, dtype=dtype, device=pmap.device)
+    _lib.check(l.pwr_cat_to_nhwc(_p(pmap), _p(dmap), _p(label), _p(dst), B, J, P * P, Cp, _dt(dst), _s(dst)), "pwr_cat_to_nhwc")
+    return dst
+
+
+def nhwc_to_cat_grad(src, J):
+    l = _lib.lib()
+    B, P, _, Cp = src.shape
+    gp = torch.empty(B, J, P, P, dtype=torch.float32, device=src.device)
+    gd = torch.empty_like(gp)
+    _lib.check(l.pwr_nhwc_to_cat_grad(_p(src), _p(gp), _p(gd), B, J, P * P, Cp, _dt(src), _s(src)), "pwr_nhwc_to_cat_grad")
+    return gp, gd
+
+
+def colsum_nhwc(x):
+    l = _lib.lib()
+    C = x.shape[-1]
+    M = x.numel() // C
+    slab = torch.empty(l.pwr_colsum_blocks(M) * C, dtype=torch.float32, device=x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.check(l.pwr_colsum_nhwc(_p(x), _p(slab), _p(out), M, C, 0, _dt(x), _s(x)), "pwr_colsum_nhwc")
+    return out
+
+
+def planesum_nchw(x):
+    l = _lib.lib()
+    B, J, P, _ = x.shape
+    part = torch.empty(B * J, dtype=torch.float32, device=x.device)
+    out = torch.empty(J, dtype=torch.float32, device=x.device)
+    _lib.check(l.pwr_planesum_nchw(_p(x), _p(part), _p(out), B, J, P * P, 0, _s(x)), "pwr_planesum_nchw")
+    return out

@@ -301,3 +301,45 @@ def test_maxpool_and_upsample(dtype, B, H, W, C):
     (h * gh).sum().backward()
     dx = K.maxpool_bwd(xd, nhwc(gh, dtype), addend=nhwc(g, dtype))
     assert_close(nchw(dx), q(x.grad + g, dtype), 1e-6 if dtype == torch.float32 else 8e-3, "maxpool bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("J,P", [(14, 64), (4, 16), (21, 10), (42, 32)])
+def test_concat_nhwc_roundtrip_and_stage_input_conv(dtype, J, P):
+    """model.py:208 concat as NHWC + model.py:137 1x1 conv on the MFMA path, fwd / wgrad / dgrad, vs torch on the CPU."""
+    from pixelwiseregression_amd import kernels as K
+    B, Fo = 2, 64
+    pm, dm, lb = rnd(B, J, P, P, seed=1).abs(), rnd(B, J, P, P, seed=2), rnd(B, 1, P, P, seed=3)
+    cat = torch.cat([pm, dm, lb], 1).float().double()
+    xc = K.cat_to_nhwc(pm.float().to(DEV), dm.float().to(DEV), lb.float().to(DEV), dtype)
+    Cp = xc.shape[-1]
+    assert Cp % 8 == 0 and Cp >= 2 * J + 1
+    assert_close(nchw(xc)[:, :2 * J + 1], q(cat, dtype), 1e-7, "concat")
+    assert float(xc[..., 2 * J + 1:].abs().max()) == 0.0 if Cp > 2 * J + 1 else True
+    w = rnd(Fo, 2 * J + 1, 1, 1, seed=4, scale=0.2)
+    catq = q(cat, dtype).requires_grad_()
+    wd = q(w, dtype).requires_grad_()
+    ref = F.conv2d(catq, wd, None)
+    dt = K.BF16 if dtype == torch.bfloat16 else K.F32
+    y, _ = K.conv_fwd(xc, K.pack_conv(w.float().to(DEV), 0, dt), Fo, 1, 1)
+    assert_close(nchw(y), ref.detach(), tol(dtype), "stage-in fwd")
+    dy = rnd(B, Fo, P, P, seed=6)
+    ref.backward(q(dy, dtype))
+    dw = K.conv_wgrad(xc, nhwc(dy, dtype), Fo, 1, 1, splits=4, cin_real=2 * J + 1)
+    assert dw.shape == (Fo, 2 * J + 1, 1, 1)
+    assert_close(dw.double().cpu(), wd.grad, tol(dtype), "stage-in wgrad")
+    dx, _ = K.conv_fwd(nhwc(dy, dtype), K.pack_conv(w.float().to(DEV), 1, dt), Cp, 1, 1)
+    gp, gd = K.nhwc_to_cat_grad(dx, J)
+    assert_close(gp.double().cpu(), catq.grad[:, :J], tol(dtype), "stage-in dgrad p")
+    assert_close(gd.double().cpu(), catq.grad[:, J:2 * J], tol(dtype), "stage-in dgrad d")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bias_gradient_sums(dtype):
+    from pixelwiseregression_amd import kernels as K
+    x = rnd(3, 64, 17, 9, seed=1)
+    assert_close(K.colsum_nhwc(nhwc(x, dtype)).double().cpu(), q(x, dtype).sum(dim=(0, 2, 3)), 1e-5, "colsum")
+    x = rnd(2, 128, 64, 64, seed=2)
+    assert_close(K.colsum_nhwc(nhwc(x, dtype)).double().cpu(), q(x, dtype).sum(dim=(0, 2, 3)), 1e-5, "colsum big")
+    g = rnd(5, 14, 64, 64, seed=3).float()
+    assert_close(K.planesum_nchw(g.to(DEV)).double().cpu(), g.double().sum(dim=(0, 2, 3)), 1e-5, "planesum")
