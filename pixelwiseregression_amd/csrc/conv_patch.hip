@@ -1,0 +1,275 @@
+// 3x3 stride-1 convolution with the input patch resident in LDS (the hot kernel: the heads' 128->128 convs are 72 % of
+// the conv FLOPs of /root/reference/model.py:54-65 / :103-114; also the stem's 32->64 / 64->128 convs :171-179, the
+// hourglass 64->64 convs :16 at 64x64 / 32x32, and every data gradient of those, which is the same conv with flipped weights).
+//
+// Workgroup = 256 threads; output tile = 4 rows x 32 columns = 128 pixels x BN channels.  The 6 x 34 pixel input
+// patch (tile + halo) is loaded ONCE from HBM/L2 -- with the preceding norm + ReLU applied on the way ("NR prologue") --
+// into LDS as [pixel][Cin] with an XOR swizzle of the 16-byte slots, and all nine taps read their shifted windows from
+// there: 1.6x input traffic instead of the 9x of the universal im2col-on-the-fly kernel, and the NR arithmetic is done
+// 1.6x instead of 9x.  Weights stream through a double-buffered [BN][64 B] LDS tile per (tap, K chunk); they are shared
+// by all workgroups and stay in L2.  MFMA 32x32x16 bf16 (or 32x32x2 fp32 in parity mode), fp32 accumulate.
+#include "conv_common.h"
+#include "pwr.h"
+
+namespace pwr {
+
+template <int NSLOT>
+__device__ __forceinline__ int patch_off(int pix, int slot) {
+  // byte offset of 16-byte slot `slot` of patch pixel `pix`; swizzled so that the 16-lane groups of ds_read_b128
+  // (32 consecutive pixels, same slot) hit 16 distinct bank slots
+  constexpr int SH = NSLOT >= 16 ? 0 : (NSLOT == 8 ? 1 : 2);
+  constexpr int MASK = (NSLOT >= 16 ? 16 : NSLOT) - 1;
+  return (pix * NSLOT + (slot ^ ((pix >> SH) & MASK))) * 16;
+}
+
+template <typename T, int CIN, int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
+  typedef typename Vec16<T>::type V;
+  constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
+  constexpr int TH = 4, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+  constexpr int BM = TH * TW, BN = WN * NR * 32;
+  static_assert(WM * MR * 32 == BM, "tile");
+  constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
+  constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
+  constexpr int PATCH_BYTES = NPIX * NSLOT * 16;
+  constexpr int WBUF_BYTES = BN * 64;
+  constexpr int NB = (BN * 4 + 255) / 256;
+  constexpr int EROWS = 64, EPITCH = BN + 4;
+  constexpr int EPI_BYTES = EROWS * EPITCH * 4;
+  constexpr int LDS_BYTES = (PATCH_BYTES + 2 * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + 2 * WBUF_BYTES) : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  char* patch = smem;
+  char* wbuf = smem + PATCH_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = t / tiles_img, tr = t - b * tiles_img;
+  const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x) + (size_t)b * p.H * p.W * CIN;
+  const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+
+  // ---- weights of iteration 0 in flight while the patch is staged
+  V rb[NB];
+  auto load_w = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int s = tid + 256 * i;
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4)
+        rb[i] = *reinterpret_cast<const V*>(w + ((size_t)it * p.CoutPad + n0 + (s >> 2)) * KE + (s & 3) * EP);
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int s = tid + 256 * i;
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(wbuf + buf * WBUF_BYTES + lds_off(s >> 2, s & 3)) = rb[i];
+    }
+  };
+  load_w(0);
+
+  // ---- stage the patch: thread -> fixed slot (channels), pixels tid/NSLOT + k*(256/NSLOT)
+  {
+    const int slot = tid % NSLOT;
+    float mu[EP], sc[EP], be[EP];
+    const bool nr = p.in_norm != nullptr;
+    if (nr) {
+      const size_t plane = (size_t)p.B * CIN;
+      const float* st = p.in_norm + (size_t)b * CIN + slot * EP;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
+    }
+    constexpr int PSTEP = 256 / NSLOT;
+    constexpr int NIT = (NPIX + PSTEP - 1) / PSTEP;
+    V v[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int pix = tid / NSLOT + k * PSTEP;
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = ty0 + py - 1, ix = tx0 + px - 1;
+      ok[k] = pix < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      v[k] = V{};
+      if (ok[k]) v[k] = *reinterpret_cast<const V*>(x + ((size_t)iy * p.W + ix) * CIN + slot * EP);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int pix = tid / NSLOT + k * PSTEP;
+      if (pix < NPIX) {
+        V o = v[k];
+        if (nr && ok[k]) {
+#pragma unroll
+          for (int e = 0; e < EP; ++e) {
+            float f = fmaf(Elem<T>::to_f(v[k][e]) - mu[e], sc[e], be[e]);
+            if (p.relu_in) f = fmaxf(f, 0.f);
+            o[e] = Elem<T>::from_f(f);
+          }
+        }
+        *reinterpret_cast<V*>(patch + patch_off<NSLOT>(pix, slot)) = o;
+      }
+    }
+  }
+  store_w(0);
+  __syncthreads();
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  constexpr bool kTwoLevel = sizeof(T) == 4;
+  f32x16 acc2[kTwoLevel ? MR : 1][kTwoLevel ? NR : 1];
+  if constexpr (kTwoLevel) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int ITERS = 9 * KCH;
+  for (int it = 0; it < ITERS; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < ITERS) load_w(it + 1);
+    const int tap = it / KCH, kch = it - tap * KCH;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const char* lB = wbuf + buf * WBUF_BYTES;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      V a[MR], bb[NR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int trow = wm * MR + i;                       // tile row of this 32-pixel M sub-tile
+        const int pix = (trow + ky) * PW + (r + kx);
+        a[i] = *reinterpret_cast<const V*>(patch + patch_off<NSLOT>(pix, kch * 4 + 2 * ss + h));
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) bb[j] = *reinterpret_cast<const V*>(lB + lds_off(wn * NR * 32 + j * 32 + r, 2 * ss + h));
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    if constexpr (kTwoLevel) {
+      if ((it & 7) == 7 || it + 1 == ITERS) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
+      }
+    }
+    if (it + 1 < ITERS) store_w(buf ^ 1);
+    __syncthreads();
+  }
+  if constexpr (kTwoLevel) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) acc[i][j] = acc2[i][j];
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32, 64 tile pixels at a time) -> coalesced 16-byte stores
+  float* E = reinterpret_cast<float*>(smem);
+  constexpr int PASSES = BM / EROWS;
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int wrow0 = wm * MR * 32;
+    if (wrow0 / EROWS == ps) {
+      const int er0 = wrow0 - ps * EROWS;
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = er0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            E[row * EPITCH + wn * NR * 32 + j * 32 + r] = acc[i][j][e];
+          }
+    }
+    __syncthreads();
+    if (p.y) {
+      T* __restrict__ y = reinterpret_cast<T*>(p.y);
+      const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+      constexpr int CPR = BN / EP;
+      for (int c = tid; c < EROWS * CPR; c += 256) {
+        const int row = c / CPR, cc = (c - row * CPR) * EP;
+        const int ml = ps * EROWS + row, n = n0 + cc;
+        const int oy = ty0 + ml / TW, ox = tx0 + ml % TW;
+        if (n < p.Cout) {
+          const size_t m = (size_t)b * HW + (size_t)oy * p.W + ox;
+          float v[EP];
+#pragma unroll
+          for (int e = 0; e < EP; ++e) v[e] = E[row * EPITCH + cc + e];
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) v[e] += p.bias[n + e];
+          }
+          if (res) {
+            V rv = *reinterpret_cast<const V*>(res + m * p.Cout + n);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) v[e] += Elem<T>::to_f(rv[e]);
+          }
+          V o;
+#pragma unroll
+          for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(v[e]);
+          *reinterpret_cast<V*>(y + m * p.Cout + n) = o;
+        }
+      }
+    }
+    if (p.y_nchw) {
+      for (int c = tid; c < EROWS * BN; c += 256) {
+        const int col = c / EROWS, row = c - col * EROWS;
+        const int ml = ps * EROWS + row, n = n0 + col;
+        if (n < p.Cout) {
+          const int oy = ty0 + ml / TW, ox = tx0 + ml % TW;
+          float v = E[row * EPITCH + col];
+          if (p.bias) v += p.bias[n];
+          p.y_nchw[((size_t)b * p.Cout + n) * HW + (size_t)oy * p.W + ox] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+bool conv_patch_applicable(const ConvParams& p) {
+  return p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.W % 32 == 0 && p.H % 4 == 0 &&
+         (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
+}
+
+template <typename T, int CIN>
+static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
+  const int bn = pick_bn(p.Cout);
+  dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2>), grid, block, 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 1, 1, 1>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_patch_t(const ConvParams& p, hipStream_t s) {
+  if (p.Cin == 128) return launch_patch_cin<T, 128>(p, s);
+  if (p.Cin == 64) return launch_patch_cin<T, 64>(p, s);
+  return launch_patch_cin<T, 32>(p, s);
+}
+
+int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
+  return dtype == PWR_BF16 ? launch_patch_t<bf16_t>(p, s) : launch_patch_t<float>(p, s);
+}
+
+}  // namespace pwr

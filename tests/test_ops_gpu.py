@@ -64,6 +64,12 @@ CONV_CASES = [
     (1, 2, 2, 64, 64, 3, 1),
     (1, 16, 16, 64, 256, 3, 1),
     (2, 128, 128, 32, 64, 3, 1),
+    # LDS-patch kernel shapes (W % 32 == 0, H % 4 == 0, Cin in {32,64,128}), incl. several tiles per row / image
+    (2, 32, 32, 64, 64, 3, 1),
+    (3, 64, 64, 64, 32, 3, 1),
+    (1, 128, 128, 64, 128, 3, 1),
+    (2, 4, 32, 128, 128, 3, 1),
+    (1, 8, 96, 32, 16, 3, 1),
 ]
 
 
@@ -90,9 +96,10 @@ def test_conv_forward(case, dtype, prologue):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("J", [14, 4, 21])
-def test_conv_forward_nchw_out(dtype, J):
+@pytest.mark.parametrize("H,Cin", [(32, 64), (64, 128), (16, 64)])
+def test_conv_forward_nchw_out(dtype, J, H, Cin):
     from pixelwiseregression_amd import kernels as K
-    B, H, Cin = 2, 32, 64
+    B = 2
     x, w, bias = rnd(B, Cin, H, H, seed=1), rnd(J, Cin, 3, 3, seed=2, scale=0.05), rnd(J, seed=3)
     ref = F.conv2d(q(x, dtype), q(w, dtype), bias.float().double(), padding=1)
     pack = K.pack_conv(w.float().to(DEV), 0, K.BF16 if dtype == torch.bfloat16 else K.F32)
