@@ -381,19 +381,188 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
       }
 }
 
-// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  Threads run along co so the S
-// slab reads are coalesced; the (small) OIHW result is written with a stride.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cin,
-                                    int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over taps*Cin*Cout, co fastest
-  const int total = Cout * Cin * taps;
-  if (idx >= total) return;
-  const int co = idx % Cout, ci = (idx / Cout) % Cin, tap = idx / (Cout * Cin);
-  if (ci >= cin_real) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += slab[((size_t)(k * taps + tap) * CinPad + ci) * CoutPad + co];
-  const size_t o = ((size_t)co * cin_real + ci) * taps + tap;
-  dw[o] = accumulate ? dw[o] + s : s;
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient with hardware-transposed LDS reads.  Both MFMA operands need 8 consecutive K (= pixel)
+// values of one channel per lane, while NHWC memory is channel-contiguous.  The tiles are therefore staged row-major
+// [pixel][channel] with plain coalesced 16-byte loads / ds_write_b128, and the fragments are read with
+// ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major).  Row pitch = 2*C + 64 bytes
+// keeps the four pixel rows of a group on different banks.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int pitch, int k0, int chb, int lane) {
+  const int li = lane & 15, cg = (lane >> 4) & 1, h = lane >> 5;
+  const char* a0 = tile + (k0 + 8 * h + (li >> 2)) * pitch + (chb + 16 * cg + 4 * (li & 3)) * 2;
+  typedef __attribute__((address_space(3))) bf16x4_t* lptr;
+  bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(a0));
+  bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(a0 + 4 * pitch));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+template <int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
+  typedef bf16_t T;
+  typedef bf16x8 V;
+  constexpr int KP = 32, EP = 8;
+  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;          // row pitches in bytes
+  constexpr int TILE_A = KP * PA, TILE_B = KP * PB;
+  constexpr int ACH = BM / EP, BCH = BN / EP;                // 16-byte chunks per pixel row
+  constexpr int NA = (KP * ACH + 255) / 256, NBL = (KP * BCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TILE_A + TILE_B)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tap = blockIdx.x, ky = tap / p.ksize, kx = tap - ky * p.ksize;
+  const int ntn = p.CoutPad / BN;
+  const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
+  const int ci0 = mtile * BM, co0 = ntile * BN;
+  const int split = blockIdx.z;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const int HoWo = p.Ho * p.Wo;
+  const int step0 = split * p.steps_per_split;
+  const int total_steps = (p.M + KP - 1) / KP;
+  int nsteps = total_steps - step0;
+  if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+  const size_t plane = (size_t)p.B * p.Cin;
+
+  V ra[NA], rb[NBL];
+  bool av[NA];
+  int ab[NA];
+  auto load_global = [&](int st) {
+    const int mbase = (step0 + st) * KP;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      const int pix = c / ACH, cq = c % ACH;
+      V v = {};
+      bool ok = false;
+      int b = 0;
+      if (c < KP * ACH) {
+        const int m = mbase + pix, ci = ci0 + cq * EP;
+        if (m < p.M && ci < p.Cin) {
+          b = m / HoWo;
+          const int rem = m - b * HoWo;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            ok = true;
+            v = *reinterpret_cast<const V*>(x + ((size_t)(b * p.H + iy) * p.W + ix) * p.Cin + ci);
+          }
+        }
+      }
+      ra[i] = v; av[i] = ok; ab[i] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int c = tid + 256 * i;
+      const int pix = c / BCH, cq = c % BCH;
+      V v = {};
+      if (c < KP * BCH) {
+        const int m = mbase + pix, co = co0 + cq * EP;
+        if (m < p.M && co < p.Cout) v = *reinterpret_cast<const V*>(dy + (size_t)m * p.Cout + co);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* lA = smem + buf * (TILE_A + TILE_B);
+    char* lB = lA + TILE_A;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      if (c < KP * ACH) {
+        const int pix = c / ACH, cq = c % ACH;
+        V v = ra[i];
+        if (p.in_norm && av[i]) v = nr_transform<T>(v, p.in_norm + (size_t)ab[i] * p.Cin + ci0 + cq * EP, plane, p.relu_in);
+        *reinterpret_cast<V*>(lA + pix * PA + cq * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int c = tid + 256 * i;
+      if (c < KP * BCH) *reinterpret_cast<V*>(lB + (c / BCH) * PB + (c % BCH) * 16) = rb[i];
+    }
+  };
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nsteps > 0) {
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < nsteps) load_global(st + 1);
+      const char* lA = smem + buf * (TILE_A + TILE_B);
+      const char* lB = lA + TILE_A;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        V a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a[i] = frag_tr(lA, PA, ss * 16, wm * MR * 32 + i * 32, lane);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) b[j] = frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (st + 1 < nsteps) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  const int r = lane & 31, h = lane >> 5;
+  const int taps = p.ksize * p.ksize;
+  float* __restrict__ out = p.slab + ((size_t)(split * taps + tap) * p.CinPad) * p.CoutPad;
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + wm * MR * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int co = co0 + wn * NR * 32 + j * 32 + r;
+        out[(size_t)ci * p.CoutPad + co] = acc[i][j][e];
+      }
+}
+
+// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 32 ci)
+// tile: slab reads are coalesced along co, the sums are transposed through LDS, the OIHW rows are written contiguously.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps,
+                                                           int Cin, int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
+  extern __shared__ float tile[];                 // [32 co][32*taps + 1]
+  const int pitch = 32 * taps + 1;
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+  const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;   // col -> co, 8 row groups -> ci
+  for (int tap = 0; tap < taps; ++tap)
+    for (int cil = rowg; cil < 32; cil += 8) {
+      const int ci = ci0 + cil, co = co0 + col;
+      float s = 0.f;
+      if (ci < Cin && co < Cout)
+        for (int k = 0; k < S; ++k) s += slab[((size_t)(k * taps + tap) * CinPad + ci) * CoutPad + co];
+      tile[col * pitch + cil * taps + tap] = s;
+    }
+  __syncthreads();
+  const int nci = min(32, cin_real - ci0);
+  if (nci <= 0) return;
+  for (int i = threadIdx.x; i < 32 * 32 * taps; i += 256) {
+    const int col2 = i / (32 * taps), rem = i - col2 * 32 * taps;
+    const int co = co0 + col2;
+    if (co < Cout && rem < nci * taps) {
+      const size_t o = ((size_t)co * cin_real + ci0) * taps + rem;
+      const float v = tile[col2 * pitch + rem];
+      dw[o] = accumulate ? dw[o] + v : v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,9 +623,15 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if (p.CoutPad % bn || p.CinPad % 128) return PWR_EINVAL;
   const int taps = p.ksize * p.ksize;
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
-  if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 2, 2, 2, 2>), grid, block, 0, s, p);
-  else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 2, 2, 2, 1>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<T, 4, 1, 1, 1>), grid, block, 0, s, p);
+  if constexpr (sizeof(T) == 2) {
+    if (bn == 128) hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 2, 2, 2>), grid, block, 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 2, 2, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 1, 1, 1>), grid, block, 0, s, p);
+  } else {
+    if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 2, 2, 2, 2>), grid, block, 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 2, 2, 2, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 4, 1, 1, 1>), grid, block, 0, s, p);
+  }
   return (int)hipGetLastError();
 }
 
@@ -525,8 +700,9 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   int rc = dtype == PWR_BF16 ? pwr::launch_wgrad<bf16_t>(p, s) : pwr::launch_wgrad<float>(p, s);
   if (rc) return rc;
   if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin) return PWR_EINVAL;
-  const int total = cout_real * Cin * ksize * ksize;
-  hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slab, dw, p.S, ksize * ksize,
-                     Cin, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+  const int taps = ksize * ksize;
+  hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + 31) / 32), dim3(256),
+                     (size_t)32 * (32 * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
+                     accumulate);
   return (int)hipGetLastError();
 }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void planesum_kernel(const float* __restrict__
 }
 }  // namespace pwr
 
-extern "C" int pwr_colsum_blocks(long long M) { long long nb = (M + 255) / 256; return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb)); }
+extern "C" int pwr_colsum_blocks(long long M) { long long nb = (M + 255) / 256; return (int)(nb > 128 ? 128 : (nb < 1 ? 1 : nb)); }
 
 extern "C" int pwr_colsum_nhwc(const void* x, float* slab, float* out, long long M, int C, int accumulate, int dtype, void* stream) {
   if (C > 256 && C % 256) return PWR_EUNSUPPORTED;
