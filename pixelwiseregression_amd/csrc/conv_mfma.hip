@@ -535,30 +535,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
       }
 }
 
-// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 32 ci)
-// tile: slab reads are coalesced along co, the sums are transposed through LDS, the OIHW rows are written contiguously.
+// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 4 ci)
+// tile: slab reads are coalesced along co, the sums are transposed through LDS, the OIHW rows are written in runs of 4*taps.
+#define PWR_RED_CI 4
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps,
                                                            int Cin, int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
-  extern __shared__ float tile[];                 // [32 co][32*taps + 1]
-  const int pitch = 32 * taps + 1;
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
-  const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;   // col -> co, 8 row groups -> ci
-  for (int tap = 0; tap < taps; ++tap)
-    for (int cil = rowg; cil < 32; cil += 8) {
-      const int ci = ci0 + cil, co = co0 + col;
-      float s = 0.f;
-      if (ci < Cin && co < Cout)
-        for (int k = 0; k < S; ++k) s += slab[((size_t)(k * taps + tap) * CinPad + ci) * CoutPad + co];
-      tile[col * pitch + cil * taps + tap] = s;
+  extern __shared__ float tile[];                 // [32 co][PWR_RED_CI*taps + 1]
+  const int items = PWR_RED_CI * taps, pitch = items + 1;
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * PWR_RED_CI;
+  const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
+  const int co = co0 + col;
+  for (int it = rowg; it < items; it += 8) {
+    const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
+    float s = 0.f;
+    if (ci < Cin && co < Cout) {
+      const float* src = slab + ((size_t)tap * CinPad + ci) * CoutPad + co;
+      const size_t stride = (size_t)taps * CinPad * CoutPad;
+      for (int k = 0; k < S; ++k) s += src[k * stride];
     }
+    tile[col * pitch + it] = s;
+  }
   __syncthreads();
-  const int nci = min(32, cin_real - ci0);
+  const int nci = min(PWR_RED_CI, cin_real - ci0);
   if (nci <= 0) return;
-  for (int i = threadIdx.x; i < 32 * 32 * taps; i += 256) {
-    const int col2 = i / (32 * taps), rem = i - col2 * 32 * taps;
-    const int co = co0 + col2;
-    if (co < Cout && rem < nci * taps) {
-      const size_t o = ((size_t)co * cin_real + ci0) * taps + rem;
+  for (int i = threadIdx.x; i < 32 * items; i += 256) {
+    const int col2 = i / items, rem = i - col2 * items;
+    const int co2 = co0 + col2;
+    if (co2 < Cout && rem < nci * taps) {
+      const size_t o = ((size_t)co2 * cin_real + ci0) * taps + rem;
       const float v = tile[col2 * pitch + rem];
       dw[o] = accumulate ? dw[o] + v : v;
     }
@@ -701,8 +705,8 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   if (rc) return rc;
   if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin) return PWR_EINVAL;
   const int taps = ksize * ksize;
-  hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + 31) / 32), dim3(256),
-                     (size_t)32 * (32 * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
+  hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + PWR_RED_CI - 1) / PWR_RED_CI), dim3(256),
+                     (size_t)32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
                      accumulate);
   return (int)hipGetLastError();
 }
