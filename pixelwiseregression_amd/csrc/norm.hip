@@ -178,35 +178,41 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restri
   }
 }
 
-// Stage A: one thread per (b,c): T1,T2[b,c] = sums over the pixel chunks (fixed order).  S1,S2 = T/HW for instance norm.
-__global__ void norm_bwd_sum_kernel(const float* __restrict__ partial, float* __restrict__ S1, float* __restrict__ S2, int B, int HW,
-                                    int C, int nchunks, int batch_mode) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * C) return;
-  const int b = idx / C, c = idx - b * C;
-  float s1 = 0.f, s2 = 0.f;
-  for (int k = 0; k < nchunks; ++k) {
-    s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
-    s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
-  }
-  const float inv = batch_mode ? 1.f : 1.f / (float)HW;
-  S1[idx] = s1 * inv; S2[idx] = s2 * inv;
-}
-// Stage B: one thread per c: dgamma/dbeta (+)= sum over b; batch norm: S1,S2 <- total/(B*HW) broadcast to every b.
-__global__ void norm_bwd_param_kernel(float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, int B, int HW, int C, int batch_mode, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// One block per 8 channels: thread (b-lane, c) sums the pixel-chunk partials of its (b, c) in a fixed order -> S1,S2[b,c]
+// (divided by HW for instance norm), then the block reduces over b for dgamma / dbeta (and, for batch norm, overwrites
+// S1,S2 with the batch-wide means).  blockDim = 256 = 32 b-lanes x 8 channels.
+__global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restrict__ partial, float* __restrict__ S1,
+                                                           float* __restrict__ S2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int B, int HW, int C, int nchunks, int batch_mode, int accumulate) {
+  __shared__ float r1[32][9], r2[32][9];
+  const int cl = threadIdx.x & 7, bl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   float t1 = 0.f, t2 = 0.f;
-  for (int b = 0; b < B; ++b) { t1 += S1[b * C + c]; t2 += S2[b * C + c]; }
-  if (batch_mode) {
-    const float n = (float)B * (float)HW;
-    for (int b = 0; b < B; ++b) { S1[b * C + c] = t1 / n; S2[b * C + c] = t2 / n; }
-  } else {
-    t1 *= (float)HW; t2 *= (float)HW;   // S held sums/HW
+  if (c < C) {
+    for (int b = bl; b < B; b += 32) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < nchunks; ++k) {
+        s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
+        s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
+      }
+      t1 += s1; t2 += s2;
+      if (!batch_mode) { S1[b * C + c] = s1 / (float)HW; S2[b * C + c] = s2 / (float)HW; }
+    }
   }
-  dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
-  dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
+  r1[bl][cl] = t1; r2[bl][cl] = t2;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int j = 0; j < 32; ++j) { a1 += r1[j][cl]; a2 += r2[j][cl]; }
+    dgamma[c] = accumulate ? dgamma[c] + a2 : a2;
+    dbeta[c] = accumulate ? dbeta[c] + a1 : a1;
+    r1[0][cl] = a1; r2[0][cl] = a2;
+  }
+  __syncthreads();
+  if (batch_mode && c < C) {
+    const float n = (float)B * (float)HW;
+    for (int b = bl; b < B; b += 32) { S1[b * C + c] = r1[0][cl] / n; S2[b * C + c] = r2[0][cl] / n; }
+  }
 }
 
 // dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend).  Same (chunk, b) decomposition as the partial kernels so that the
@@ -319,9 +325,8 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
     hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state,
                        B, partial, HW, C, nch, relu);
   }
-  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, S1, S2, B, HW, C, nch, mode == 1 ? 1 : 0);
-  hipLaunchKernelGGL(norm_bwd_param_kernel, dim3((C + 63) / 64), dim3(64), 0, s, S1, S2, dgamma, dbeta, B, HW, C, mode == 1 ? 1 : 0,
-                     accumulate);
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, S1, S2, dgamma, dbeta, B, HW, C, nch,
+                     mode == 1 ? 1 : 0, accumulate);
   if (mode == 2) {  // statistics are constants: dy = scale * gm
     hipMemsetAsync(S1, 0, (size_t)B * C * 4, s);
     hipMemsetAsync(S2, 0, (size_t)B * C * 4, s);

@@ -291,27 +291,33 @@ extern "C" int pwr_add_inplace(const void* x, void* y, long long n, int dtype, v
 
 // ---- bias gradients: column sums ------------------------------------------------------------------
 namespace pwr {
-// NHWC [M][C] T -> slab[block][C]
+// NHWC [M][C] T -> slab[block][C]: 16-byte loads, thread = (row lane, 8/4-channel chunk)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ slab, long long M, int C,
                                                              int rows_per_block) {
-  extern __shared__ float red[];   // [256/C' ...] sized 256 floats per row group
-  const int lanes_c = C < 256 ? C : 256;
-  const int pl = 256 / lanes_c;
-  const int pj = threadIdx.x / lanes_c, c0 = threadIdx.x % lanes_c;
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];   // [pl][C]
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
-  for (int c = c0; c < C; c += lanes_c) {
-    float s = 0.f;
-    if (pj < pl)
-      for (long long r = r0 + pj; r < r0 + rows_per_block && r < M; r += pl) s += Elem<T>::to_f(x[(size_t)r * C + c]);
-    __syncthreads();
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (pj == 0) {
-      float t = 0.f;
-      for (int j = 0; j < pl; ++j) t += red[j * lanes_c + c0];
-      slab[(size_t)blockIdx.x * C + c] = t;
+  float s[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) s[e] = 0.f;
+  if (pj < pl) {
+    for (long long r = r0 + pj; r < r0 + rows_per_block && r < M; r += pl) {
+      V v = *reinterpret_cast<const V*>(x + (size_t)r * C + cq * EP);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) s[e] += Elem<T>::to_f(v[e]);
     }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) red[pj * C + cq * EP + e] = s[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int j = 0; j < pl; ++j) t += red[j * C + c];
+    slab[(size_t)blockIdx.x * C + c] = t;
   }
 }
 // NCHW fp32 [B][J][N]: part[b][j] = sum_n  (grid (J,B)); then out[j] (+)= sum_b part[b][j]
@@ -328,13 +334,14 @@ __global__ __launch_bounds__(256) void planesum_kernel(const float* __restrict__
 extern "C" int pwr_colsum_blocks(long long M) { long long nb = (M + 255) / 256; return (int)(nb > 128 ? 128 : (nb < 1 ? 1 : nb)); }
 
 extern "C" int pwr_colsum_nhwc(const void* x, float* slab, float* out, long long M, int C, int accumulate, int dtype, void* stream) {
-  if (C > 256 && C % 256) return PWR_EUNSUPPORTED;
-  if (C < 256 && 256 % C) return PWR_EUNSUPPORTED;
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
   const int nb = pwr_colsum_blocks(M);
   const int rpb = (int)((M + nb - 1) / nb);
+  const size_t sh = (size_t)(256 / (C / EP)) * C * 4;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PWR_BF16) hipLaunchKernelGGL((pwr::colsum_partial_kernel<bf16_t>), dim3(nb), dim3(256), 1024, s, (const bf16_t*)x, slab, M, C, rpb);
-  else hipLaunchKernelGGL((pwr::colsum_partial_kernel<float>), dim3(nb), dim3(256), 1024, s, (const float*)x, slab, M, C, rpb);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((pwr::colsum_partial_kernel<bf16_t>), dim3(nb), dim3(256), sh, s, (const bf16_t*)x, slab, M, C, rpb);
+  else hipLaunchKernelGGL((pwr::colsum_partial_kernel<float>), dim3(nb), dim3(256), sh, s, (const float*)x, slab, M, C, rpb);
   return pwr_slab_reduce(slab, out, nb, C, accumulate, stream);
 }
 
