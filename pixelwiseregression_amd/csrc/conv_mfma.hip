@@ -14,6 +14,7 @@
 #include "pwr_common.h"
 #include "pwr.h"
 #include "conv_common.h"
+#include <type_traits>
 
 namespace pwr {
 
@@ -535,6 +536,198 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient of a 3x3 stride-1 conv, three taps (one kernel row ky) per workgroup.  A K tile is 32
+// consecutive output pixels of ONE image row (needs W % 32 == 0); the matching input row segment is staged with a
+// one-pixel halo (34 pixels), so the same LDS tile serves kx = 0,1,2 -- the ds_read_b64_tr_b16 row address simply
+// shifts by kx.  Per MFMA this loads / normalises / stages 3x less than the one-tap kernel and its integer index math
+// is incremental (no divisions in the loop).  192 accumulator registers per wave -> one workgroup per CU; global
+// loads are prefetched two tiles ahead in registers.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
+  typedef bf16_t T;
+  typedef bf16x8 V;
+  constexpr int KP = 32, EP = 8, AP = KP + 2;
+  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;
+  constexpr int TILE_A = AP * PA, TILE_B = KP * PB;
+  constexpr int ACH = BM / EP, BCH = BN / EP;
+  constexpr int NA = (AP * ACH + 255) / 256, NBL = (KP * BCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (TILE_A + TILE_B)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int ky = blockIdx.x;
+  const int ntn = p.CoutPad / BN;
+  const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
+  const int ci0 = mtile * BM, co0 = ntile * BN;
+  const int split = blockIdx.z;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const int step0 = split * p.steps_per_split;
+  const int total_steps = p.M / KP;                 // W % 32 == 0 -> M % 32 == 0
+  int nsteps = total_steps - step0;
+  if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+  const int tiles_x = p.W / KP;
+  const size_t plane = (size_t)p.B * p.Cin;
+
+  // tile coordinates of step `st` (incremental, no divisions in the loop)
+  int tb, ty, tx;   // batch, row, x tile of the NEXT tile to be loaded
+  {
+    const int t0 = step0;
+    tb = t0 / (p.H * tiles_x);
+    const int rem = t0 - tb * p.H * tiles_x;
+    ty = rem / tiles_x; tx = rem - ty * tiles_x;
+  }
+  auto advance = [&]() { if (++tx == tiles_x) { tx = 0; if (++ty == p.H) { ty = 0; ++tb; } } };
+
+  // per-thread NR state for its channel chunk (reloaded when the batch index changes)
+  const int acq = tid % ACH;
+  float mu[EP], sc[EP], be[EP];
+  int state_b = -1;
+  auto load_state = [&](int b) {
+    if (p.in_norm && b != state_b) {
+      const float* stp = p.in_norm + (size_t)b * p.Cin + ci0 + acq * EP;
+      if (ci0 + acq * EP < p.Cin) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { mu[e] = stp[e]; sc[e] = stp[2 * plane + e]; be[e] = stp[3 * plane + e]; }
+      }
+      state_b = b;
+    }
+  };
+
+  struct Stage { V a[NA]; V b[NBL]; unsigned okmask; int bidx; bool rowok; };
+  Stage sg[2];
+  auto load_global = [&](Stage& S) {
+    const int iy = ty + ky - 1;
+    S.rowok = iy >= 0 && iy < p.H;
+    S.bidx = tb;
+    S.okmask = 0;
+    const size_t rowbase = ((size_t)tb * p.H + (S.rowok ? iy : 0)) * p.W;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      const int pix = c / ACH, cq = c % ACH;     // ACH is a power of two
+      V v = {};
+      if (c < AP * ACH) {
+        const int ix = tx * KP + pix - 1, ci = ci0 + cq * EP;
+        if (S.rowok && ix >= 0 && ix < p.W && ci < p.Cin) {
+          v = *reinterpret_cast<const V*>(x + (rowbase + ix) * p.Cin + ci);
+          S.okmask |= 1u << i;
+        }
+      }
+      S.a[i] = v;
+    }
+    const size_t m0 = ((size_t)tb * p.H + ty) * p.W + (size_t)tx * KP;
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int c = tid + 256 * i;
+      const int pix = c / BCH, cq = c % BCH;
+      V v = {};
+      if (c < KP * BCH) {
+        const int co = co0 + cq * EP;
+        if (co < p.Cout) v = *reinterpret_cast<const V*>(dy + (m0 + pix) * p.Cout + co);
+      }
+      S.b[i] = v;
+    }
+    advance();
+  };
+  auto store_lds = [&](Stage& S, int buf) {
+    char* lA = smem + buf * (TILE_A + TILE_B);
+    char* lB = lA + TILE_A;
+    load_state(S.bidx);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i;
+      if (c < AP * ACH) {
+        const int pix = c / ACH, cq = c % ACH;
+        V v = S.a[i];
+        if (p.in_norm && ((S.okmask >> i) & 1)) {
+          V o;
+#pragma unroll
+          for (int e = 0; e < EP; ++e) {
+            float f = fmaf((float)v[e] - mu[e], sc[e], be[e]);
+            if (p.relu_in) f = fmaxf(f, 0.f);
+            o[e] = (bf16_t)f;
+          }
+          v = o;
+        }
+        *reinterpret_cast<V*>(lA + pix * PA + cq * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int c = tid + 256 * i;
+      if (c < KP * BCH) *reinterpret_cast<V*>(lB + (c / BCH) * PB + (c % BCH) * 16) = S.b[i];
+    }
+  };
+
+  f32x16 acc[3][MR][NR];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+  // one pipeline step with a compile-time stage index (runtime-indexed register arrays would go to scratch)
+  auto body = [&](auto BUF, int st) {
+    constexpr int buf = decltype(BUF)::value;
+    const bool rowok_cur = sg[buf].rowok;
+    if (st + 2 < nsteps) load_global(sg[buf]);       // sg[buf] was already stored to LDS: refill with tile st+2
+    if (rowok_cur) {
+      const char* lA = smem + buf * (TILE_A + TILE_B);
+      const char* lB = lA + TILE_A;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        V b[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) b[j] = frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          V a[MR];
+#pragma unroll
+          for (int i = 0; i < MR; ++i) a[i] = frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane);
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < nsteps) store_lds(sg[buf ^ 1], buf ^ 1);
+    __syncthreads();
+  };
+  if (nsteps > 0) {
+    load_global(sg[0]);
+    if (nsteps > 1) load_global(sg[1]);
+    store_lds(sg[0], 0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; st += 2) {
+      body(std::integral_constant<int, 0>{}, st);
+      if (st + 1 < nsteps) body(std::integral_constant<int, 1>{}, st + 1);
+    }
+  }
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* __restrict__ out = p.slab + ((size_t)(split * 9 + ky * 3 + t) * p.CinPad) * p.CoutPad;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = ci0 + wm * MR * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int co = co0 + wn * NR * 32 + j * 32 + r;
+          out[(size_t)ci * p.CoutPad + co] = acc[t][i][j][e];
+        }
+  }
+}
+
 // dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 4 ci)
 // tile: slab reads are coalesced along co, the sums are transposed through LDS, the OIHW rows are written in runs of 4*taps.
 #define PWR_RED_CI 4
@@ -628,6 +821,13 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   const int taps = p.ksize * p.ksize;
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
   if constexpr (sizeof(T) == 2) {
+    if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
+      dim3 g3(3, grid.y, p.S);
+      if (bn == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 2>), g3, block, 0, s, p);
+      else if (bn == 64) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 1>), g3, block, 0, s, p);
+      else hipLaunchKernelGGL((conv_wgrad3_kernel<4, 1, 1, 1>), g3, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
     if (bn == 128) hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 2, 2, 2>), grid, block, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 2, 2, 1>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 1, 1, 1>), grid, block, 0, s, p);

@@ -152,7 +152,7 @@ struct Engine {
     const int KE = dtype == PWR_BF16 ? 32 : 16;
     const int steps = (M + KE - 1) / KE;
     const int tiles = k * k * ((cin + 127) / 128) * (pwr_conv_out_pad(cout) / (cout > 64 ? 128 : (cout > 32 ? 64 : 32)));
-    int s = (256 + tiles - 1) / tiles;
+    int s = (512 + tiles - 1) / tiles;
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;

@@ -1,0 +1,36 @@
+"""Isolated timing of the two hot kernels at the BASELINE C2 heads shape (for rocprofv3 --pmc runs)."""
+import sys, os, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pixelwiseregression_amd import kernels as K
+
+dev = "cuda:0"
+B, P, F_ = 32, 64, 128
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
+dy = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
+w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
+pack = K.pack_conv(w, 0, K.BF16)
+st = K.norm_stats(x, torch.ones(F_, device=dev), torch.zeros(F_, device=dev), mode=0)
+bias = torch.zeros(F_, device=dev)
+flops = 2.0 * B * P * P * F_ * F_ * 9
+
+def timeit(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+if which in ("all", "fwd"):
+    t = timeit(lambda: K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st))
+    print(json.dumps({"kernel": "conv3x3_patch fwd (+NR prologue)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+    t = timeit(lambda: K.conv_fwd(x, pack, F_, 3, 1))
+    print(json.dumps({"kernel": "conv3x3_patch (no prologue: dgrad form)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+if which in ("all", "wgrad"):
+    for splits in (28, 57, 86, 114):
+        t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=st, splits=splits))
+        print(json.dumps({"kernel": "conv_wgrad_tr + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
