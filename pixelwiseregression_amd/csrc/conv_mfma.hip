@@ -728,26 +728,38 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
   }
 }
 
-// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 4 ci)
-// tile: slab reads are coalesced along co, the sums are transposed through LDS, the OIHW rows are written in runs of 4*taps.
-#define PWR_RED_CI 4
+// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 2 ci) tile.
+// Threads: 32 co lanes x 8 slab groups; every thread keeps one independent sum per (ci, tap) item over its share of the S
+// slabs (coalesced 128-byte reads along co, items*S/8 loads in flight), the 8 groups are combined in a fixed order through
+// LDS, and the OIHW rows are written in runs of 2*taps floats.
+#define PWR_RED_CI 2
+#define PWR_RED_MAXITEMS 18
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps,
                                                            int Cin, int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
-  extern __shared__ float tile[];                 // [32 co][PWR_RED_CI*taps + 1]
+  extern __shared__ float tile[];                 // [8 groups][32 co][items + 1]
   const int items = PWR_RED_CI * taps, pitch = items + 1;
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * PWR_RED_CI;
-  const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int co = co0 + col;
-  for (int it = rowg; it < items; it += 8) {
-    const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
-    float s = 0.f;
-    if (ci < Cin && co < Cout) {
-      const float* src = slab + ((size_t)tap * CinPad + ci) * CoutPad + co;
-      const size_t stride = (size_t)taps * CinPad * CoutPad;
-      for (int k = 0; k < S; ++k) s += src[k * stride];
+  float acc[PWR_RED_MAXITEMS];
+#pragma unroll
+  for (int it = 0; it < PWR_RED_MAXITEMS; ++it) acc[it] = 0.f;
+  if (co < Cout) {
+    const size_t stride = (size_t)taps * CinPad * CoutPad;
+    for (int k = grp; k < S; k += 8) {
+      const float* base = slab + k * stride + co;
+#pragma unroll
+      for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
+        if (it < items) {
+          const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
+          if (ci < Cin) acc[it] += base[((size_t)tap * CinPad + ci) * CoutPad];
+        }
+      }
     }
-    tile[col * pitch + it] = s;
   }
+#pragma unroll
+  for (int it = 0; it < PWR_RED_MAXITEMS; ++it)
+    if (it < items) tile[(grp * 32 + col) * pitch + it] = acc[it];
   __syncthreads();
   const int nci = min(PWR_RED_CI, cin_real - ci0);
   if (nci <= 0) return;
@@ -755,8 +767,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int col2 = i / items, rem = i - col2 * items;
     const int co2 = co0 + col2;
     if (co2 < Cout && rem < nci * taps) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += tile[(g * 32 + col2) * pitch + rem];
       const size_t o = ((size_t)co2 * cin_real + ci0) * taps + rem;
-      const float v = tile[col2 * pitch + rem];
       dw[o] = accumulate ? dw[o] + v : v;
     }
   }
@@ -903,10 +917,10 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype == PWR_BF16 ? pwr::launch_wgrad<bf16_t>(p, s) : pwr::launch_wgrad<float>(p, s);
   if (rc) return rc;
-  if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin) return PWR_EINVAL;
+  if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin || ksize * ksize * PWR_RED_CI > PWR_RED_MAXITEMS) return PWR_EINVAL;
   const int taps = ksize * ksize;
   hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + PWR_RED_CI - 1) / PWR_RED_CI), dim3(256),
-                     (size_t)32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
+                     (size_t)8 * 32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
                      accumulate);
   return (int)hipGetLastError();
 }

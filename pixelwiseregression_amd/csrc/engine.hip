@@ -151,8 +151,12 @@ struct Engine {
   int splits_for(int M, int cin, int cout, int k) const {
     const int KE = dtype == PWR_BF16 ? 32 : 16;
     const int steps = (M + KE - 1) / KE;
-    const int tiles = k * k * ((cin + 127) / 128) * (pwr_conv_out_pad(cout) / (cout > 64 ? 128 : (cout > 32 ? 64 : 32)));
-    int s = (512 + tiles - 1) / tiles;
+    const int per = ((cin + 127) / 128) * (pwr_conv_out_pad(cout) / (cout > 64 ? 128 : (cout > 32 ? 64 : 32)));
+    // bf16 3x3 stride-1 layers on W % 32 == 0 maps use the 3-taps-per-workgroup kernel (grid 3 x tiles x splits,
+    // one workgroup per CU); everything else one tap per workgroup at >= 2 workgroups per CU
+    const bool w3 = dtype == PWR_BF16 && k == 3 && M % 32 == 0;
+    const int tiles = (w3 ? 3 : k * k) * per;
+    int s = ((w3 ? 264 : 512) + tiles - 1) / tiles;
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
