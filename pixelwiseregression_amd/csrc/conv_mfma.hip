@@ -729,37 +729,47 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
 }
 
 // dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 2 ci) tile.
-// Threads: 32 co lanes x 8 slab groups; every thread keeps one independent sum per (ci, tap) item over its share of the S
-// slabs (coalesced 128-byte reads along co, items*S/8 loads in flight), the 8 groups are combined in a fixed order through
-// LDS, and the OIHW rows are written in runs of 2*taps floats.
+// Threads: 8 lanes x float4 = 32 co, times 32 slab groups; every thread keeps one independent float4 sum per (ci, tap)
+// item over its share of the S slabs (16-byte loads).  The 8 groups of a wave are combined with shuffles, the 4 waves
+// through LDS in a fixed order, and the OIHW rows are written in runs of 2*taps floats.
 #define PWR_RED_CI 2
 #define PWR_RED_MAXITEMS 18
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps,
                                                            int Cin, int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
-  extern __shared__ float tile[];                 // [8 groups][32 co][items + 1]
+  extern __shared__ float tile[];                 // [4 waves][32 co][items + 1]
   const int items = PWR_RED_CI * taps, pitch = items + 1;
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * PWR_RED_CI;
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int co = co0 + col;
-  float acc[PWR_RED_MAXITEMS];
+  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+  const int co = co0 + c4 * 4;                    // CoutPad % 32 == 0: the float4 stays inside the padded row
+  f32x4 acc[PWR_RED_MAXITEMS];
 #pragma unroll
-  for (int it = 0; it < PWR_RED_MAXITEMS; ++it) acc[it] = 0.f;
-  if (co < Cout) {
-    const size_t stride = (size_t)taps * CinPad * CoutPad;
-    for (int k = grp; k < S; k += 8) {
-      const float* base = slab + k * stride + co;
+  for (int it = 0; it < PWR_RED_MAXITEMS; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)taps * CinPad * CoutPad;
+  for (int k = grp; k < S; k += 32) {
+    const float* base = slab + k * stride + co;
 #pragma unroll
-      for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
-        if (it < items) {
-          const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
-          if (ci < Cin) acc[it] += base[((size_t)tap * CinPad + ci) * CoutPad];
-        }
+    for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
+      if (it < items) {
+        const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
+        if (ci < Cin) acc[it] += *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
       }
     }
   }
+  // combine the 8 slab groups inside each wave (lanes l, l^8, l^16, l^32 hold the same co)
 #pragma unroll
-  for (int it = 0; it < PWR_RED_MAXITEMS; ++it)
-    if (it < items) tile[(grp * 32 + col) * pitch + it] = acc[it];
+  for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
+    if (it < items) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        acc[it].x += __shfl_xor(acc[it].x, o, 64); acc[it].y += __shfl_xor(acc[it].y, o, 64);
+        acc[it].z += __shfl_xor(acc[it].z, o, 64); acc[it].w += __shfl_xor(acc[it].w, o, 64);
+      }
+      if ((threadIdx.x & 63) < 8) {
+        float* t = tile + (wave * 32 + c4 * 4) * pitch + it;
+        t[0] = acc[it].x; t[pitch] = acc[it].y; t[2 * pitch] = acc[it].z; t[3 * pitch] = acc[it].w;
+      }
+    }
+  }
   __syncthreads();
   const int nci = min(PWR_RED_CI, cin_real - ci0);
   if (nci <= 0) return;
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (co2 < Cout && rem < nci * taps) {
       float v = 0.f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) v += tile[(g * 32 + col2) * pitch + rem];
+      for (int g = 0; g < 4; ++g) v += tile[(g * 32 + col2) * pitch + rem];
       const size_t o = ((size_t)co2 * cin_real + ci0) * taps + rem;
       dw[o] = accumulate ? dw[o] + v : v;
     }
@@ -920,7 +930,7 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin || ksize * ksize * PWR_RED_CI > PWR_RED_MAXITEMS) return PWR_EINVAL;
   const int taps = ksize * ksize;
   hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + PWR_RED_CI - 1) / PWR_RED_CI), dim3(256),
-                     (size_t)8 * 32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
+                     (size_t)4 * 32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
                      accumulate);
   return (int)hipGetLastError();
 }
