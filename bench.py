@@ -214,9 +214,14 @@ def main():
         }
         if args.backend == "hip":
             t, flops = time_head_conv(dev, B_PER_GPU)
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<bf16,128x128 tile> 3x3 128->128 @64x64, B=%d" % B_PER_GPU,
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tj):     # HBM bytes per launch from the rocprofv3 PMC passes (see the file for the command)
+                traffic = json.load(open(tj)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
+            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_patch_kernel<bf16,Cin128,128x128 tile> 3x3 128->128 @64x64, B=%d (+fused norm/ReLU)" % B_PER_GPU,
                                "achieved": flops / t / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": flops / t / 1e12 / PEAK_BF16_TFLOPS, "traffic": None, "us_per_launch": t * 1e6}
+                               "frac": flops / t / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic, "us_per_launch": t * 1e6,
+                               "flop_per_launch": flops}
             td, nb = time_decoder(dev, B_PER_GPU)
             out["roofline_decoder"] = {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": td * 1e6}

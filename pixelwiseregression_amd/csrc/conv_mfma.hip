@@ -558,11 +558,15 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int ky = blockIdx.x;
+  // blockIdx.x enumerates (split, ky) so that the three ky workgroups of one split are 8 ids apart: they land on the
+  // same XCD (speed only) and share the dy tiles and the overlapping input rows in that XCD's L2.
+  const int grp = blockIdx.x / 24, rr = blockIdx.x - grp * 24;
+  const int ky = rr >> 3;
+  const int split = grp * 8 + (rr & 7);
+  if (split >= p.S) return;
   const int ntn = p.CoutPad / BN;
   const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
   const int ci0 = mtile * BM, co0 = ntile * BN;
-  const int split = blockIdx.z;
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
   const int step0 = split * p.steps_per_split;
@@ -846,7 +850,7 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
   if constexpr (sizeof(T) == 2) {
     if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
-      dim3 g3(3, grid.y, p.S);
+      dim3 g3(24 * ((p.S + 7) / 8), grid.y, 1);
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 2>), g3, block, 0, s, p);
       else if (bn == 64) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 1>), g3, block, 0, s, p);
       else hipLaunchKernelGGL((conv_wgrad3_kernel<4, 1, 1, 1>), g3, block, 0, s, p);
