@@ -8,6 +8,8 @@
 // there: 1.6x input traffic instead of the 9x of the universal im2col-on-the-fly kernel, and the NR arithmetic is done
 // 1.6x instead of 9x.  Weights stream through a double-buffered [BN][64 B] LDS tile per (tap, K chunk); they are shared
 // by all workgroups and stay in L2.  MFMA 32x32x16 bf16 (or 32x32x2 fp32 in parity mode), fp32 accumulate.
+#include <cstdlib>
+
 #include "conv_common.h"
 #include "pwr.h"
 
@@ -22,7 +24,7 @@ __device__ __forceinline__ int patch_off(int pix, int slot) {
   return (pix * NSLOT + (slot ^ ((pix >> SH) & MASK))) * 16;
 }
 
-template <typename T, int CIN, int WM, int WN, int MR, int NR>
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA>
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
   constexpr int NB = (BN * 4 + 255) / 256;
   constexpr int EROWS = 64, EPITCH = BN + 4;
   constexpr int EPI_BYTES = EROWS * EPITCH * 4;
-  constexpr int LDS_BYTES = (PATCH_BYTES + 2 * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + 2 * WBUF_BYTES) : EPI_BYTES;
+  constexpr int NSTAGE = DMA ? 3 : 2;             // weight ring: LDS-DMA runs two K steps ahead
+  constexpr int LDS_BYTES = (PATCH_BYTES + NSTAGE * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + NSTAGE * WBUF_BYTES) : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   char* patch = smem;
   char* wbuf = smem + PATCH_BYTES;
@@ -68,7 +71,24 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
       if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(wbuf + buf * WBUF_BYTES + lds_off(s >> 2, s & 3)) = rb[i];
     }
   };
-  load_w(0);
+  // LDS-DMA form: global_load_lds writes 64 lanes x 16 B = 1 KiB (16 tile rows) per wave instruction, linearly; the
+  // XOR swizzle of the tile is applied to the per-lane SOURCE address instead (cdna_hip_programming.md rule 21).
+  constexpr int NCHUNK = WBUF_BYTES / 1024;       // wave instructions per stage
+  constexpr int NBW = (NCHUNK + 3) / 4;           // per wave
+  auto dma_w = [&](int it, int stage) {
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      const int ch = i * 4 + wid;
+      if (NCHUNK >= 4 * (i + 1) || ch < NCHUNK) {
+        const int row = 16 * ch + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        const char* src = reinterpret_cast<const char*>(w) + ((size_t)it * p.CoutPad + n0 + row) * 64 + slot * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wbuf + stage * WBUF_BYTES + ch * 1024), 16, 0, 0);
+      }
+    }
+  };
+  if constexpr (DMA) { dma_w(0, 0); dma_w(1, 1); } else { load_w(0); }
 
   // ---- stage the patch: thread -> fixed slot (channels), pixels tid/NSLOT + k*(256/NSLOT)
   {
@@ -111,8 +131,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
       }
     }
   }
-  store_w(0);
-  __syncthreads();
+  if constexpr (!DMA) store_w(0);
+  __syncthreads();     // (drains the two DMA stages in flight as well)
 
   f32x16 acc[MR][NR];
 #pragma unroll
@@ -135,8 +155,24 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
   const int r = lane & 31, h = lane >> 5;
   constexpr int ITERS = 9 * KCH;
   for (int it = 0; it < ITERS; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < ITERS) load_w(it + 1);
+    int buf;
+    if constexpr (DMA) {
+      // stage `it` has landed once all but this wave's newest stage (it+1) are retired; after the barrier every wave's
+      // share has landed and everybody is done reading stage it-1, which the DMA for it+2 may now overwrite
+      if (it + 1 < ITERS) {
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      buf = it % 3;
+      if (it + 2 < ITERS) dma_w(it + 2, (it + 2) % 3);
+    } else {
+      buf = it & 1;
+      if (it + 1 < ITERS) load_w(it + 1);
+    }
     const int tap = it / KCH, kch = it - tap * KCH;
     const int ky = tap / 3, kx = tap - ky * 3;
     const char* lB = wbuf + buf * WBUF_BYTES;
@@ -171,9 +207,12 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
           for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
       }
     }
-    if (it + 1 < ITERS) store_w(buf ^ 1);
-    __syncthreads();
+    if constexpr (!DMA) {
+      if (it + 1 < ITERS) store_w(buf ^ 1);
+      __syncthreads();
+    }
   }
+  if constexpr (DMA) __syncthreads();
   if constexpr (kTwoLevel) {
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -255,9 +294,17 @@ template <typename T, int CIN>
 static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
-  if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2>), grid, block, 0, s, p);
-  else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 1>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 1, 1, 1>), grid, block, 0, s, p);
+  static const bool dma = [] { const char* e = getenv("PWR_PATCH_DMA"); return e ? atoi(e) != 0 : true; }();
+  // fp32 (parity mode) patches leave no room for a third weight stage next to a second workgroup: register staging
+  if (dma && sizeof(T) == 2) {
+    if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2, true>), grid, block, 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 1, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 1, 1, 1, true>), grid, block, 0, s, p);
+  } else {
+    if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2, false>), grid, block, 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 1, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 1, 1, 1, false>), grid, block, 0, s, p);
+  }
   return (int)hipGetLastError();
 }
 
