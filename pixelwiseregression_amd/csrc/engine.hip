@@ -156,7 +156,8 @@ struct Engine {
     // one workgroup per CU); everything else one tap per workgroup at >= 2 workgroups per CU
     const bool w3 = dtype == PWR_BF16 && k == 3 && M % 32 == 0;
     const int tiles = (w3 ? 3 : k * k) * per;
-    int s = ((w3 ? 264 : 512) + tiles - 1) / tiles;
+    int s = w3 ? (256 / tiles) / 8 * 8 : (512 + tiles - 1) / tiles;   // w3: one wave of workgroups, whole XCD groups (no tail)
+    if (w3 && s < 8) s = 8;
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
