@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="hip", choices=["hip", "aten"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (debug)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: all ranks share cuda:0 (with --dist-backend gloo) to exercise the data-parallel path on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,12 +136,17 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
         sys.exit(2)
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from pixelwiseregression_amd import PixelwiseRegression
     from pixelwiseregression_amd.synthetic import make_batch

@@ -1,0 +1,59 @@
+"""GPU: the data-parallel path end to end on ONE GPU -- two ranks share cuda:0 and all-reduce over gloo (RCCL refuses two
+ranks on one device; the 8-GPU RCCL run is the driver's).  Checks that after one step both ranks hold identical parameters
+and that the averaged gradient equals the mean of the two shard gradients computed without DDP."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pixelwiseregression_amd import PixelwiseRegression
+from pixelwiseregression_amd.ddp import DataParallel
+from pixelwiseregression_amd.synthetic import make_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda:0")
+def loss_of(m, b):
+    res = m(b["img"], b["label_img"], b["mask"])
+    return sum(torch.mean(torch.sum((uvd - b["uvd"]) ** 2, dim=2)) for (_, _, uvd) in res)
+torch.manual_seed(7 + rank)                       # different init per rank: the broadcast must fix it
+m = PixelwiseRegression(4, stage=2, label_size=16, features=32, level=2, norm_method="instance").to(dev).train()
+DataParallel(m)
+shards = [make_batch(2, 4, S=32, seed=50 + r, device=dev) for r in range(world)]
+# reference: mean of the shard gradients, computed by every rank without the hook
+m._ddp, ddp = None, m._ddp
+ref = torch.zeros_like(m.flat_parameters())
+for r in range(world):
+    m.zero_grad(set_to_none=True)
+    loss_of(m, shards[r]).backward()
+    ref += m.flat_grad() / world
+m._ddp = ddp
+m.zero_grad(set_to_none=True)
+loss_of(m, shards[rank]).backward()
+err = (m.flat_grad() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+gathered = [torch.empty_like(m.flat_parameters()) for _ in range(world)]
+dist.all_gather(gathered, m.flat_parameters())
+same = all(torch.equal(gathered[0], g) for g in gathered)
+print("RESULT", rank, err, same, flush=True)
+dist.destroy_process_group()
+""" % ROOT
+
+
+def test_ddp_two_ranks_one_gpu(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29611", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(lines) == 2, (r.stdout[-2000:], r.stderr[-2000:])
+    for l in lines:
+        _, rank, err, same = l.split()
+        assert float(err) < 1e-5, l
+        assert same == "True", l
