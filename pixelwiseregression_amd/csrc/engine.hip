@@ -587,6 +587,8 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
     c.out_p[s] = (float*)outs[3 * s]; c.out_D[s] = (float*)outs[3 * s + 1]; c.out_uvd[s] = (float*)outs[3 * s + 2];
   }
   e->generation++;
+  // hand-off counters of the fused norm kernels live at the head of the partial scratch: zero once per call
+  if (e->need_partial) hipMemsetAsync(c.arena + e->scr_partial, 0, 8192 < e->need_partial ? 8192 : e->need_partial, (hipStream_t)stream);
   for (size_t i = 0; i < e->fwd.size(); ++i) {
     int rc = e->fwd[i](c);
     if (rc) { char b[96]; snprintf(b, sizeof b, "forward op %zu failed with %d", i, rc); g_last_error = b; return rc; }

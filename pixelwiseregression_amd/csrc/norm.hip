@@ -9,6 +9,8 @@
 // Statistics use shifted sums (shift k[c] = first pixel of the sample / batch) so that
 // var = E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically; partials per pixel chunk are written to a
 // slab and combined in a fixed order (deterministic, no atomics).
+#include <cstdlib>
+
 #include "pwr_common.h"
 #include "pwr.h"
 
@@ -106,6 +108,87 @@ __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __res
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
     }
+  }
+}
+
+// InstanceNorm statistics in ONE launch: every block writes the partial sums of its pixel chunk, then the block that
+// arrives last for sample b (ticket from an agent-scope counter) combines the chunks of b in a fixed order and writes the
+// [4][B][C] state.  Hand-off protocol (cdna_hip_programming.md, Guideline 16): plain stores -> every wave s_waitcnt vmcnt(0)
+// -> workgroup barrier -> lane 0: agent release fence, vmcnt(0), relaxed agent fetch_add; the last arriver: agent acquire
+// fence, vmcnt(0), barrier, plain loads.  The counter is reset by the last arriver (it must be zero before the first use).
+template <typename T>
+__global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restrict__ y, float* __restrict__ partial,
+                                                               int* __restrict__ counters, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ state, int B,
+                                                               int HW, int C, int nchunks, float eps) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];  // [pl][2][C]
+  __shared__ int s_last;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const T* base = y + (size_t)b * HW * C;
+  float s1[EP], s2[EP], k[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (pj < pl) {
+    V kv = *reinterpret_cast<const V*>(base + cq * EP);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) k[e] = Elem<T>::to_f(kv[e]);
+    for (int pp = p0 + pj; pp < p1; pp += pl) {
+      V v = *reinterpret_cast<const V*>(base + (size_t)pp * C + cq * EP);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float d = Elem<T>::to_f(v[e]) - k[e];
+        s1[e] += d;
+        s2[e] = fmaf(d, d, s2[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      red[(pj * 2 + 0) * C + cq * EP + e] = s1[e];
+      red[(pj * 2 + 1) * C + cq * EP + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < pl; ++j) s += red[j * 2 * C + i];
+    partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(&counters[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == nchunks - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&counters[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const size_t plane = (size_t)B * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int kk = 0; kk < nchunks; ++kk) {
+      a1 += partial[((size_t)(b * nchunks + kk) * 2 + 0) * C + c];
+      a2 += partial[((size_t)(b * nchunks + kk) * 2 + 1) * C + c];
+    }
+    const float n = (float)HW;
+    const float k0 = Elem<T>::to_f(base[c]);
+    const float m1 = a1 / n;
+    const float var = fmaxf(a2 / n - m1 * m1, 0.f);
+    const float mean = k0 + m1, rstd = 1.f / sqrtf(var + eps);
+    const int idx = b * C + c;
+    state[idx] = mean; state[plane + idx] = rstd; state[2 * plane + idx] = gamma[c] * rstd; state[3 * plane + idx] = beta[c];
   }
 }
 
@@ -276,7 +359,11 @@ using namespace pwr;
 
 extern "C" int pwr_norm_chunks(int B, int HW) { return norm_chunks(B, HW); }
 
-extern "C" size_t pwr_norm_partial_bytes(int B, int HW, int C) { return (size_t)B * norm_chunks(B, HW) * 2 * C * sizeof(float); }
+// workspace = [counters: B + 1 ints, padded to 256 B, must be zero before the first use (they reset themselves)] [partials]
+static inline size_t norm_counter_bytes(int B) { return ((size_t)(B + 1) * 4 + 255) / 256 * 256; }
+extern "C" size_t pwr_norm_partial_bytes(int B, int HW, int C) {
+  return norm_counter_bytes(B) + (size_t)B * norm_chunks(B, HW) * 2 * C * sizeof(float);
+}
 
 // mode: 0 instance, 1 batch (training statistics), 2 batch eval (running statistics)
 extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -294,6 +381,14 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   const int pl = 256 / (C / EP);
   const size_t sh = (size_t)pl * 2 * C * 4;
   const int n = mode == 1 ? C : B * C;
+  int* counters = reinterpret_cast<int*>(partial);
+  partial = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + norm_counter_bytes(B));
+  static const bool fuse = [] { const char* e = getenv("PWR_NORM_FUSED"); return e ? atoi(e) != 0 : true; }();
+  if (mode == 0 && fuse) {
+    if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, nch, eps);
+    else hipLaunchKernelGGL((norm_stats_fused_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)y, partial, counters, gamma, beta, state, B, HW, C, nch, eps);
+    return (int)hipGetLastError();
+  }
   if (dtype == PWR_BF16) {
     hipLaunchKernelGGL((norm_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)y, partial, HW, C, nch, mode);
     hipLaunchKernelGGL((norm_finalize_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, s, (const bf16_t*)y, partial, gamma,
@@ -318,6 +413,7 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
   const int nch = norm_chunks(B, HW);
   const int pl = 256 / (C / EP);
   const size_t sh = (size_t)pl * 2 * C * 4;
+  partial = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + norm_counter_bytes(B));
   if (dtype == PWR_BF16) {
     hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y,
                        state, B, partial, HW, C, nch, relu);

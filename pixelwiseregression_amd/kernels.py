@@ -145,7 +145,7 @@ def norm_stats(y, gamma, beta, mode=0, running_mean=None, running_var=None, eps=
     l = _lib.lib()
     B, H, W, C = y.shape
     dev = y.device
-    partial = torch.empty(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=dev)
+    partial = torch.zeros(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=dev)   # hand-off counters must start at 0
     state = torch.empty(4, B, C, dtype=torch.float32, device=dev)
     _lib.check(l.pwr_norm_stats(_p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(partial), _p(state),
                                 B, H * W, C, mode, eps, momentum, _dt(y), _s(y)), "pwr_norm_stats")

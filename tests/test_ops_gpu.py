@@ -350,3 +350,34 @@ def test_bias_gradient_sums(dtype):
     assert_close(K.colsum_nhwc(nhwc(x, dtype)).double().cpu(), q(x, dtype).sum(dim=(0, 2, 3)), 1e-5, "colsum big")
     g = rnd(5, 14, 64, 64, seed=3).float()
     assert_close(K.planesum_nchw(g.to(DEV)).double().cpu(), g.double().sum(dim=(0, 2, 3)), 1e-5, "planesum")
+
+
+def test_norm_fused_handoff_stress():
+    """The single-launch InstanceNorm statistics hand partial sums from all blocks of a sample to the last-arriving block
+    (agent-scope release/acquire).  Alternate two inputs through the SAME workspace 300 times: a stale or torn read of a
+    partial would reproduce the other input's statistics.  Every result must equal the first (validated) one bit for bit."""
+    from pixelwiseregression_amd import kernels as K, _lib
+    import torch
+    B, H, W, C = 32, 64, 64, 128
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    xs = [(torch.randn(B, H, W, C, device=DEV) * (1 + i) + 3 * i).to(torch.bfloat16) for i in range(2)]
+    l = _lib.lib()
+    partial = torch.zeros(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=DEV)
+    state = torch.empty(4, B, C, dtype=torch.float32, device=DEV)
+
+    def run(x):
+        _lib.check(l.pwr_norm_stats(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, partial.data_ptr(), state.data_ptr(),
+                                    B, H * W, C, 0, 1e-5, 0.1, K.BF16, _lib.stream_ptr(x.device)), "pwr_norm_stats")
+        return state.clone()
+
+    refs = []
+    for x in xs:
+        st = run(x)
+        m = x.float().mean(dim=(1, 2))
+        assert (st[0] - m).abs().max().item() < 1e-3 * max(1.0, m.abs().max().item())
+        refs.append(st)
+    # a small kernel in between keeps other CUs' caches warm with lines of the workspace
+    for it in range(300):
+        i = it & 1
+        st = run(xs[i])
+        assert torch.equal(st, refs[i]), "iteration %d: hand-off returned different statistics" % it
