@@ -6,5 +6,6 @@ Public surface mirrors the reference's ``model.py`` / ``utils.py`` names for the
 """
 from .model import PixelwiseRegression  # noqa: F401
 from .metric import recover_uvd, uvd2xyz, mean_joint_error, INTRINSICS  # noqa: F401
+from .checkpoint import save_model, load_model  # noqa: F401
 
-__all__ = ["PixelwiseRegression", "recover_uvd", "uvd2xyz", "mean_joint_error", "INTRINSICS"]
+__all__ = ["PixelwiseRegression", "recover_uvd", "uvd2xyz", "mean_joint_error", "INTRINSICS", "save_model", "load_model"]

@@ -116,7 +116,7 @@ __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __res
 // [4][B][C] state.  Hand-off protocol (cdna_hip_programming.md, Guideline 16): plain stores -> every wave s_waitcnt vmcnt(0)
 // -> workgroup barrier -> lane 0: agent release fence, vmcnt(0), relaxed agent fetch_add; the last arriver: agent acquire
 // fence, vmcnt(0), barrier, plain loads.  The counter is reset by the last arriver (it must be zero before the first use).
-template <typename T>
+template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restrict__ y, float* __restrict__ partial,
                                                                int* __restrict__ counters, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ state, int B,
@@ -158,6 +158,21 @@ __global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restri
     float s = 0.f;
     for (int j = 0; j < pl; ++j) s += red[j * 2 * C + i];
     partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+  }
+  if constexpr (SINGLE) {   // one block owns the whole sample: its own partials are visible after a workgroup barrier
+    __syncthreads();
+    const size_t plane1 = (size_t)B * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float a1 = partial[((size_t)b * 2 + 0) * C + c], a2 = partial[((size_t)b * 2 + 1) * C + c];
+      const float n = (float)HW;
+      const float k0 = Elem<T>::to_f(base[c]);
+      const float m1 = a1 / n;
+      const float var = fmaxf(a2 / n - m1 * m1, 0.f);
+      const float mean = k0 + m1, rstd = 1.f / sqrtf(var + eps);
+      const int idx = b * C + c;
+      state[idx] = mean; state[plane1 + idx] = rstd; state[2 * plane1 + idx] = gamma[c] * rstd; state[3 * plane1 + idx] = beta[c];
+    }
+    return;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -383,10 +398,18 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   const int n = mode == 1 ? C : B * C;
   int* counters = reinterpret_cast<int*>(partial);
   partial = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + norm_counter_bytes(B));
-  static const bool fuse = [] { const char* e = getenv("PWR_NORM_FUSED"); return e ? atoi(e) != 0 : true; }();
+  // Measured on MI355X (BASELINE C2): the in-kernel hand-off costs more than the launch it saves (1024 blocks x release
+  // fence): train step 13.0 ms fused vs 12.6 ms as two launches.  So it is opt-in; small maps, where ONE block owns the
+  // whole sample and no hand-off is needed, always take the single-launch form.
+  static const bool fuse = [] { const char* e = getenv("PWR_NORM_FUSED"); return e ? atoi(e) != 0 : false; }();
+  if (mode == 0 && HW <= 512) {
+    if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t, true>), dim3(1, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
+    else hipLaunchKernelGGL((norm_stats_fused_kernel<float, true>), dim3(1, B), dim3(256), sh, s, (const float*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
+    return (int)hipGetLastError();
+  }
   if (mode == 0 && fuse) {
-    if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, nch, eps);
-    else hipLaunchKernelGGL((norm_stats_fused_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)y, partial, counters, gamma, beta, state, B, HW, C, nch, eps);
+    if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t, false>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, nch, eps);
+    else hipLaunchKernelGGL((norm_stats_fused_kernel<float, false>), dim3(nch, B), dim3(256), sh, s, (const float*)y, partial, counters, gamma, beta, state, B, HW, C, nch, eps);
     return (int)hipGetLastError();
   }
   if (dtype == PWR_BF16) {

@@ -95,3 +95,35 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(l, name), "libpwr_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     assert _lib.lib().pwr_abi_version() == _lib.ABI_VERSION
+
+
+def test_checkpoint_format_matches_reference(tmp_path):
+    """utils.py:302-314: {"state_dict","seed","model_param"}; a checkpoint in that format round-trips with strict=True."""
+    from pixelwiseregression_amd import save_model, load_model
+    from weights_util import fill_state_dict
+    kw = dict(stage=2, label_size=16, features=32, level=2, kernel_size=3, norm_method="batch", heatmap_method="softmax")
+    m = PixelwiseRegression(4, **kw)
+    m.load_state_dict(fill_state_dict(m.state_dict(), seed=5))
+    path = str(tmp_path / "MSRA_default_final.pt")
+    save_model(m, path, seed=0, model_param=kw)
+    raw = torch.load(path, map_location="cpu")
+    assert set(raw) == {"state_dict", "seed", "model_param"}
+    assert list(raw["state_dict"].keys()) == list(m.state_dict().keys())
+    m2 = PixelwiseRegression(4, **raw["model_param"])
+    seed, param = load_model(m2, path, eval_mode=True)
+    assert seed == 0 and param == kw and not m2.training
+    for (k, a), (_, b_) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b_), k
+
+
+def test_metric_tail_matches_reference_golden(golden_dir):
+    """recover_uvd / uvd2xyz / mean joint error (utils.py:332-337, datasets.py:100-111, train.py:276) vs reference outputs."""
+    from pixelwiseregression_amd import recover_uvd, uvd2xyz, mean_joint_error, INTRINSICS
+    g = np.load(os.path.join(golden_dir, "metric.npz"))
+    for name, (fx, fy, hu, hv) in INTRINSICS.items():
+        uvd = torch.from_numpy(g[name + "_uvd"].copy())
+        rec = recover_uvd(uvd, torch.from_numpy(g[name + "_box"]), torch.from_numpy(g[name + "_com"]), torch.from_numpy(g[name + "_cube"]))
+        np.testing.assert_allclose(rec.numpy(), g[name + "_rec"], rtol=1e-6, atol=1e-4)
+        xyz = uvd2xyz(rec.numpy(), fx, fy, hu, hv)
+        np.testing.assert_allclose(xyz, g[name + "_xyz"], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(mean_joint_error(xyz, g[name + "_xyz_gt"]), g[name + "_err"], rtol=1e-5, atol=1e-3)
