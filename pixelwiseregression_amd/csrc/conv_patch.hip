@@ -2,7 +2,7 @@
 // the conv FLOPs of /root/reference/model.py:54-65 / :103-114; also the stem's 32->64 / 64->128 convs :171-179, the
 // hourglass 64->64 convs :16 at 64x64 / 32x32, and every data gradient of those, which is the same conv with flipped weights).
 //
-// Workgroup = 256 threads; output tile = 4 rows x 32 columns = 128 pixels x BN channels.  The 6 x 34 pixel input
+// Workgroup = 256 threads, output tile = 4 rows x 32 columns (or 512 threads, 8 x 32) x BN channels.  The (TH+2) x 34 pixel input
 // patch (tile + halo) is loaded ONCE from HBM/L2 -- with the preceding norm + ReLU applied on the way ("NR prologue") --
 // into LDS as [pixel][Cin] with an XOR swizzle of the 16-byte slots, and all nine taps read their shifted windows from
 // there: 1.6x input traffic instead of the 9x of the universal im2col-on-the-fly kernel, and the NR arithmetic is done
@@ -25,17 +25,17 @@ __device__ __forceinline__ int patch_off(int pix, int slot) {
 }
 
 template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA>
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
-  constexpr int TH = 4, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+  constexpr int NT = WM * WN * 64;                // threads per workgroup (256 or 512)
+  constexpr int TH = WM * MR, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;   // tile = TH rows x 32 columns
   constexpr int BM = TH * TW, BN = WN * NR * 32;
-  static_assert(WM * MR * 32 == BM, "tile");
   constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
   constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
   constexpr int PATCH_BYTES = NPIX * NSLOT * 16;
   constexpr int WBUF_BYTES = BN * 64;
-  constexpr int NB = (BN * 4 + 255) / 256;
+  constexpr int NB = (BN * 4 + NT - 1) / NT;
   constexpr int EROWS = 64, EPITCH = BN + 4;
   constexpr int EPI_BYTES = EROWS * EPITCH * 4;
   constexpr int NSTAGE = DMA ? 3 : 2;             // weight ring: LDS-DMA runs two K steps ahead
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;
+  const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;   // requires H % TH == 0
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int b = t / tiles_img, tr = t - b * tiles_img;
   const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
@@ -59,27 +59,28 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
   auto load_w = [&](int it) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int s = tid + 256 * i;
-      if (BN * 4 >= 256 * (i + 1) || s < BN * 4)
+      const int s = tid + NT * i;
+      if (BN * 4 >= NT * (i + 1) || s < BN * 4)
         rb[i] = *reinterpret_cast<const V*>(w + ((size_t)it * p.CoutPad + n0 + (s >> 2)) * KE + (s & 3) * EP);
     }
   };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int s = tid + 256 * i;
-      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(wbuf + buf * WBUF_BYTES + lds_off(s >> 2, s & 3)) = rb[i];
+      const int s = tid + NT * i;
+      if (BN * 4 >= NT * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(wbuf + buf * WBUF_BYTES + lds_off(s >> 2, s & 3)) = rb[i];
     }
   };
   // LDS-DMA form: global_load_lds writes 64 lanes x 16 B = 1 KiB (16 tile rows) per wave instruction, linearly; the
   // XOR swizzle of the tile is applied to the per-lane SOURCE address instead (cdna_hip_programming.md rule 21).
   constexpr int NCHUNK = WBUF_BYTES / 1024;       // wave instructions per stage
-  constexpr int NBW = (NCHUNK + 3) / 4;           // per wave
+  constexpr int NWAVE = NT / 64;
+  constexpr int NBW = (NCHUNK + NWAVE - 1) / NWAVE;   // per wave
   auto dma_w = [&](int it, int stage) {
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-      const int ch = i * 4 + wid;
-      if (NCHUNK >= 4 * (i + 1) || ch < NCHUNK) {
+      const int ch = i * NWAVE + wid;
+      if (NCHUNK >= NWAVE * (i + 1) || ch < NCHUNK) {
         const int row = 16 * ch + (lane >> 2);
         const int slot = (lane & 3) ^ ((row >> 2) & 3);
         const char* src = reinterpret_cast<const char*>(w) + ((size_t)it * p.CoutPad + n0 + row) * 64 + slot * 16;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
 #pragma unroll
       for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
     }
-    constexpr int PSTEP = 256 / NSLOT;
+    constexpr int PSTEP = NT / NSLOT;
     constexpr int NIT = (NPIX + PSTEP - 1) / PSTEP;
     V v[NIT];
     bool ok[NIT];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
       T* __restrict__ y = reinterpret_cast<T*>(p.y);
       const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
       constexpr int CPR = BN / EP;
-      for (int c = tid; c < EROWS * CPR; c += 256) {
+      for (int c = tid; c < EROWS * CPR; c += NT) {
         const int row = c / CPR, cc = (c - row * CPR) * EP;
         const int ml = ps * EROWS + row, n = n0 + cc;
         const int oy = ty0 + ml / TW, ox = tx0 + ml % TW;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvParams p) {
       }
     }
     if (p.y_nchw) {
-      for (int c = tid; c < EROWS * BN; c += 256) {
+      for (int c = tid; c < EROWS * BN; c += NT) {
         const int col = c / EROWS, row = c - col * EROWS;
         const int ml = ps * EROWS + row, n = n0 + col;
         if (n < p.Cout) {
@@ -297,6 +298,15 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
   static const bool dma = [] { const char* e = getenv("PWR_PATCH_DMA"); return e ? atoi(e) != 0 : true; }();
   // fp32 (parity mode) patches leave no room for a third weight stage next to a second workgroup: register staging
   if (dma && sizeof(T) == 2) {
+    static const bool big = [] { const char* e = getenv("PWR_PATCH_BIG"); return e ? atoi(e) != 0 : true; }();
+    if constexpr (sizeof(T) == 2 && CIN == 128) {
+      if (bn == 128 && p.H % 8 == 0 && big) {
+        // 8 waves, 8x32-pixel tile: the per-CU weight stream from L2 (the limiter of the 4x32 form) is halved
+        dim3 g8(p.B * (p.H / 8) * (p.W / 32), p.CoutPad / bn);
+        hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 2, 2, 2, true>), g8, dim3(512), 0, s, p);
+        return (int)hipGetLastError();
+      }
+    }
     if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2, true>), grid, block, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 1, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 1, 1, 1, true>), grid, block, 0, s, p);
