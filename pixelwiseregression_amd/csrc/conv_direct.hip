@@ -96,7 +96,15 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += slab[(size_t)k * n + i];
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {      // 8 loads in flight, fixed summation order
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = slab[(size_t)(k + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += a[u];
+  }
+  for (; k < S; ++k) s += slab[(size_t)k * n + i];
   out[i] = accumulate ? out[i] + s : s;
 }
 

@@ -75,11 +75,18 @@ __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __res
   if (!batch_mode) {
     if (idx >= B * C) return;
     const int b = idx / C, c = idx - b * C;
+    // fixed summation order, but 8 loads in flight per accumulator chain (a plain loop waits for every load in turn)
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-      s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
-      s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
+    const float* pp = partial + ((size_t)b * nchunks * 2) * C + c;
+    int k = 0;
+    for (; k + 8 <= nchunks; k += 8) {
+      float a[8], q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = pp[((size_t)(k + u) * 2 + 0) * C]; q[u] = pp[((size_t)(k + u) * 2 + 1) * C]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += q[u]; }
     }
+    for (; k < nchunks; ++k) { s1 += pp[((size_t)k * 2 + 0) * C]; s2 += pp[((size_t)k * 2 + 1) * C]; }
     const float n = (float)HW;
     const float kk = Elem<T>::to_f(y[(size_t)b * HW * C + c]);
     const float m1 = s1 / n;
@@ -289,10 +296,16 @@ __global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restri
   if (c < C) {
     for (int b = bl; b < B; b += 32) {
       float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < nchunks; ++k) {
-        s1 += partial[((size_t)(b * nchunks + k) * 2 + 0) * C + c];
-        s2 += partial[((size_t)(b * nchunks + k) * 2 + 1) * C + c];
+      const float* pp = partial + ((size_t)b * nchunks * 2) * C + c;
+      int k = 0;
+      for (; k + 8 <= nchunks; k += 8) {
+        float a[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = pp[((size_t)(k + u) * 2 + 0) * C]; q[u] = pp[((size_t)(k + u) * 2 + 1) * C]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += q[u]; }
       }
+      for (; k < nchunks; ++k) { s1 += pp[((size_t)k * 2 + 0) * C]; s2 += pp[((size_t)k * 2 + 1) * C]; }
       t1 += s1; t2 += s2;
       if (!batch_mode) { S1[b * C + c] = s1 / (float)HW; S2[b * C + c] = s2 / (float)HW; }
     }
