@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
     V kv = *reinterpret_cast<const V*>(kb + cq * EP);
 #pragma unroll
     for (int e = 0; e < EP; ++e) k[e] = Elem<T>::to_f(kv[e]);
+#pragma unroll 4
     for (int pp = p0 + pj; pp < p1; pp += pl) {
       V v = *reinterpret_cast<const V*>(base + (size_t)pp * C + cq * EP);
 #pragma unroll
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restri
     V kv = *reinterpret_cast<const V*>(base + cq * EP);
 #pragma unroll
     for (int e = 0; e < EP; ++e) k[e] = Elem<T>::to_f(kv[e]);
+#pragma unroll 4
     for (int pp = p0 + pj; pp < p1; pp += pl) {
       V v = *reinterpret_cast<const V*>(base + (size_t)pp * C + cq * EP);
 #pragma unroll
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restri
       const int c = b * C + cq * EP + e;
       mu[e] = mean[c]; rs[e] = rstd[c]; sc[e] = scale[c]; sh[e] = shift[c];
     }
+#pragma unroll 4
     for (int pp = p0 + pj; pp < p1; pp += pl) {
       V gv = *reinterpret_cast<const V*>(g + base + (size_t)pp * C + cq * EP);
       V yv = *reinterpret_cast<const V*>(y + base + (size_t)pp * C + cq * EP);
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
     s1[e] = S1[c]; s2[e] = S2[c];
   }
+#pragma unroll 4
   for (int pp = p0 + pj; pp < p1; pp += pl) {
     const size_t off = base + (size_t)pp * C + cq * EP;
     V gv = *reinterpret_cast<const V*>(g + off);

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 #pragma unroll
   for (int e = 0; e < EP; ++e) s[e] = 0.f;
   if (pj < pl) {
+#pragma unroll 4
     for (long long r = r0 + pj; r < r0 + rows_per_block && r < M; r += pl) {
       V v = *reinterpret_cast<const V*>(x + (size_t)r * C + cq * EP);
 #pragma unroll
