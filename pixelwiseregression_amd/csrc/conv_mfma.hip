@@ -60,13 +60,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 
   V ra[2], rb[NB];
   bool av[2];
-  int cur_c0 = 0;
+  // norm state of the two A rows for the K chunk in flight, loaded TOGETHER with the data so that the two L2 latencies
+  // overlap (small maps are latency bound: one workgroup walks the whole K loop alone)
+  float nmu[2][EP], nsc[2][EP], nbe[2][EP];
+  const size_t nplane = (size_t)p.B * p.Cin;
 
   auto load_global = [&](int it) {
     const int tap = it / p.KCH, kch = it - tap * p.KCH;
     const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
     const int c0 = kch * KE + q * EP;
-    cur_c0 = c0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int iy, ix;
@@ -82,7 +84,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       av[i] = ok;
       V v = {};
-      if (ok) v = *reinterpret_cast<const V*>(x + ((size_t)(ab[i] * p.H + iy) * p.W + ix) * p.Cin + c0);
+      if (ok) {
+        v = *reinterpret_cast<const V*>(x + ((size_t)(ab[i] * p.H + iy) * p.W + ix) * p.Cin + c0);
+        if (p.in_norm) {
+          const float* st = p.in_norm + (size_t)ab[i] * p.Cin + c0;
+#pragma unroll
+          for (int e = 0; e < EP; ++e) { nmu[i][e] = st[e]; nsc[i][e] = st[2 * nplane + e]; nbe[i][e] = st[3 * nplane + e]; }
+        }
+      }
       ra[i] = v;
     }
 #pragma unroll
@@ -100,8 +109,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       V v = ra[i];
-      if (p.in_norm && av[i])
-        v = nr_transform<T>(v, p.in_norm + (size_t)ab[i] * p.Cin + cur_c0, (size_t)p.B * p.Cin, p.relu_in);
+      if (p.in_norm && av[i]) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          float f = fmaf(Elem<T>::to_f(v[e]) - nmu[i][e], nsc[i][e], nbe[i][e]);
+          if (p.relu_in) f = fmaxf(f, 0.f);
+          o[e] = Elem<T>::from_f(f);
+        }
+        v = o;
+      }
       *reinterpret_cast<V*>(lA + lds_off((tid >> 2) + 64 * i, q)) = v;
     }
 #pragma unroll
