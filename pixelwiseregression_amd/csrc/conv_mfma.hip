@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   float nmu[2][EP], nsc[2][EP], nbe[2][EP];
   const size_t nplane = (size_t)p.B * p.Cin;
 
-  auto load_global = [&](int it) {
-    const int tap = it / p.KCH, kch = it - tap * p.KCH;
-    const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+  // (tap, K chunk) of the next tile to load, advanced incrementally: no integer divisions in the K loop
+  int l_tap = 0, l_kch = 0, l_ky = 0, l_kx = 0;
+  auto load_global = [&](int) {
+    const int tap = l_tap, kch = l_kch, ky = l_ky, kx = l_kx;
+    if (++l_kch == p.KCH) { l_kch = 0; ++l_tap; if (++l_kx == p.ksize) { l_kx = 0; ++l_ky; } }
     const int c0 = kch * KE + q * EP;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
