@@ -58,16 +58,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   const int taps = p.ksize * p.ksize;
   const int iters = taps * p.KCH;
 
-  // Two register stages: the global loads of K tile it+2 are issued before tile it is multiplied, i.e. two MFMA phases
-  // ahead of their LDS store -- small maps are latency bound (one workgroup walks the whole K loop alone).  The norm
-  // state of the A rows is loaded together with the data so that the two L2 latencies overlap.
-  struct Stage { V a[2]; V b[NB]; bool av[2]; float mu[2][EP], sc[2][EP], be[2][EP]; };
-  Stage sg[2];
+  V ra[2], rb[NB];
+  bool av[2];
+  // norm state of the two A rows for the K chunk in flight, loaded TOGETHER with the data so that the two L2 latencies
+  // overlap (small maps are latency bound: one workgroup walks the whole K loop alone)
+  float nmu[2][EP], nsc[2][EP], nbe[2][EP];
   const size_t nplane = (size_t)p.B * p.Cin;
 
   // (tap, K chunk) of the next tile to load, advanced incrementally: no integer divisions in the K loop
   int l_tap = 0, l_kch = 0, l_ky = 0, l_kx = 0;
-  auto load_global = [&](Stage& S) {
+  auto load_global = [&](int) {
     const int tap = l_tap, kch = l_kch, ky = l_ky, kx = l_kx;
     if (++l_kch == p.KCH) { l_kch = 0; ++l_tap; if (++l_kx == p.ksize) { l_kx = 0; ++l_ky; } }
     const int c0 = kch * KE + q * EP;
@@ -84,38 +84,38 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
         iy = sy >> 1; ix = sx >> 1;
       }
       ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      S.av[i] = ok;
+      av[i] = ok;
       V v = {};
       if (ok) {
         v = *reinterpret_cast<const V*>(x + ((size_t)(ab[i] * p.H + iy) * p.W + ix) * p.Cin + c0);
         if (p.in_norm) {
           const float* st = p.in_norm + (size_t)ab[i] * p.Cin + c0;
 #pragma unroll
-          for (int e = 0; e < EP; ++e) { S.mu[i][e] = st[e]; S.sc[i][e] = st[2 * nplane + e]; S.be[i][e] = st[3 * nplane + e]; }
+          for (int e = 0; e < EP; ++e) { nmu[i][e] = st[e]; nsc[i][e] = st[2 * nplane + e]; nbe[i][e] = st[3 * nplane + e]; }
         }
       }
-      S.a[i] = v;
+      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int s = tid + 256 * i;
       if (BN * 4 >= 256 * (i + 1) || s < BN * 4) {
         const int row = s >> 2, qq = s & 3;
-        S.b[i] = *reinterpret_cast<const V*>(w + ((size_t)(tap * p.KCH + kch) * p.CoutPad + n0 + row) * KE + qq * EP);
+        rb[i] = *reinterpret_cast<const V*>(w + ((size_t)(tap * p.KCH + kch) * p.CoutPad + n0 + row) * KE + qq * EP);
       }
     }
   };
-  auto store_lds = [&](Stage& S, int buf) {
+  auto store_lds = [&](int buf) {
     char* lA = smem + buf * (BM + BN) * 64;
     char* lB = lA + BM * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      V v = S.a[i];
-      if (p.in_norm && S.av[i]) {
+      V v = ra[i];
+      if (p.in_norm && av[i]) {
         V o;
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
-          float f = fmaf(Elem<T>::to_f(v[e]) - S.mu[i][e], S.sc[i][e], S.be[i][e]);
+          float f = fmaf(Elem<T>::to_f(v[e]) - nmu[i][e], nsc[i][e], nbe[i][e]);
           if (p.relu_in) f = fmaxf(f, 0.f);
           o[e] = Elem<T>::from_f(f);
         }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int s = tid + 256 * i;
-      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(lB + lds_off(s >> 2, s & 3)) = S.b[i];
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(lB + lds_off(s >> 2, s & 3)) = rb[i];
     }
   };
 
@@ -150,9 +150,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
   }
-  auto body = [&](auto BUF, int it) {
-    constexpr int buf = decltype(BUF)::value;
-    if (it + 2 < iters) load_global(sg[buf]);        // sg[buf] (tile it) is already in LDS: refill with tile it+2
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < iters) load_global(it + 1);
     const char* lA = smem + buf * (BM + BN) * 64;
     mma_tile<T, MR, NR>(lA, lA + BM * 64, wm * MR * 32, wn * NR * 32, lane, acc);
     if constexpr (kTwoLevel) {
@@ -163,16 +166,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
           for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
       }
     }
-    if (it + 1 < iters) store_lds(sg[buf ^ 1], buf ^ 1);
+    if (it + 1 < iters) store_lds(buf ^ 1);
     __syncthreads();
-  };
-  load_global(sg[0]);
-  if (iters > 1) load_global(sg[1]);
-  store_lds(sg[0], 0);
-  __syncthreads();
-  for (int it = 0; it < iters; it += 2) {
-    body(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < iters) body(std::integral_constant<int, 1>{}, it + 1);
   }
   if constexpr (kTwoLevel) {
 #pragma unroll
