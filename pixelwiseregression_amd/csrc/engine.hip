@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -38,7 +39,24 @@ struct Ctx {
   const float* g_uvd[8] = {};
   void* stream = nullptr;
   int training = 1;
+  // second stream for the parameter-gradient kernels (wgrad + reduce + bias sums): they only feed the flat gradient
+  // buffer, so they run beside the data-gradient / norm-backward chain instead of inside it
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool use_side = true;
 };
+
+// run `op` on the side stream, ordered after everything enqueued so far on the main stream
+static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
+  if (!c.use_side || !c.side) return op(c);
+  hipEventRecord(c.ev_fork, (hipStream_t)c.stream);
+  hipStreamWaitEvent(c.side, c.ev_fork, 0);
+  void* main_stream = c.stream;
+  c.stream = c.side;
+  const int rc = op(c);
+  c.stream = main_stream;
+  return rc;
+}
 
 typedef std::function<int(Ctx&)> Op;
 
@@ -222,14 +240,21 @@ struct Engine {
     want_slab(pwr_conv_wgrad_slab_bytes(cv.Cout, cv.Cin, cv.k, splits));
     want_slab((size_t)pwr_colsum_blocks(M) * cv.Cout * 4);
     Engine* E = this;
+    // parameter gradients: side stream
     bwd_cur.push_back([=](Ctx& c) {
-      int rc = pwr_conv_wgrad(c.arena + x.off, c.arena + y.goff, has_nr ? (float*)(c.arena + n.state) : nullptr,
-                              1, (float*)(c.arena + E->scr_slab), c.grads + cv.w, 0,
-                              Bc, x.H, x.W, cv.Cin, cv.cin_real, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c.stream);
-      if (rc) return rc;
-      if (bias_grad || (E->norm_mode == 1 && !c.training))
-        rc = pwr_colsum_nhwc(c.arena + y.goff, (float*)(c.arena + E->scr_slab), c.grads + cv.b, (long long)M, cv.Cout, 0, dt, c.stream);
-      if (rc || !need_dx) return rc;
+      return run_on_side(c, [=](Ctx& c2) {
+        int rc = pwr_conv_wgrad(c2.arena + x.off, c2.arena + y.goff, has_nr ? (float*)(c2.arena + n.state) : nullptr,
+                                1, (float*)(c2.arena + E->scr_slab), c2.grads + cv.w, 0,
+                                Bc, x.H, x.W, cv.Cin, cv.cin_real, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c2.stream);
+        if (rc) return rc;
+        if (bias_grad || (E->norm_mode == 1 && !c2.training))
+          rc = pwr_colsum_nhwc(c2.arena + y.goff, (float*)(c2.arena + E->scr_slab), c2.grads + cv.b, (long long)M, cv.Cout, 0, dt, c2.stream);
+        return rc;
+      });
+    });
+    if (!need_dx) return;
+    // data gradient: main stream
+    bwd_cur.push_back([=](Ctx& c) {
       if (cv.stride == 1)
         return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0,
                             accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k,
@@ -348,8 +373,10 @@ struct Engine {
       if (rc) return rc;
       rc = pwr_planesum_nchw((const float*)(c.arena + g_nchw_off), (float*)(c.arena + E->scr_S1), c.grads + c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
       if (rc) return rc;
-      rc = pwr_conv_wgrad(c.arena + h3.off, c.arena + gT, (float*)(c.arena + n2.state), 1,
-                          (float*)(c.arena + E->scr_slab), c.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c.stream);
+      rc = run_on_side(c, [=](Ctx& c2) {
+        return pwr_conv_wgrad(c2.arena + h3.off, c2.arena + gT, (float*)(c2.arena + n2.state), 1,
+                              (float*)(c2.arena + E->scr_slab), c2.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c2.stream);
+      });
       if (rc) return rc;
       return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
                           Jp, c3.Cin, c3.k, 1, 0, dt, c.stream);
@@ -408,7 +435,9 @@ struct Engine {
       norm_bwd(sy[0], sn[0], 0, false);
       const Tn y0 = sy[0]; const ConvL c0 = sc[0];
       bwd_cur.push_back([=](Ctx& c) {
-        return pwr_stem_conv_wgrad(c.img, c.arena + y0.goff, (float*)(c.arena + E->scr_slab), c.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c.stream);
+        return run_on_side(c, [=](Ctx& c2) {
+          return pwr_stem_conv_wgrad(c2.img, c2.arena + y0.goff, (float*)(c2.arena + E->scr_slab), c2.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c2.stream);
+        });
       });
       std::swap(stem_bwd, bwd_cur);
     }
@@ -545,7 +574,14 @@ extern "C" void* pwr_engine_create(const int* cfg, int B, int dtype, int trainin
   return e;
 }
 
-extern "C" void pwr_engine_destroy(void* h) { delete (Engine*)h; }
+extern "C" void pwr_engine_destroy(void* h) {
+  Engine* e = (Engine*)h;
+  if (e->ctx.side) {
+    hipStreamSynchronize(e->ctx.side);
+    hipEventDestroy(e->ctx.ev_fork); hipEventDestroy(e->ctx.ev_join); hipStreamDestroy(e->ctx.side);
+  }
+  delete e;
+}
 extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
 extern "C" size_t pwr_engine_pack_bytes(void* h) { return ((Engine*)h)->pack_bytes; }
 extern "C" int pwr_engine_num_segments(void* h) { return (int)((Engine*)h)->bwd.size(); }
@@ -607,14 +643,30 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
   for (int s = 0; s < e->stages; ++s) {
     c.g_p[s] = (const float*)gouts[3 * s]; c.g_D[s] = (const float*)gouts[3 * s + 1]; c.g_uvd[s] = (const float*)gouts[3 * s + 2];
   }
+  if (c.use_side && !c.side) {
+    const char* env = getenv("PWR_SIDE_STREAM");
+    c.use_side = env ? atoi(env) != 0 : true;
+    if (c.use_side) {
+      if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) {
+        c.use_side = false; c.side = nullptr;
+      }
+    }
+  }
   if (seg == 0) {
     hipError_t er = hipMemsetAsync(c.grads, 0, (size_t)n_grad_floats * 4, (hipStream_t)stream);
     if (er != hipSuccess) return (int)er;
   }
   auto& ops = e->bwd[seg];
-  for (size_t i = 0; i < ops.size(); ++i) {
-    int rc = ops[i](c);
-    if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; return rc; }
+  int rc = 0;
+  for (size_t i = 0; i < ops.size() && !rc; ++i) {
+    rc = ops[i](c);
+    if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
   }
-  return 0;
+  if (c.use_side && c.side) {   // join: the segment's parameter gradients are complete before anything later on `stream`
+    hipEventRecord(c.ev_join, c.side);
+    hipStreamWaitEvent((hipStream_t)stream, c.ev_join, 0);
+  }
+  return rc;
 }
