@@ -133,6 +133,12 @@ int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* 
 int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);
 
+/* InstanceNorm + ReLU backward for maps of at most 512 pixels in ONE launch (one workgroup owns a sample); the
+ * per-sample sums [B][2][C] feed pwr_norm_param_grad (dgamma / dbeta over the batch), which is off the critical path. */
+int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* sums, const void* addend, void* dy, int relu, int B,
+                       int HW, int C, int dtype, void* stream);
+int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Hourglass plumbing (model.py:40, :45-47), NHWC.
  * ------------------------------------------------------------------------------------------- */

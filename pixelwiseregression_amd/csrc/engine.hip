@@ -65,6 +65,7 @@ struct Tn {  // NHWC activation in the arena
   int H = 0, W = 0, C = 0;
 };
 struct NormL {
+  size_t sums = 0;  // [B][2][C] fp32 per-sample backward sums (small maps)
   size_t state;  // [4][B][C] fp32: mean, rstd, scale, beta
   long long gamma, beta, rm = -1, rv = -1;
   int C;
@@ -164,6 +165,7 @@ struct Engine {
     n.beta = take_param(C);
     if (norm_mode == 1) { n.rm = take_buffer(); n.rv = take_buffer(); }
     n.state = alloc((size_t)4 * B * C * 4);
+    if (training) n.sums = alloc((size_t)2 * B * C * 4);
     return n;
   }
   int splits_for(int M, int cin, int cout, int k) const {
@@ -205,6 +207,14 @@ struct Engine {
     Engine* E = this;
     bwd_cur.push_back([=](Ctx& c) {
       int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+      if (mode == 0 && HW <= 512) {   // one launch on the critical path; dgamma / dbeta beside it
+        int rc = pwr_norm_bwd_small(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + n.sums),
+                                    has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
+        if (rc) return rc;
+        return run_on_side(c, [=](Ctx& c2) {
+          return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
+        });
+      }
       return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                           (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                           has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0,

@@ -376,6 +376,104 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   }
 }
 
+// Small maps (HW <= 512): ONE block owns a whole sample, so the two reductions and the element-wise apply of the
+// InstanceNorm backward fit in one launch; the per-sample sums go to `sums` [B][2][C] for the (off-critical-path)
+// dgamma / dbeta reduction over the batch.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_small_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                             const float* __restrict__ state, float* __restrict__ sums,
+                                                             const T* __restrict__ addend, T* __restrict__ dy, int B, int HW, int C,
+                                                             int relu) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];   // [pl][2][C] + [2][C]
+  const int b = blockIdx.x;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  float* tot = red + (size_t)pl * 2 * C;
+  const size_t base = (size_t)b * HW * C;
+  const size_t plane = (size_t)B * C;
+  float mu[EP], rs[EP], sc[EP], sh[EP], s1[EP], s2[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (pj < pl) {
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const int c = b * C + cq * EP + e;
+      mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
+    }
+#pragma unroll 2
+    for (int pp = pj; pp < HW; pp += pl) {
+      V gv = *reinterpret_cast<const V*>(g + base + (size_t)pp * C + cq * EP);
+      V yv = *reinterpret_cast<const V*>(y + base + (size_t)pp * C + cq * EP);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float yy = Elem<T>::to_f(yv[e]);
+        float gg = Elem<T>::to_f(gv[e]);
+        if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
+        s1[e] += gg;
+        s2[e] = fmaf(gg, (yy - mu[e]) * rs[e], s2[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      red[(pj * 2 + 0) * C + cq * EP + e] = s1[e];
+      red[(pj * 2 + 1) * C + cq * EP + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int j = 0; j < pl; ++j) t += red[j * 2 * C + i];
+    tot[i] = t;
+    sums[(size_t)b * 2 * C + i] = t;
+  }
+  __syncthreads();
+  if (pj >= pl) return;
+  const float inv = 1.f / (float)HW;
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { s1[e] = tot[cq * EP + e] * inv; s2[e] = tot[C + cq * EP + e] * inv; }
+#pragma unroll 2
+  for (int pp = pj; pp < HW; pp += pl) {
+    const size_t off = base + (size_t)pp * C + cq * EP;
+    V gv = *reinterpret_cast<const V*>(g + off);
+    V yv = *reinterpret_cast<const V*>(y + off);
+    V av = {};
+    if (addend) av = *reinterpret_cast<const V*>(addend + off);
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const float yy = Elem<T>::to_f(yv[e]);
+      float gg = Elem<T>::to_f(gv[e]);
+      if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
+      const float xn = (yy - mu[e]) * rs[e];
+      float r = sc[e] * (gg - s1[e] - xn * s2[e]);
+      if (addend) r += Elem<T>::to_f(av[e]);
+      o[e] = Elem<T>::from_f(r);
+    }
+    *reinterpret_cast<V*>(dy + off) = o;
+  }
+}
+
+// dgamma[c] (+)= sum_b sums[b][1][c]; dbeta[c] (+)= sum_b sums[b][0][c]   (fixed order)
+__global__ void norm_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
+                                       int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t1 = 0.f, t2 = 0.f;
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    float a[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = sums[((size_t)(b + u) * 2 + 0) * C + c]; q[u] = sums[((size_t)(b + u) * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { t1 += a[u]; t2 += q[u]; }
+  }
+  for (; b < B; ++b) { t1 += sums[((size_t)b * 2 + 0) * C + c]; t2 += sums[((size_t)b * 2 + 1) * C + c]; }
+  dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
+  dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
+}
+
 static inline int norm_chunks(int B, int HW) {
   int n = (1024 + B - 1) / B;
   int maxc = (HW + 31) / 32;
@@ -474,5 +572,23 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
     hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
                        S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
   }
+  return (int)hipGetLastError();
+}
+
+// InstanceNorm + ReLU backward for small maps (HW <= 512) in one launch; `sums` ([B][2][C] floats) receives the per-sample
+// reductions for pwr_norm_param_grad, which may run later / on another stream.
+extern "C" int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* sums, const void* addend, void* dy, int relu,
+                                  int B, int HW, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256 || HW > 512) return PWR_EUNSUPPORTED;
+  const int pl = 256 / (C / EP);
+  const size_t sh = ((size_t)pl * 2 * C + 2 * C) * 4;
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_bwd_small_kernel<bf16_t>), dim3(B), dim3(256), sh, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)y, state, sums, (const bf16_t*)addend, (bf16_t*)dy, B, HW, C, relu);
+  else hipLaunchKernelGGL((norm_bwd_small_kernel<float>), dim3(B), dim3(256), sh, (hipStream_t)stream, (const float*)g, (const float*)y, state, sums, (const float*)addend, (float*)dy, B, HW, C, relu);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream) {
+  hipLaunchKernelGGL(norm_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, dgamma, dbeta, B, C, accumulate);
   return (int)hipGetLastError();
 }

@@ -244,3 +244,17 @@ def planesum_nchw(x):
     out = torch.empty(J, dtype=torch.float32, device=x.device)
     _lib.check(l.pwr_planesum_nchw(_p(x), _p(part), _p(out), B, J, P * P, 0, _s(x)), "pwr_planesum_nchw")
     return out
+
+
+def norm_bwd_small(g, y, state, relu=True, addend=None):
+    """InstanceNorm+ReLU backward for maps of <= 512 pixels in one launch (+ the batch reduction of dgamma / dbeta)."""
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    sums = torch.empty(B, 2, C, dtype=torch.float32, device=y.device)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty_like(dgamma)
+    _lib.check(l.pwr_norm_bwd_small(_p(g), _p(y), _p(state), _p(sums), _p(addend), _p(dy), int(relu), B, H * W, C, _dt(y), _s(y)),
+               "pwr_norm_bwd_small")
+    _lib.check(l.pwr_norm_param_grad(_p(sums), _p(dgamma), _p(dbeta), B, C, 0, _s(y)), "pwr_norm_param_grad")
+    return dy, dgamma, dbeta

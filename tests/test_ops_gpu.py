@@ -249,6 +249,11 @@ def test_instance_norm_stats_and_backward(dtype, B, H, W, C):
     assert_close(nchw(dy), yq.grad + q(add, dtype), t, "norm bwd dy")
     assert_close(dgam.double().cpu(), gd.grad, t, "dgamma")
     assert_close(dbet.double().cpu(), bd.grad, t, "dbeta")
+    if H * W <= 512:    # the single-launch small-map form must agree as well
+        dy2, dgam2, dbet2 = K.norm_bwd_small(nhwc(g, dtype), yd, state, relu=True, addend=nhwc(add, dtype))
+        assert_close(nchw(dy2), yq.grad + q(add, dtype), t, "norm bwd small dy")
+        assert_close(dgam2.double().cpu(), gd.grad, t, "small dgamma")
+        assert_close(dbet2.double().cpu(), bd.grad, t, "small dbeta")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
