@@ -207,7 +207,8 @@ struct Engine {
     Engine* E = this;
     bwd_cur.push_back([=](Ctx& c) {
       int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
-      if (mode == 0 && HW <= 512) {   // one launch on the critical path; dgamma / dbeta beside it
+      static const int small_max = [] { const char* e = getenv("PWR_NORM_BWD_SMALL"); return e ? atoi(e) : 0; }();   // measured on MI355X: 9.94 ms/step off, 10.12 at 16, 10.22 at 64 -> off
+      if (mode == 0 && HW <= small_max) {   // one launch on the critical path; dgamma / dbeta beside it
         int rc = pwr_norm_bwd_small(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + n.sums),
                                     has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
         if (rc) return rc;

@@ -517,7 +517,8 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   // fence): train step 13.0 ms fused vs 12.6 ms as two launches.  So it is opt-in; small maps, where ONE block owns the
   // whole sample and no hand-off is needed, always take the single-launch form.
   static const bool fuse = [] { const char* e = getenv("PWR_NORM_FUSED"); return e ? atoi(e) != 0 : false; }();
-  if (mode == 0 && HW <= 512) {
+  static const int fwd_small = [] { const char* e = getenv("PWR_NORM_FWD_SMALL"); return e ? atoi(e) : 512; }();
+  if (mode == 0 && HW <= fwd_small) {
     if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t, true>), dim3(1, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
     else hipLaunchKernelGGL((norm_stats_fused_kernel<float, true>), dim3(1, B), dim3(256), sh, s, (const float*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
     return (int)hipGetLastError();
