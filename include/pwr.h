@@ -133,6 +133,14 @@ int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* 
 int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);
 
+/* InstanceNorm backward split so that the batch reduction of dgamma / dbeta can run beside the critical path:
+ * pwr_norm_bwd_main = partial sums into `partial` (pwr_norm_bwd_partial_bytes; keep it until pwr_norm_bwd_params ran) + apply,
+ * pwr_norm_bwd_params = dgamma / dbeta from `partial`. */
+size_t pwr_norm_bwd_partial_bytes(int B, int HW, int C);
+int pwr_norm_bwd_main(const void* g, const void* y, const float* state, float* partial, const void* addend, void* dy, int relu, int B,
+                      int HW, int C, int dtype, void* stream);
+int pwr_norm_bwd_params(const float* partial, float* dgamma, float* dbeta, int accumulate, int B, int HW, int C, void* stream);
+
 /* InstanceNorm + ReLU backward for maps of at most 512 pixels in ONE launch (one workgroup owns a sample); the
  * per-sample sums [B][2][C] feed pwr_norm_param_grad (dgamma / dbeta over the batch), which is off the critical path. */
 int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* sums, const void* addend, void* dy, int relu, int B,

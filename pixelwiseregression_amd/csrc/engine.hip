@@ -166,7 +166,7 @@ struct Engine {
     if (norm_mode == 1) { n.rm = take_buffer(); n.rv = take_buffer(); }
     n.state = alloc((size_t)4 * B * C * 4);
     if (training) n.sums = alloc((size_t)2 * B * C * 4);
-    return n;
+    return n;   // (the backward partial slab is sized per tensor in norm_bwd)
   }
   int splits_for(int M, int cin, int cout, int k) const {
     const int KE = dtype == PWR_BF16 ? 32 : 16;
@@ -205,6 +205,7 @@ struct Engine {
   void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
     Engine* E = this;
+    const size_t bpart = nm == 0 ? alloc(pwr_norm_bwd_partial_bytes(B, HW, C)) : 0;   // private: read later by the side stream
     bwd_cur.push_back([=](Ctx& c) {
       int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
       static const int small_max = [] { const char* e = getenv("PWR_NORM_BWD_SMALL"); return e ? atoi(e) : 0; }();   // measured on MI355X: 9.94 ms/step off, 10.12 at 16, 10.22 at 64 -> off
@@ -214,6 +215,14 @@ struct Engine {
         if (rc) return rc;
         return run_on_side(c, [=](Ctx& c2) {
           return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
+        });
+      }
+      if (mode == 0) {   // 2 launches on the critical path; dgamma / dbeta beside it
+        int rc = pwr_norm_bwd_main(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + bpart),
+                                   has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
+        if (rc) return rc;
+        return run_on_side(c, [=](Ctx& c2) {
+          return pwr_norm_bwd_params((float*)(c2.arena + bpart), c2.grads + n.gamma, c2.grads + n.beta, 0, Bc, HW, C, c2.stream);
         });
       }
       return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),

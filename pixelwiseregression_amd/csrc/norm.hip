@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restri
       }
       for (; k < nchunks; ++k) { s1 += pp[((size_t)k * 2 + 0) * C]; s2 += pp[((size_t)k * 2 + 1) * C]; }
       t1 += s1; t2 += s2;
-      if (!batch_mode) { S1[b * C + c] = s1 / (float)HW; S2[b * C + c] = s2 / (float)HW; }
+      if (!batch_mode && S1) { S1[b * C + c] = s1 / (float)HW; S2[b * C + c] = s2 / (float)HW; }
     }
   }
   r1[bl][cl] = t1; r2[bl][cl] = t2;
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restri
 
 // dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend).  Same (chunk, b) decomposition as the partial kernels so that the
 // per-channel constants are loaded once per thread, not once per element.
-template <typename T>
+// FROM_PARTIAL (instance norm): every block sums the pixel-chunk partials of its sample itself (fixed order, so all
+// blocks of a sample get identical sums) instead of waiting for a separate reduction launch.
+template <typename T, bool FROM_PARTIAL>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                              const float* __restrict__ state, int B,
                                                              const float* __restrict__ S1, const float* __restrict__ S2,
@@ -567,12 +569,45 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
     hipMemsetAsync(S2, 0, (size_t)B * C * 4, s);
   }
   if (dtype == PWR_BF16) {
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, false>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
                        S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
   } else {
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<float>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
                        S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
   }
+  return (int)hipGetLastError();
+}
+
+// The same for InstanceNorm as two entry points, so that the batch reduction of dgamma / dbeta can leave the critical path:
+//   pwr_norm_bwd_main:   partial sums (written to `partial`, which must stay untouched until pwr_norm_bwd_params ran)
+//                        + apply; the apply blocks combine the partials of their sample themselves (2 launches)
+//   pwr_norm_bwd_params: dgamma / dbeta from `partial` (any stream, any time later)
+extern "C" size_t pwr_norm_bwd_partial_bytes(int B, int HW, int C) { return (size_t)B * norm_chunks(B, HW) * 2 * C * sizeof(float); }
+
+extern "C" int pwr_norm_bwd_main(const void* g, const void* y, const float* state, float* partial, const void* addend, void* dy,
+                                 int relu, int B, int HW, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = norm_chunks(B, HW);
+  const int pl = 256 / (C / EP);
+  const size_t sh = (size_t)pl * 2 * C * 4;
+  if (dtype == PWR_BF16) {
+    hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y, state, B, partial, HW, C, nch, relu);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, true>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
+                       partial, nullptr, (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
+  } else {
+    hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state, B, partial, HW, C, nch, relu);
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float, true>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
+                       partial, nullptr, (const float*)addend, (float*)dy, HW, C, nch, relu);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_norm_bwd_params(const float* partial, float* dgamma, float* dbeta, int accumulate, int B, int HW, int C, void* stream) {
+  const int nch = norm_chunks(B, HW);
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, (float*)nullptr, (float*)nullptr,
+                     dgamma, dbeta, B, HW, C, nch, 0, accumulate);
   return (int)hipGetLastError();
 }
 

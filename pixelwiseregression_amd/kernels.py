@@ -258,3 +258,17 @@ def norm_bwd_small(g, y, state, relu=True, addend=None):
                "pwr_norm_bwd_small")
     _lib.check(l.pwr_norm_param_grad(_p(sums), _p(dgamma), _p(dbeta), B, C, 0, _s(y)), "pwr_norm_param_grad")
     return dy, dgamma, dbeta
+
+
+def norm_bwd_split(g, y, state, relu=True, addend=None):
+    """InstanceNorm+ReLU backward as the engine issues it: main part (partials + apply) and the parameter part."""
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    partial = torch.empty(l.pwr_norm_bwd_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=y.device)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty_like(dgamma)
+    _lib.check(l.pwr_norm_bwd_main(_p(g), _p(y), _p(state), _p(partial), _p(addend), _p(dy), int(relu), B, H * W, C, _dt(y), _s(y)),
+               "pwr_norm_bwd_main")
+    _lib.check(l.pwr_norm_bwd_params(_p(partial), _p(dgamma), _p(dbeta), 0, B, H * W, C, _s(y)), "pwr_norm_bwd_params")
+    return dy, dgamma, dbeta

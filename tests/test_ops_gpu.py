@@ -249,6 +249,10 @@ def test_instance_norm_stats_and_backward(dtype, B, H, W, C):
     assert_close(nchw(dy), yq.grad + q(add, dtype), t, "norm bwd dy")
     assert_close(dgam.double().cpu(), gd.grad, t, "dgamma")
     assert_close(dbet.double().cpu(), bd.grad, t, "dbeta")
+    dy3, dgam3, dbet3 = K.norm_bwd_split(nhwc(g, dtype), yd, state, relu=True, addend=nhwc(add, dtype))   # the engine's form
+    assert_close(nchw(dy3), yq.grad + q(add, dtype), t, "norm bwd split dy")
+    assert_close(dgam3.double().cpu(), gd.grad, t, "split dgamma")
+    assert_close(dbet3.double().cpu(), bd.grad, t, "split dbeta")
     if H * W <= 512:    # the single-launch small-map form must agree as well
         dy2, dgam2, dbet2 = K.norm_bwd_small(nhwc(g, dtype), yd, state, relu=True, addend=nhwc(add, dtype))
         assert_close(nchw(dy2), yq.grad + q(add, dtype), t, "norm bwd small dy")
