@@ -354,7 +354,25 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   for (int e = 0; e < EP; ++e) {
     const int c = b * C + cq * EP + e;
     mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
-    s1[e] = S1[c]; s2[e] = S2[c];
+    if constexpr (!FROM_PARTIAL) { s1[e] = S1[c]; s2[e] = S2[c]; }
+  }
+  if constexpr (FROM_PARTIAL) {   // S1 = the partial slab [B][nchunks][2][C]
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const float* pp0 = S1 + ((size_t)b * nchunks * 2) * C + cq * EP;
+#pragma unroll 4
+    for (int k = 0; k < nchunks; ++k) {
+#pragma unroll
+      for (int e = 0; e < EP; e += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pp0 + ((size_t)k * 2 + 0) * C + e);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pp0 + ((size_t)k * 2 + 1) * C + e);
+        s1[e] += a.x; s1[e + 1] += a.y; s1[e + 2] += a.z; s1[e + 3] += a.w;
+        s2[e] += q.x; s2[e + 1] += q.y; s2[e + 2] += q.z; s2[e + 3] += q.w;
+      }
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { s1[e] *= inv; s2[e] *= inv; }
   }
 #pragma unroll 4
   for (int pp = p0 + pj; pp < p1; pp += pl) {
