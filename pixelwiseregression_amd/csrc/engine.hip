@@ -205,7 +205,10 @@ struct Engine {
   void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
     Engine* E = this;
-    const size_t bpart = nm == 0 ? alloc(pwr_norm_bwd_partial_bytes(B, HW, C)) : 0;   // private: read later by the side stream
+    // measured on MI355X (C2): the split form (apply blocks combine the partials; dgamma/dbeta on the side stream) is SLOWER
+    // than the plain three-launch form, 10.7 vs 9.9 ms per step -> opt-in only
+    static const bool split = [] { const char* e = getenv("PWR_NORM_BWD_SPLIT"); return e ? atoi(e) != 0 : false; }();
+    const size_t bpart = (nm == 0 && split) ? alloc(pwr_norm_bwd_partial_bytes(B, HW, C)) : 0;
     bwd_cur.push_back([=](Ctx& c) {
       int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
       static const int small_max = [] { const char* e = getenv("PWR_NORM_BWD_SMALL"); return e ? atoi(e) : 0; }();   // measured on MI355X: 9.94 ms/step off, 10.12 at 16, 10.22 at 64 -> off
@@ -217,7 +220,7 @@ struct Engine {
           return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
         });
       }
-      if (mode == 0) {   // 2 launches on the critical path; dgamma / dbeta beside it
+      if (mode == 0 && split) {   // 2 launches on the critical path; dgamma / dbeta beside it
         int rc = pwr_norm_bwd_main(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + bpart),
                                    has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
         if (rc) return rc;
