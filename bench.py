@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="hip", choices=["hip", "aten"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--harness", default="native", choices=["native", "torch"],
+                    help="native: pixelwiseregression_amd.train.TrainStep (loss + AdamW kernels on the flat buffers); "
+                         "torch: autograd + torch.optim.AdamW, the reference's loop verbatim")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (debug)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share cuda:0 (with --dist-backend gloo) to exercise the data-parallel path on a 1-GPU box")
@@ -156,7 +159,11 @@ def main():
     if world > 1:
         from pixelwiseregression_amd.ddp import DataParallel
         DataParallel(model)
-    if args.backend == "hip":
+    native = args.backend == "hip" and args.harness == "native"
+    if native:
+        from pixelwiseregression_amd.train import TrainStep
+        trainer = TrainStep(model, opt="adam", lr=1e-4, beta1=0.9, beta2=0.999, weight_decay=0.0, alpha=1.0, lambda_h=1.0, lambda_d=0.01)
+    elif args.backend == "hip":
         flat = torch.nn.Parameter(model.flat_parameters())
         flat.grad = model.flat_grad()
         opt = torch.optim.AdamW([flat], lr=1e-4, betas=(0.9, 0.999), weight_decay=0, fused=True)
@@ -165,6 +172,8 @@ def main():
     batch = make_batch(B_PER_GPU, J, S=S, seed=1234 + rank, device=dev, dense_targets=True)
 
     def step():
+        if native:
+            return trainer(batch["img"], batch["label_img"], batch["mask"], batch["uvd"], batch["heatmaps"], batch["depthmaps"])
         model.zero_grad(set_to_none=True)
         res = model(batch["img"], batch["label_img"], batch["mask"])
         loss = train_loss(res, batch)
@@ -216,6 +225,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: NYU 14-joint, 128x128 depth crops, batch 32 per GPU, train (AdamW, %s), "
                                    "features 128, level 4, stage 2, instance norm" % args.precision,
                        "global_batch": world * B_PER_GPU, "backend": args.backend,
+                       "harness": args.harness if args.backend == "hip" else "torch",
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "infer_frames_per_s": world * B_PER_GPU / dt_inf,
             "final_loss": final_loss,

@@ -205,6 +205,21 @@ long long pwr_engine_generation(void* engine);
  * accumulated) into the bound flat gradient buffer, in the layout of the parameters. */
 int pwr_engine_backward(void* engine, const void* const* gouts, int seg, long long n_grad_floats, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Train-step tail (train.py:139-142, 195-208) on the flat fp32 buffers.
+ * ------------------------------------------------------------------------------------------- */
+int pwr_loss_blocks(long long n);
+/* One term of the loss of train.py:197-199: loss[0] (+)= scale * sum (a - t)^2 and, if g != NULL, g = 2*scale*(a - t).
+ * scale carries alpha / lambda and the 1/(B*J) of the batch-joint mean.  partial: pwr_loss_blocks(n) floats. */
+int pwr_loss_sqdiff(const float* a, const float* t, float* g, float scale, float* partial, float* loss, int accumulate, long long n,
+                    void* stream);
+/* torch.optim.AdamW (train.py:140 builds AdamW for --opt adam) / torch.optim.SGD(momentum) steps on flat buffers.
+ * grad_scale multiplies the gradient first (1/world size after an all-reduce SUM). step is 1-based. */
+int pwr_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, void* stream);
+int pwr_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first,
+                 float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

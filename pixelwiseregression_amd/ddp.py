@@ -32,8 +32,12 @@ class DataParallel:
         b, e = self.ranges[seg]
         self.works.append(dist.all_reduce(model.flat_grad()[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self, model):
+    def wait(self):
+        """Block the current stream until every segment's all-reduce (SUM) has finished; the caller scales by 1/world."""
         for w in self.works:
             w.wait()
         self.works = []
+
+    def finish(self, model):
+        self.wait()
         model.flat_grad().mul_(1.0 / self.world)
