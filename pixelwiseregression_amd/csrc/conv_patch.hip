@@ -15,15 +15,9 @@
 
 namespace pwr {
 
-template <int NSLOT>
-__device__ __forceinline__ int patch_off(int pix, int slot) {
-  // byte offset of 16-byte slot `slot` of patch pixel `pix`; swizzled so that the 16-lane groups of ds_read_b128
-  // (32 consecutive pixels, same slot) hit 16 distinct bank slots
-  constexpr int SH = NSLOT >= 16 ? 0 : (NSLOT == 8 ? 1 : 2);
-  constexpr int MASK = (NSLOT >= 16 ? 16 : NSLOT) - 1;
-  return (pix * NSLOT + (slot ^ ((pix >> SH) & MASK))) * 16;
-}
-
+// Patch pixels are padded by one 16-byte slot: with a pitch of NSLOT*16+16 bytes the 16-lane groups of ds_read_b128
+// (32 consecutive pixels, same channel slot) fall on 16 distinct bank slots WITHOUT an XOR swizzle, so every fragment
+// address is (per-lane base) + (compile-time constant): no vector ALU work in the K loop for the A operand.
 template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
@@ -33,7 +27,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   constexpr int BM = TH * TW, BN = WN * NR * 32;
   constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
   constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
-  constexpr int PATCH_BYTES = NPIX * NSLOT * 16;
+  constexpr int PITCH = NSLOT * 16 + 16;         // bytes per patch pixel (padded, see above)
+  constexpr int PATCH_BYTES = NPIX * PITCH;
   constexpr int WBUF_BYTES = BN * 64;
   constexpr int NB = (BN * 4 + NT - 1) / NT;
   constexpr int EROWS = 64, EPITCH = BN + 4;
@@ -128,7 +123,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
             o[e] = Elem<T>::from_f(f);
           }
         }
-        *reinterpret_cast<V*>(patch + patch_off<NSLOT>(pix, slot)) = o;
+        *reinterpret_cast<V*>(patch + pix * PITCH + slot * 16) = o;
       }
     }
   }
@@ -155,7 +150,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 
   const int r = lane & 31, h = lane >> 5;
   constexpr int ITERS = 9 * KCH;
+  const char* aBase[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) aBase[i] = patch + ((wm * MR + i) * PW + r) * PITCH + h * 16;
+  int bOff[NR][2];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    bOff[j][0] = lds_off(wn * NR * 32 + j * 32 + r, h);
+    bOff[j][1] = lds_off(wn * NR * 32 + j * 32 + r, 2 + h);
+  }
+  // fully unrolled over (ky, kx, K chunk): every LDS offset, ring stage and wait count is a compile-time constant
+#pragma unroll
   for (int it = 0; it < ITERS; ++it) {
+    const int tap = it / KCH, kch = it - tap * KCH;
+    const int ky = tap / 3, kx = tap - ky * 3;
     int buf;
     if constexpr (DMA) {
       // stage `it` has landed once all but this wave's newest stage (it+1) are retired; after the barrier every wave's
@@ -174,20 +182,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       buf = it & 1;
       if (it + 1 < ITERS) load_w(it + 1);
     }
-    const int tap = it / KCH, kch = it - tap * KCH;
-    const int ky = tap / 3, kx = tap - ky * 3;
     const char* lB = wbuf + buf * WBUF_BYTES;
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       V a[MR], bb[NR];
 #pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        const int trow = wm * MR + i;                       // tile row of this 32-pixel M sub-tile
-        const int pix = (trow + ky) * PW + (r + kx);
-        a[i] = *reinterpret_cast<const V*>(patch + patch_off<NSLOT>(pix, kch * 4 + 2 * ss + h));
-      }
+      for (int i = 0; i < MR; ++i)
+        a[i] = *reinterpret_cast<const V*>(aBase[i] + (ky * PW + kx) * PITCH + kch * 64 + ss * 32);
 #pragma unroll
-      for (int j = 0; j < NR; ++j) bb[j] = *reinterpret_cast<const V*>(lB + lds_off(wn * NR * 32 + j * 32 + r, 2 * ss + h));
+      for (int j = 0; j < NR; ++j) bb[j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
