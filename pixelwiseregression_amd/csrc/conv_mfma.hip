@@ -41,55 +41,82 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
   const int HoWo = p.Ho * p.Wo;
 
-  // ---- per-thread A rows: (tid>>2) and (tid>>2)+64, slot q = tid&3
+  // ---- per-thread A rows: (tid>>2) and (tid>>2)+64, slot q = tid&3.  Everything that does not depend on the (tap, K chunk)
+  // of an iteration is computed once: the pointer of tap (0,0), a bit mask of the taps that fall inside the image, the
+  // norm-state pointer and the LDS offsets.  Per iteration only wave-uniform offsets are added (scalar ALU).
   const int q = tid & 3;
-  int ab[2], aoy[2], aox[2];
-  bool amv[2];
+  const int taps = p.ksize * p.ksize;
+  const int iters = taps * p.KCH;
+  const T* xrow[2];
+  const float* strow[2];
+  unsigned vmask[2];
+  int aoff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + (tid >> 2) + 64 * i;
-    amv[i] = m < p.M;
-    const int mm = amv[i] ? m : 0;
-    ab[i] = mm / HoWo;
-    const int rem = mm - ab[i] * HoWo;
-    aoy[i] = rem / p.Wo;
-    aox[i] = rem - aoy[i] * p.Wo;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
+    const int b = mm / HoWo;
+    const int rem = mm - b * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int by, bx;
+    unsigned mask = 0;
+    if (p.mode == 0) {
+      by = oy * p.stride - p.pad; bx = ox * p.stride - p.pad;
+      for (int t = 0; t < taps; ++t) {
+        const int ky = t / p.ksize, kx = t - ky * p.ksize;
+        const int iy = by + ky, ix = bx + kx;
+        if (mv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+      }
+    } else {  // gather form of the stride-2 transposed conv: iy = (oy + pad - ky)/2 when even = by - (ky >> 1)
+      by = (oy + p.pad) >> 1; bx = (ox + p.pad) >> 1;
+      for (int t = 0; t < taps; ++t) {
+        const int ky = t / p.ksize, kx = t - ky * p.ksize;
+        const int sy = oy + p.pad - ky, sx = ox + p.pad - kx;
+        const int iy = sy >> 1, ix = sx >> 1;
+        if (mv && !(sy & 1) && !(sx & 1) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+      }
+    }
+    vmask[i] = mask;
+    xrow[i] = x + ((long long)(b * p.H + by) * p.W + bx) * p.Cin + q * EP;
+    strow[i] = p.in_norm ? p.in_norm + (size_t)b * p.Cin + q * EP : nullptr;
+    aoff[i] = lds_off((tid >> 2) + 64 * i, q);
   }
-  const int taps = p.ksize * p.ksize;
-  const int iters = taps * p.KCH;
+  const T* wrow[NB];
+  int boff[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int s = tid + 256 * i;
+    wrow[i] = w + (size_t)(n0 + (s >> 2)) * KE + (s & 3) * EP;
+    boff[i] = BM * 64 + lds_off(s >> 2, s & 3);
+  }
+  const size_t nplane = (size_t)p.B * p.Cin;
+  const long long wstride = (long long)p.CoutPad * KE;      // elements between consecutive (tap, K chunk) weight tiles
 
   V ra[2], rb[NB];
   bool av[2];
-  // norm state of the two A rows for the K chunk in flight, loaded TOGETHER with the data so that the two L2 latencies
-  // overlap (small maps are latency bound: one workgroup walks the whole K loop alone)
   float nmu[2][EP], nsc[2][EP], nbe[2][EP];
-  const size_t nplane = (size_t)p.B * p.Cin;
 
   // (tap, K chunk) of the next tile to load, advanced incrementally: no integer divisions in the K loop
-  int l_tap = 0, l_kch = 0, l_ky = 0, l_kx = 0;
+  int l_it = 0, l_tap = 0, l_kch = 0, l_ky = 0, l_kx = 0;
   auto load_global = [&](int) {
-    const int tap = l_tap, kch = l_kch, ky = l_ky, kx = l_kx;
+    const int tap = l_tap, kch = l_kch;
+    // wave-uniform element offset of this tap relative to tap (0,0)
+    const long long tapoff = p.mode == 0 ? ((long long)l_ky * p.W + l_kx) * p.Cin : -((long long)(l_ky >> 1) * p.W + (l_kx >> 1)) * p.Cin;
+    const long long koff = tapoff + kch * KE;
+    const bool kfull = kch * KE + q * EP < p.Cin;
+    const long long woff = (long long)l_it * wstride;
+    ++l_it;
     if (++l_kch == p.KCH) { l_kch = 0; ++l_tap; if (++l_kx == p.ksize) { l_kx = 0; ++l_ky; } }
-    const int c0 = kch * KE + q * EP;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int iy, ix;
-      bool ok = amv[i] && c0 < p.Cin;
-      if (p.mode == 0) {
-        iy = aoy[i] * p.stride + ky - p.pad;
-        ix = aox[i] * p.stride + kx - p.pad;
-      } else {  // gather form of the stride-2 transposed conv (dgrad of a stride-2 conv)
-        const int sy = aoy[i] + p.pad - ky, sx = aox[i] + p.pad - kx;
-        ok = ok && ((sy & 1) == 0) && ((sx & 1) == 0);
-        iy = sy >> 1; ix = sx >> 1;
-      }
-      ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const bool ok = ((vmask[i] >> tap) & 1u) && kfull;
       av[i] = ok;
       V v = {};
       if (ok) {
-        v = *reinterpret_cast<const V*>(x + ((size_t)(ab[i] * p.H + iy) * p.W + ix) * p.Cin + c0);
+        v = *reinterpret_cast<const V*>(xrow[i] + koff);
         if (p.in_norm) {
-          const float* st = p.in_norm + (size_t)ab[i] * p.Cin + c0;
+          const float* st = strow[i] + kch * KE;
 #pragma unroll
           for (int e = 0; e < EP; ++e) { nmu[i][e] = st[e]; nsc[i][e] = st[2 * nplane + e]; nbe[i][e] = st[3 * nplane + e]; }
         }
@@ -99,15 +126,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int s = tid + 256 * i;
-      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) {
-        const int row = s >> 2, qq = s & 3;
-        rb[i] = *reinterpret_cast<const V*>(w + ((size_t)(tap * p.KCH + kch) * p.CoutPad + n0 + row) * KE + qq * EP);
-      }
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) rb[i] = *reinterpret_cast<const V*>(wrow[i] + woff);
     }
   };
   auto store_lds = [&](int buf) {
-    char* lA = smem + buf * (BM + BN) * 64;
-    char* lB = lA + BM * 64;
+    char* base = smem + buf * (BM + BN) * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       V v = ra[i];
@@ -121,12 +144,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
         }
         v = o;
       }
-      *reinterpret_cast<V*>(lA + lds_off((tid >> 2) + 64 * i, q)) = v;
+      *reinterpret_cast<V*>(base + aoff[i]) = v;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int s = tid + 256 * i;
-      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(lB + lds_off(s >> 2, s & 3)) = rb[i];
+      if (BN * 4 >= 256 * (i + 1) || s < BN * 4) *reinterpret_cast<V*>(base + boff[i]) = rb[i];
     }
   };
 
