@@ -85,7 +85,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 // conv_patch.hip
-bool conv_patch_applicable(const ConvParams& p);
+bool conv_patch_applicable(const ConvParams& p, int dtype);
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s);
 
 }  // namespace pwr

@@ -876,7 +876,7 @@ template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   if (p.CoutPad % bn) return PWR_EINVAL;
-  if (conv_patch_applicable(p)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
+  if (conv_patch_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
   dim3 grid((p.M + 127) / 128, p.CoutPad / bn), block(256);
   if (bn == 128) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, 2, 2, 2>), grid, block, 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, 2, 2, 1>), grid, block, 0, s, p);

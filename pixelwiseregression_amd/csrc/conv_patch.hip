@@ -4,10 +4,14 @@
 //
 // Workgroup = 256 threads, output tile = 4 rows x 32 columns (or 512 threads, 8 x 32) x BN channels.  The (TH+2) x 34 pixel input
 // patch (tile + halo) is loaded ONCE from HBM/L2 -- with the preceding norm + ReLU applied on the way ("NR prologue") --
-// into LDS as [pixel][Cin] with an XOR swizzle of the 16-byte slots, and all nine taps read their shifted windows from
+// into LDS as [pixel][Cin] (pixel pitch padded by 16 B), and all nine taps read their shifted windows from
 // there: 1.6x input traffic instead of the 9x of the universal im2col-on-the-fly kernel, and the NR arithmetic is done
-// 1.6x instead of 9x.  Weights stream through a double-buffered [BN][64 B] LDS tile per (tap, K chunk); they are shared
+// 1.6x instead of 9x.  Weights stream through a 3-stage LDS-DMA ring of [BN][64 B] tiles per (tap, K chunk); they are shared
 // by all workgroups and stay in L2.  MFMA 32x32x16 bf16 (or 32x32x2 fp32 in parity mode), fp32 accumulate.
+//
+// Small square maps (TW = W = H in {2,4,8,16}: the inner hourglass levels) use the same kernel with the 128-pixel tile made
+// of SUB sub-blocks of RH x TW pixels, each with its own halo patch -- whole images (or half of a 16x16 one) of several
+// samples.  There the point is latency, not traffic: one round of global loads instead of one per (tap, K chunk).
 #include <cstdlib>
 
 #include "conv_common.h"
@@ -18,13 +22,16 @@ namespace pwr {
 // Patch pixels are padded by one 16-byte slot: with a pitch of NSLOT*16+16 bytes the 16-lane groups of ds_read_b128
 // (32 consecutive pixels, same channel slot) fall on 16 distinct bank slots WITHOUT an XOR swizzle, so every fragment
 // address is (per-lane base) + (compile-time constant): no vector ALU work in the K loop for the A operand.
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA>
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
   constexpr int NT = WM * WN * 64;                // threads per workgroup (256 or 512)
-  constexpr int TH = WM * MR, TW = 32, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;   // tile = TH rows x 32 columns
-  constexpr int BM = TH * TW, BN = WN * NR * 32;
+  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  constexpr int TH = WM * MR;                     // tile rows of the TW == 32 form
+  constexpr int RH = TW == 32 ? TH : (TW * TW < BM ? TW : BM / TW);   // rows of one sub-block
+  constexpr int SUBPIX = RH * TW, SUB = BM / SUBPIX;                  // 128-pixel tile = SUB sub-blocks of RH x TW pixels
+  constexpr int PH = RH + 2, PW = TW + 2, PP = PH * PW, NPIX = SUB * PP;
   constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
   constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
   constexpr int PITCH = NSLOT * 16 + 16;         // bytes per patch pixel (padded, see above)
@@ -41,12 +48,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;   // requires H % TH == 0
   const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = t / tiles_img, tr = t - b * tiles_img;
-  const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
+  const int HW = p.H * p.W;
+  int b = 0, ty0 = 0, tx0 = 0;
+  if constexpr (TW == 32) {
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;   // requires H % TH == 0
+    b = t / tiles_img;
+    const int tr = t - b * tiles_img;
+    ty0 = (tr / tiles_x) * TH; tx0 = (tr % tiles_x) * TW;
+  }
+  const long long L0 = (long long)t * BM, Mtot = (long long)p.B * HW;   // small maps: tile = BM consecutive NHWC pixels
   const int n0 = blockIdx.y * BN;
-  const T* __restrict__ x = reinterpret_cast<const T*>(p.x) + (size_t)b * p.H * p.W * CIN;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
 
   // ---- weights of iteration 0 in flight while the patch is staged
@@ -86,34 +99,44 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   };
   if constexpr (DMA) { dma_w(0, 0); dma_w(1, 1); } else { load_w(0); }
 
-  // ---- stage the patch: thread -> fixed slot (channels), pixels tid/NSLOT + k*(256/NSLOT)
+  // ---- stage the patch: thread -> fixed sub-block and 16-byte channel slot, pixels pl + k*PL of that sub-block
   {
-    const int slot = tid % NSLOT;
+    constexpr int TPS = NT / SUB, PL = TPS / NSLOT;
+    static_assert(TPS % NSLOT == 0 && PL >= 1, "sub-block needs at least one thread per channel slot");
+    constexpr int NIT = (PP + PL - 1) / PL;
+    const int sub = tid / TPS, pl = (tid % TPS) / NSLOT, slot = tid % NSLOT;
+    int sb = b, sy0 = ty0, sx0 = tx0;
+    bool sv = true;
+    if constexpr (TW != 32) {
+      const long long Ls = L0 + sub * SUBPIX;
+      sv = Ls < Mtot;
+      sb = sv ? (int)(Ls / HW) : 0;
+      sy0 = ((int)(Ls - (long long)sb * HW)) / TW; sx0 = 0;
+    }
+    const T* __restrict__ xs = x + (size_t)sb * HW * CIN;
     float mu[EP], sc[EP], be[EP];
     const bool nr = p.in_norm != nullptr;
     if (nr) {
       const size_t plane = (size_t)p.B * CIN;
-      const float* st = p.in_norm + (size_t)b * CIN + slot * EP;
+      const float* st = p.in_norm + (size_t)sb * CIN + slot * EP;
 #pragma unroll
       for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
     }
-    constexpr int PSTEP = NT / NSLOT;
-    constexpr int NIT = (NPIX + PSTEP - 1) / PSTEP;
     V v[NIT];
     bool ok[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int pix = tid / NSLOT + k * PSTEP;
+      const int pix = pl + k * PL;
       const int py = pix / PW, px = pix - py * PW;
-      const int iy = ty0 + py - 1, ix = tx0 + px - 1;
-      ok[k] = pix < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int iy = sy0 + py - 1, ix = sx0 + px - 1;
+      ok[k] = sv && pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       v[k] = V{};
-      if (ok[k]) v[k] = *reinterpret_cast<const V*>(x + ((size_t)iy * p.W + ix) * CIN + slot * EP);
+      if (ok[k]) v[k] = *reinterpret_cast<const V*>(xs + ((size_t)iy * p.W + ix) * CIN + slot * EP);
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int pix = tid / NSLOT + k * PSTEP;
-      if (pix < NPIX) {
+      const int pix = pl + k * PL;
+      if (pix < PP) {
         V o = v[k];
         if (nr && ok[k]) {
 #pragma unroll
@@ -123,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
             o[e] = Elem<T>::from_f(f);
           }
         }
-        *reinterpret_cast<V*>(patch + pix * PITCH + slot * 16) = o;
+        *reinterpret_cast<V*>(patch + (sub * PP + pix) * PITCH + slot * 16) = o;
       }
     }
   }
@@ -152,7 +175,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   constexpr int ITERS = 9 * KCH;
   const char* aBase[MR];
 #pragma unroll
-  for (int i = 0; i < MR; ++i) aBase[i] = patch + ((wm * MR + i) * PW + r) * PITCH + h * 16;
+  for (int i = 0; i < MR; ++i) {
+    const int R = (wm * MR + i) * 32 + r;          // tile pixel of this lane's fragment row
+    const int fs = R / SUBPIX, rr = R - fs * SUBPIX;
+    aBase[i] = patch + (fs * PP + (rr / TW) * PW + rr % TW) * PITCH + h * 16;
+  }
   int bOff[NR][2];
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
@@ -227,7 +254,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   // ---- epilogue: accumulators -> LDS (fp32, 64 tile pixels at a time) -> coalesced 16-byte stores
   float* E = reinterpret_cast<float*>(smem);
   constexpr int PASSES = BM / EROWS;
-  const int HW = p.H * p.W;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     const int wrow0 = wm * MR * 32;
@@ -251,9 +277,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       for (int c = tid; c < EROWS * CPR; c += NT) {
         const int row = c / CPR, cc = (c - row * CPR) * EP;
         const int ml = ps * EROWS + row, n = n0 + cc;
-        const int oy = ty0 + ml / TW, ox = tx0 + ml % TW;
-        if (n < p.Cout) {
-          const size_t m = (size_t)b * HW + (size_t)oy * p.W + ox;
+        size_t m;
+        bool mvalid = true;
+        if constexpr (TW == 32) m = (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+        else { m = (size_t)(L0 + ml); mvalid = L0 + ml < Mtot; }
+        if (n < p.Cout && mvalid) {
           float v[EP];
 #pragma unroll
           for (int e = 0; e < EP; ++e) v[e] = E[row * EPITCH + cc + e];
@@ -277,11 +305,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       for (int c = tid; c < EROWS * BN; c += NT) {
         const int col = c / EROWS, row = c - col * EROWS;
         const int ml = ps * EROWS + row, n = n0 + col;
-        if (n < p.Cout) {
-          const int oy = ty0 + ml / TW, ox = tx0 + ml % TW;
+        int ob = b, opix;
+        bool mvalid = true;
+        if constexpr (TW == 32) opix = (ty0 + ml / TW) * p.W + tx0 + ml % TW;
+        else { mvalid = L0 + ml < Mtot; ob = (int)((L0 + ml) / HW); opix = (int)(L0 + ml - (long long)ob * HW); }
+        if (n < p.Cout && mvalid) {
           float v = E[row * EPITCH + col];
           if (p.bias) v += p.bias[n];
-          p.y_nchw[((size_t)b * p.Cout + n) * HW + (size_t)oy * p.W + ox] = v;
+          p.y_nchw[((size_t)ob * p.Cout + n) * HW + opix] = v;
         }
       }
     }
@@ -289,9 +320,32 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   }
 }
 
-bool conv_patch_applicable(const ConvParams& p) {
-  return p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.W % 32 == 0 && p.H % 4 == 0 &&
-         (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
+// small square maps of the inner hourglass levels (64 -> 64 channels): whole images per tile
+static bool small_map(const ConvParams& p, int dtype) {
+  static const bool on = [] { const char* e = getenv("PWR_PATCH_SMALL"); return e ? atoi(e) != 0 : true; }();
+  if (!on || p.H != p.W || p.Cin != 64 || pick_bn(p.Cout) != 64) return false;
+  if (p.W == 2) return dtype == PWR_BF16;     // fp32: 16 channel slots > the 8 threads a 2x2 image gets
+  return p.W == 4 || p.W == 8 || p.W == 16;
+}
+
+bool conv_patch_applicable(const ConvParams& p, int dtype) {
+  if (!(p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1)) return false;
+  if (small_map(p, dtype)) return true;
+  return p.W % 32 == 0 && p.H % 4 == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
+}
+
+template <typename T>
+static int launch_patch_small(const ConvParams& p, hipStream_t s) {
+  constexpr bool dma = sizeof(T) == 2;
+  dim3 grid((unsigned)(((long long)p.B * p.H * p.W + 127) / 128), p.CoutPad / 64), block(256);
+  if (p.W == 16) hipLaunchKernelGGL((conv3x3_patch_kernel<T, 64, 2, 2, 2, 1, dma, 16>), grid, block, 0, s, p);
+  else if (p.W == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<T, 64, 2, 2, 2, 1, dma, 8>), grid, block, 0, s, p);
+  else if (p.W == 4) hipLaunchKernelGGL((conv3x3_patch_kernel<T, 64, 2, 2, 2, 1, dma, 4>), grid, block, 0, s, p);
+  else {
+    if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv3x3_patch_kernel<T, 64, 2, 2, 2, 1, dma, 2>), grid, block, 0, s, p);
+    else return (int)hipErrorInvalidValue;
+  }
+  return (int)hipGetLastError();
 }
 
 template <typename T, int CIN>
@@ -329,6 +383,7 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
 }
 
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
+  if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);
   return dtype == PWR_BF16 ? launch_patch_t<bf16_t>(p, s) : launch_patch_t<float>(p, s);
 }
 

@@ -70,6 +70,15 @@ CONV_CASES = [
     (1, 128, 128, 64, 128, 3, 1),
     (2, 4, 32, 128, 128, 3, 1),
     (1, 8, 96, 32, 16, 3, 1),
+    # small square maps (whole images per tile): ragged last tile, several tiles, 2 N tiles
+    (3, 2, 2, 64, 64, 3, 1),
+    (40, 2, 2, 64, 64, 3, 1),
+    (3, 4, 4, 64, 64, 3, 1),
+    (9, 4, 4, 64, 48, 3, 1),
+    (1, 8, 8, 64, 64, 3, 1),
+    (5, 8, 8, 64, 64, 3, 1),
+    (1, 16, 16, 64, 64, 3, 1),
+    (3, 16, 16, 64, 40, 3, 1),
 ]
 
 
