@@ -148,6 +148,26 @@ int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* 
 int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ResBlock (model.py:6-23: norm, ReLU, conv1x1 C->C/2, norm, ReLU, conv3x3, norm, ReLU, conv1x1 C/2->C, + x) on the small
+ * square maps of the inner hourglass levels as ONE launch per direction: one workgroup owns one sample, activations stay in
+ * LDS between the three GEMMs.  bf16, InstanceNorm, C == 128, H == W in {2,4,8,16} (pwr_resblock_small_supported).
+ * Forward writes what the unfused sequence (pwr_norm_stats + pwr_conv_fwd, three times) writes: the pre-norm conv outputs
+ * t1, t2 [B,H,W,C/2] (NULL to skip), the three [4][B][C] norm states and out [B,H,W,C].  wa/wb/wc: kind-0 weight packs.
+ * Backward takes g_out = dL/d out and writes dt2, dt1 (the dy operands of the weight gradients of conv b / conv a), dx
+ * (skip connection included) and the per-sample norm sums [B][2][C] for pwr_norm_param_grad; w*_d: kind-1 packs.
+ * ------------------------------------------------------------------------------------------- */
+int pwr_resblock_small_supported(int H, int W, int C, int norm_mode, int dtype);
+int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* out, const void* wa, const void* wb, const void* wc,
+                           const float* bias_a, const float* bias_b, const float* bias_c, const float* gamma_a,
+                           const float* beta_a, const float* gamma_b, const float* beta_b, const float* gamma_c,
+                           const float* beta_c, float* state_a, float* state_b, float* state_c, int B, int H, int W, int C,
+                           float eps, int dtype, void* stream);
+int pwr_resblock_bwd_small(const void* gout, const void* x, const void* t1, const void* t2, void* dx, void* dt1, void* dt2,
+                           const void* wc_d, const void* wb_d, const void* wa_d, const float* state_a, const float* state_b,
+                           const float* state_c, float* sums_a, float* sums_b, float* sums_c, int B, int H, int W, int C,
+                           int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Hourglass plumbing (model.py:40, :45-47), NHWC.
  * ------------------------------------------------------------------------------------------- */
 int pwr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);

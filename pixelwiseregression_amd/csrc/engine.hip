@@ -41,20 +41,29 @@ struct Ctx {
   int training = 1;
   // second stream for the parameter-gradient kernels (wgrad + reduce + bias sums): they only feed the flat gradient
   // buffer, so they run beside the data-gradient / norm-backward chain instead of inside it
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Several side streams, used round-robin, each with its own split-K slab: most of these kernels are small and latency-bound,
+  // so independent layers' weight gradients overlap each other as well as the main chain.
+  static constexpr int kMaxSide = 4;
+  hipStream_t side[kMaxSide] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
+  int n_side = 0, side_rr = 0;
+  size_t slab_off = 0, slab_stride = 0;   // byte offset of the current stream's slab inside the slab scratch
   bool use_side = true;
 };
 
 // run `op` on the side stream, ordered after everything enqueued so far on the main stream
 static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
-  if (!c.use_side || !c.side) return op(c);
+  if (!c.use_side || c.n_side == 0) return op(c);
+  const int k = c.side_rr;
+  c.side_rr = (k + 1) % c.n_side;
   hipEventRecord(c.ev_fork, (hipStream_t)c.stream);
-  hipStreamWaitEvent(c.side, c.ev_fork, 0);
+  hipStreamWaitEvent(c.side[k], c.ev_fork, 0);
   void* main_stream = c.stream;
-  c.stream = c.side;
+  c.stream = c.side[k];
+  c.slab_off = (size_t)k * c.slab_stride;
   const int rc = op(c);
   c.stream = main_stream;
+  c.slab_off = 0;
   return rc;
 }
 
@@ -267,11 +276,11 @@ struct Engine {
     bwd_cur.push_back([=](Ctx& c) {
       return run_on_side(c, [=](Ctx& c2) {
         int rc = pwr_conv_wgrad(c2.arena + x.off, c2.arena + y.goff, has_nr ? (float*)(c2.arena + n.state) : nullptr,
-                                1, (float*)(c2.arena + E->scr_slab), c2.grads + cv.w, 0,
+                                1, (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + cv.w, 0,
                                 Bc, x.H, x.W, cv.Cin, cv.cin_real, cv.Cout, cv.Cout, cv.k, cv.stride, splits, dt, c2.stream);
         if (rc) return rc;
         if (bias_grad || (E->norm_mode == 1 && !c2.training))
-          rc = pwr_colsum_nhwc(c2.arena + y.goff, (float*)(c2.arena + E->scr_slab), c2.grads + cv.b, (long long)M, cv.Cout, 0, dt, c2.stream);
+          rc = pwr_colsum_nhwc(c2.arena + y.goff, (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + cv.b, (long long)M, cv.Cout, 0, dt, c2.stream);
         return rc;
       });
     });
@@ -300,6 +309,7 @@ struct Engine {
     r.cb = conv_params(Fh, Fh, 3, 1, true, true);
     r.nc = norm_params(Fh);
     r.cc = conv_params(Fh, x.C, 1, 1, true, true);
+    if (pwr_resblock_small_supported(x.H, x.W, x.C, norm_mode, dtype)) return resblock_fused(x, r);
     norm_fwd(x, r.na);
     r.t1 = conv_fwd(x, &r.na, r.ca, nullptr, tr);
     norm_fwd(r.t1, r.nb);
@@ -316,6 +326,48 @@ struct Engine {
       norm_bwd(r.t1, r.nb, 0, false);
       conv_bwd(x, &r.na, r.ca, r.t1, false, true, false);
       norm_bwd(x, r.na, out.goff, true);  // x.g = out.g (skip) + NRbwd(g)
+      append_block(blk);
+    }
+    return out;
+  }
+  // Small square maps (inner hourglass levels, bf16 + InstanceNorm): the whole block is one launch per direction
+  // (csrc/resblock_small.hip).  It writes the same tensors / states as the unfused sequence, so the weight gradients
+  // (side stream) are the usual kernels.
+  Tn resblock_fused(const Tn& x, ResB r) {
+    const bool tr = training;
+    const int Bc = B, dt = dtype, Fh = x.C / 2;
+    if (tr) { r.t1 = tensor(x.H, x.W, Fh, true); r.t2 = tensor(x.H, x.W, Fh, true); }
+    Tn out = tensor(x.H, x.W, x.C, tr);
+    const ResB rb = r;
+    fwd.push_back([=](Ctx& c) {
+      return pwr_resblock_fwd_small(c.arena + x.off, tr ? c.arena + rb.t1.off : nullptr, tr ? c.arena + rb.t2.off : nullptr, c.arena + out.off,
+                                    c.packs + rb.ca.pack_f, c.packs + rb.cb.pack_f, c.packs + rb.cc.pack_f, c.params + rb.ca.b,
+                                    c.params + rb.cb.b, c.params + rb.cc.b, c.params + rb.na.gamma, c.params + rb.na.beta,
+                                    c.params + rb.nb.gamma, c.params + rb.nb.beta, c.params + rb.nc.gamma, c.params + rb.nc.beta,
+                                    (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state), (float*)(c.arena + rb.nc.state),
+                                    Bc, x.H, x.W, x.C, 1e-5f, dt, c.stream);
+    });
+    if (tr) {
+      std::vector<Op> blk;
+      std::swap(blk, bwd_cur);
+      conv_bwd(r.t2, &r.nc, r.cc, out, true, false, false);     // side stream: dW_c, db_c (need only out.g)
+      bwd_cur.push_back([=](Ctx& c) {
+        return pwr_resblock_bwd_small(c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
+                                      c.arena + rb.t1.goff, c.arena + rb.t2.goff, c.packs + rb.cc.pack_d, c.packs + rb.cb.pack_d,
+                                      c.packs + rb.ca.pack_d, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
+                                      (float*)(c.arena + rb.nc.state), (float*)(c.arena + rb.na.sums), (float*)(c.arena + rb.nb.sums),
+                                      (float*)(c.arena + rb.nc.sums), Bc, x.H, x.W, x.C, dt, c.stream);
+      });
+      conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, false, false);   // side stream: dW_b from t2.g
+      conv_bwd(x, &r.na, r.ca, r.t1, false, false, false);      // side stream: dW_a from t1.g
+      bwd_cur.push_back([=](Ctx& c) {
+        return run_on_side(c, [=](Ctx& c2) {
+          int rc = pwr_norm_param_grad((float*)(c2.arena + rb.na.sums), c2.grads + rb.na.gamma, c2.grads + rb.na.beta, Bc, rb.na.C, 0, c2.stream);
+          if (!rc) rc = pwr_norm_param_grad((float*)(c2.arena + rb.nb.sums), c2.grads + rb.nb.gamma, c2.grads + rb.nb.beta, Bc, rb.nb.C, 0, c2.stream);
+          if (!rc) rc = pwr_norm_param_grad((float*)(c2.arena + rb.nc.sums), c2.grads + rb.nc.gamma, c2.grads + rb.nc.beta, Bc, rb.nc.C, 0, c2.stream);
+          return rc;
+        });
+      });
       append_block(blk);
     }
     return out;
@@ -398,7 +450,7 @@ struct Engine {
       if (rc) return rc;
       rc = run_on_side(c, [=](Ctx& c2) {
         return pwr_conv_wgrad(c2.arena + h3.off, c2.arena + gT, (float*)(c2.arena + n2.state), 1,
-                              (float*)(c2.arena + E->scr_slab), c2.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c2.stream);
+                              (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c2.stream);
       });
       if (rc) return rc;
       return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
@@ -459,7 +511,7 @@ struct Engine {
       const Tn y0 = sy[0]; const ConvL c0 = sc[0];
       bwd_cur.push_back([=](Ctx& c) {
         return run_on_side(c, [=](Ctx& c2) {
-          return pwr_stem_conv_wgrad(c2.img, c2.arena + y0.goff, (float*)(c2.arena + E->scr_slab), c2.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c2.stream);
+          return pwr_stem_conv_wgrad(c2.img, c2.arena + y0.goff, (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c2.stream);
         });
       });
       std::swap(stem_bwd, bwd_cur);
@@ -561,7 +613,9 @@ struct Engine {
     // shared scratch
     scr_partial = alloc(need_partial);
     scr_S1 = alloc(need_sc); scr_S2 = alloc(need_sc);
-    scr_slab = alloc(scr_slab_bytes);
+    scr_slab_bytes = (scr_slab_bytes + 255) / 256 * 256;
+    scr_slab = alloc(scr_slab_bytes * Ctx::kMaxSide);
+    ctx.slab_stride = scr_slab_bytes;
     // segments in execution order: last stage first, stem last
     if (tr) {
       for (int s = stages - 1; s >= 0; --s) bwd.push_back(stage_bwd[s]);
@@ -599,10 +653,11 @@ extern "C" void* pwr_engine_create(const int* cfg, int B, int dtype, int trainin
 
 extern "C" void pwr_engine_destroy(void* h) {
   Engine* e = (Engine*)h;
-  if (e->ctx.side) {
-    hipStreamSynchronize(e->ctx.side);
-    hipEventDestroy(e->ctx.ev_fork); hipEventDestroy(e->ctx.ev_join); hipStreamDestroy(e->ctx.side);
+  for (int k = 0; k < e->ctx.n_side; ++k) {
+    hipStreamSynchronize(e->ctx.side[k]);
+    hipEventDestroy(e->ctx.ev_join[k]); hipStreamDestroy(e->ctx.side[k]);
   }
+  if (e->ctx.ev_fork) hipEventDestroy(e->ctx.ev_fork);
   delete e;
 }
 extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
@@ -666,16 +721,18 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
   for (int s = 0; s < e->stages; ++s) {
     c.g_p[s] = (const float*)gouts[3 * s]; c.g_D[s] = (const float*)gouts[3 * s + 1]; c.g_uvd[s] = (const float*)gouts[3 * s + 2];
   }
-  if (c.use_side && !c.side) {
-    const char* env = getenv("PWR_SIDE_STREAM");
-    c.use_side = env ? atoi(env) != 0 : true;
-    if (c.use_side) {
-      if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) {
-        c.use_side = false; c.side = nullptr;
-      }
+  if (c.use_side && c.n_side == 0) {
+    const char* env = getenv("PWR_SIDE_STREAM");   // number of side streams, 0 = everything on the caller's stream
+    int want = env ? atoi(env) : 2;
+    if (want > Ctx::kMaxSide) want = Ctx::kMaxSide;
+    c.use_side = want > 0;
+    if (c.use_side && hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess) c.use_side = false;
+    for (int k = 0; c.use_side && k < want; ++k) {
+      if (hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming) != hipSuccess) break;
+      c.n_side = k + 1;
     }
+    if (c.n_side == 0) c.use_side = false;
   }
   if (seg == 0) {
     hipError_t er = hipMemsetAsync(c.grads, 0, (size_t)n_grad_floats * 4, (hipStream_t)stream);
@@ -687,9 +744,9 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
     rc = ops[i](c);
     if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
   }
-  if (c.use_side && c.side) {   // join: the segment's parameter gradients are complete before anything later on `stream`
-    hipEventRecord(c.ev_join, c.side);
-    hipStreamWaitEvent((hipStream_t)stream, c.ev_join, 0);
+  for (int k = 0; c.use_side && k < c.n_side; ++k) {   // join: the segment's parameter gradients are complete before anything later on `stream`
+    hipEventRecord(c.ev_join[k], c.side[k]);
+    hipStreamWaitEvent((hipStream_t)stream, c.ev_join[k], 0);
   }
   return rc;
 }

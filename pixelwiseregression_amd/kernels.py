@@ -272,3 +272,37 @@ def norm_bwd_split(g, y, state, relu=True, addend=None):
                "pwr_norm_bwd_main")
     _lib.check(l.pwr_norm_bwd_params(_p(partial), _p(dgamma), _p(dbeta), 0, B, H * W, C, _s(y)), "pwr_norm_bwd_params")
     return dy, dgamma, dbeta
+
+
+def resblock_small_supported(H, W, C, norm_mode, dtype):
+    return bool(_lib.lib().pwr_resblock_small_supported(H, W, C, norm_mode, dtype))
+
+
+def resblock_fwd_small(x, packs, biases, gammas, betas, eps=1e-5):
+    """One-launch ResBlock forward on a small map.  packs/biases/gammas/betas: 3-tuples for (a, b, c) = (1x1 C->C/2, 3x3, 1x1
+    C/2->C); packs of kind 0.  Returns out, t1, t2, (state_a, state_b, state_c)."""
+    l = _lib.lib()
+    B, H, W, C = x.shape
+    dev = x.device
+    t1 = torch.empty(B, H, W, C // 2, dtype=x.dtype, device=dev)
+    t2 = torch.empty_like(t1)
+    out = torch.empty_like(x)
+    st = [torch.empty(4, B, c, dtype=torch.float32, device=dev) for c in (C, C // 2, C // 2)]
+    _lib.check(l.pwr_resblock_fwd_small(_p(x), _p(t1), _p(t2), _p(out), _p(packs[0]), _p(packs[1]), _p(packs[2]),
+                                        _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(gammas[0]), _p(betas[0]), _p(gammas[1]),
+                                        _p(betas[1]), _p(gammas[2]), _p(betas[2]), _p(st[0]), _p(st[1]), _p(st[2]), B, H, W, C, eps,
+                                        _dt(x), _s(x)), "pwr_resblock_fwd_small")
+    return out, t1, t2, st
+
+
+def resblock_bwd_small(gout, x, t1, t2, packs_d, states):
+    """One-launch ResBlock backward.  packs_d: kind-1 packs of (a, b, c).  Returns dx, dt1, dt2, (sums_a, sums_b, sums_c)."""
+    l = _lib.lib()
+    B, H, W, C = x.shape
+    dev = x.device
+    dx, dt1, dt2 = torch.empty_like(x), torch.empty_like(t1), torch.empty_like(t2)
+    sums = [torch.empty(B, 2, c, dtype=torch.float32, device=dev) for c in (C, C // 2, C // 2)]
+    _lib.check(l.pwr_resblock_bwd_small(_p(gout), _p(x), _p(t1), _p(t2), _p(dx), _p(dt1), _p(dt2), _p(packs_d[2]), _p(packs_d[1]),
+                                        _p(packs_d[0]), _p(states[0]), _p(states[1]), _p(states[2]), _p(sums[0]), _p(sums[1]),
+                                        _p(sums[2]), B, H, W, C, _dt(x), _s(x)), "pwr_resblock_bwd_small")
+    return dx, dt1, dt2, sums

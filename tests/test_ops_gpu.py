@@ -399,3 +399,69 @@ def test_norm_fused_handoff_stress():
         i = it & 1
         st = run(xs[i])
         assert torch.equal(st, refs[i]), "iteration %d: hand-off returned different statistics" % it
+
+
+# ---------------------------------------------------------------- fused small-map ResBlock (model.py:6-23)
+@pytest.mark.parametrize("B,H", [(3, 2), (2, 4), (5, 8), (2, 16), (33, 4)])
+def test_resblock_small_fused_vs_unfused(B, H):
+    """One-launch ResBlock == the unfused kernel sequence (same rounding points), forward and backward, and both close to a
+    float64 torch ResBlock evaluated on the bf16-rounded parameters."""
+    from pixelwiseregression_amd import kernels as K
+    C, Fh, dt = 128, 64, torch.bfloat16
+    assert K.resblock_small_supported(H, H, C, 0, K.BF16)
+    x = rnd(B, C, H, H, seed=1)
+    ws = [rnd(Fh, C, 1, 1, seed=2, scale=C ** -0.5), rnd(Fh, Fh, 3, 3, seed=3, scale=(9 * Fh) ** -0.5), rnd(C, Fh, 1, 1, seed=4, scale=Fh ** -0.5)]
+    bs = [rnd(Fh, seed=5, scale=0.1), rnd(Fh, seed=6, scale=0.1), rnd(C, seed=7, scale=0.1)]
+    gs = [1 + 0.2 * rnd(C, seed=8), 1 + 0.2 * rnd(Fh, seed=9), 1 + 0.2 * rnd(Fh, seed=10)]
+    bes = [0.2 * rnd(C, seed=11), 0.2 * rnd(Fh, seed=12), 0.2 * rnd(Fh, seed=13)]
+    gout = rnd(B, C, H, H, seed=14)
+    dev = lambda t: t.float().to(DEV)
+    xd, gd_ = nhwc(x, dt), nhwc(gout, dt)
+    wf = [K.pack_conv(dev(w), 0, K.BF16) for w in ws]
+    wd = [K.pack_conv(dev(w), 1, K.BF16) for w in ws]
+    bd, gmd, bed = [dev(t) for t in bs], [dev(t) for t in gs], [dev(t) for t in bes]
+
+    # ---- unfused sequence
+    sa = K.norm_stats(xd, gmd[0], bed[0])
+    t1, _ = K.conv_fwd(xd, wf[0], Fh, 1, 1, bias=bd[0], norm=sa)
+    sb = K.norm_stats(t1, gmd[1], bed[1])
+    t2, _ = K.conv_fwd(t1, wf[1], Fh, 3, 1, bias=bd[1], norm=sb)
+    sc = K.norm_stats(t2, gmd[2], bed[2])
+    out, _ = K.conv_fwd(t2, wf[2], C, 1, 1, bias=bd[2], norm=sc, residual=xd)
+    g2, _ = K.conv_fwd(gd_, wd[2], Fh, 1, 1)
+    dt2, dgc, dbc = K.norm_bwd(g2, t2, sc)
+    g1, _ = K.conv_fwd(dt2, wd[1], Fh, 3, 1)
+    dt1, dgb, dbb = K.norm_bwd(g1, t1, sb)
+    g0, _ = K.conv_fwd(dt1, wd[0], C, 1, 1)
+    dx, dga, dba = K.norm_bwd(g0, xd, sa, addend=gd_)
+
+    # ---- fused
+    fout, ft1, ft2, fst = K.resblock_fwd_small(xd, wf, bd, gmd, bed)
+    # (backward on the UNFUSED forward's tensors and states: identical ReLU masks, so only summation order differs)
+    fdx, fdt1, fdt2, fsums = K.resblock_bwd_small(gd_, xd, t1, t2, wd, [sa, sb, sc])
+    torch.cuda.synchronize()
+
+    def close(a, b, rel, what):
+        assert_close(a.double().cpu(), b.double().cpu(), rel, what)
+    # same rounding points: differences are single bf16 ulps where an fp32 sum order tipped a rounding
+    for a, b, what in ((fst[0], sa, "state a"), (fst[1], sb, "state b"), (fst[2], sc, "state c")):
+        close(a, b, 2e-2, what)
+    close(ft1, t1, 1e-2, "t1"); close(ft2, t2, 2e-2, "t2"); close(fout, out, 2e-2, "out")
+    close(fdt2, dt2, 3e-2, "dt2"); close(fdt1, dt1, 3e-2, "dt1"); close(fdx, dx, 3e-2, "dx")
+    for s_, dg, db, what in ((fsums[0], dga, dba, "a"), (fsums[1], dgb, dbb, "b"), (fsums[2], dgc, dbc, "c")):
+        close(s_[:, 1].sum(0), dg, 3e-2, "dgamma " + what)
+        close(s_[:, 0].sum(0), db, 3e-2, "dbeta " + what)
+
+    # ---- float64 torch ResBlock on the bf16-rounded operands
+    xq = q(x, dt).requires_grad_(True)
+    wq = [q(w, dt) for w in ws]
+    h = F.conv2d(torch.relu(F.instance_norm(xq, weight=gs[0].float().double(), bias=bes[0].float().double(), eps=1e-5)), wq[0], bs[0].float().double())
+    h = F.conv2d(torch.relu(F.instance_norm(h, weight=gs[1].float().double(), bias=bes[1].float().double(), eps=1e-5)), wq[1], bs[1].float().double(), padding=1)
+    h = F.conv2d(torch.relu(F.instance_norm(h, weight=gs[2].float().double(), bias=bes[2].float().double(), eps=1e-5)), wq[2], bs[2].float().double())
+    ref = xq + h
+    ref.backward(q(gout, dt))
+    assert_close(nchw(fout), ref.detach(), 3e-2, "fused out vs float64")
+    if H > 2:   # (4-pixel instance norm is too ill-conditioned for a bf16 gradient comparison)
+        # bf16 roundings of t1 / t2 flip ReLUs of near-zero pre-activations: an L2 criterion, not a max-norm one
+        rel_l2 = ((nchw(fdx) - xq.grad).norm() / xq.grad.norm()).item()
+        assert rel_l2 < 5e-2, "fused dx vs float64: rel L2 %.3e" % rel_l2
