@@ -46,7 +46,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   // norm-state pointer and the LDS offsets.  Per iteration only wave-uniform offsets are added (scalar ALU).
   const int q = tid & 3;
   const int taps = p.ksize * p.ksize;
-  const int iters = taps * p.KCH;
+  // GEMM row -> (sample, output pixel).  mode 0: NHWC order.  mode 1 (data gradient of a stride-2 conv): rows are ordered by
+  // the parity class (oy & 1, ox & 1) of the output pixel first, so that a 128-row tile holds one class and only needs the
+  // taps that class can reach (1, 2, 2 or 4 of the 9) -- the other iterations are skipped below, 4x less work.
+  const int Mq = p.M >> 2, HWi = p.H * p.W;
+  auto row_pixel = [&](int m, int& b, int& oy, int& ox) {
+    if (p.mode == 0) {
+      b = m / HoWo;
+      const int rem = m - b * HoWo;
+      oy = rem / p.Wo; ox = rem - oy * p.Wo;
+    } else {
+      const int cls = m / Mq, idx = m - cls * Mq;
+      b = idx / HWi;
+      const int rem = idx - b * HWi;
+      const int yq = rem / p.W;
+      oy = 2 * yq + (cls >> 1); ox = 2 * (rem - yq * p.W) + (cls & 1);
+    }
+  };
   const T* xrow[2];
   const float* strow[2];
   unsigned vmask[2];
@@ -56,9 +72,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     const int m = m0 + (tid >> 2) + 64 * i;
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
-    const int b = mm / HoWo;
-    const int rem = mm - b * HoWo;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int b, oy, ox;
+    row_pixel(mm, b, oy, ox);
     int by, bx;
     unsigned mask = 0;
     if (p.mode == 0) {
@@ -90,6 +105,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     wrow[i] = w + (size_t)(n0 + (s >> 2)) * KE + (s & 3) * EP;
     boff[i] = BM * 64 + lds_off(s >> 2, s & 3);
   }
+  // taps that at least one row of this tile can reach (block-uniform): the K loop runs over those only
+  __shared__ unsigned s_tapmask;
+  if (tid == 0) s_tapmask = 0;
+  __syncthreads();
+  if (vmask[0] | vmask[1]) atomicOr(&s_tapmask, vmask[0] | vmask[1]);
+  __syncthreads();
+  const unsigned tapmask = s_tapmask;
+  const int iters = __popc(tapmask) * p.KCH;
   const size_t nplane = (size_t)p.B * p.Cin;
   const long long wstride = (long long)p.CoutPad * KE;      // elements between consecutive (tap, K chunk) weight tiles
 
@@ -98,16 +121,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   float nmu[2][EP], nsc[2][EP], nbe[2][EP];
 
   // (tap, K chunk) of the next tile to load, advanced incrementally: no integer divisions in the K loop
-  int l_it = 0, l_tap = 0, l_kch = 0, l_ky = 0, l_kx = 0;
+  unsigned l_rem = tapmask;
+  int l_kch = 0;
   auto load_global = [&](int) {
-    const int tap = l_tap, kch = l_kch;
+    const int tap = __ffs(l_rem) - 1, kch = l_kch;
+    const int l_ky = p.ksize == 3 ? (tap * 11) >> 5 : 0, l_kx = tap - l_ky * p.ksize;
     // wave-uniform element offset of this tap relative to tap (0,0)
     const long long tapoff = p.mode == 0 ? ((long long)l_ky * p.W + l_kx) * p.Cin : -((long long)(l_ky >> 1) * p.W + (l_kx >> 1)) * p.Cin;
     const long long koff = tapoff + kch * KE;
     const bool kfull = kch * KE + q * EP < p.Cin;
-    const long long woff = (long long)l_it * wstride;
-    ++l_it;
-    if (++l_kch == p.KCH) { l_kch = 0; ++l_tap; if (++l_kx == p.ksize) { l_kx = 0; ++l_ky; } }
+    const long long woff = (long long)(tap * p.KCH + kch) * wstride;
+    if (++l_kch == p.KCH) { l_kch = 0; l_rem &= l_rem - 1; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = ((vmask[i] >> tap) & 1u) && kfull;
@@ -173,8 +197,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
   }
-  load_global(0);
-  store_lds(0);
+  if (iters > 0) { load_global(0); store_lds(0); }
   __syncthreads();
   for (int it = 0; it < iters; ++it) {
     const int buf = it & 1;
@@ -225,8 +248,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       constexpr int CPR = BN / EP;               // 16-byte chunks per row
       for (int c = tid; c < EROWS * CPR; c += 256) {
         const int row = c / CPR, cc = (c - row * CPR) * EP;
-        const int m = m0 + ps * EROWS + row, n = n0 + cc;
-        if (m < p.M && n < p.Cout) {
+        const int mg = m0 + ps * EROWS + row, n = n0 + cc;
+        if (mg < p.M && n < p.Cout) {
+          int m = mg;
+          if (p.mode != 0) { int b_, oy_, ox_; row_pixel(mg, b_, oy_, ox_); m = (b_ * p.Ho + oy_) * p.Wo + ox_; }
           float v[EP];
 #pragma unroll
           for (int e = 0; e < EP; ++e) v[e] = E[row * EPITCH + cc + e];
@@ -249,10 +274,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     if (p.y_nchw) {
       for (int c = tid; c < EROWS * BN; c += 256) {
         const int col = c / EROWS, row = c - col * EROWS;
-        const int m = m0 + ps * EROWS + row, n = n0 + col;
-        if (m < p.M && n < p.Cout) {
+        const int mg = m0 + ps * EROWS + row, n = n0 + col;
+        if (mg < p.M && n < p.Cout) {
           float v = E[row * EPITCH + col];
           if (p.bias) v += p.bias[n];
+          int m = mg;
+          if (p.mode != 0) { int b_, oy_, ox_; row_pixel(mg, b_, oy_, ox_); m = (b_ * p.Ho + oy_) * p.Wo + ox_; }
           const int b = m / HoWo, pix = m - b * HoWo;
           p.y_nchw[((size_t)b * p.Cout + n) * HoWo + pix] = v;
         }

@@ -134,9 +134,12 @@ def test_conv_dgrad_stride1(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv_dgrad_stride2(dtype):
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 32, 64, 128), (1, 6, 16, 32), (3, 20, 128, 128), (2, 64, 128, 128)])
+def test_conv_dgrad_stride2(dtype, B, H, Cin, Cout):
+    """rows are processed in parity-class order (tiles of one class skip the taps it cannot reach); the small cases have
+    tiles that straddle classes and samples."""
     from pixelwiseregression_amd import kernels as K
-    B, H, Cin, Cout, k = 2, 32, 64, 128, 3
+    k = 3
     w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
     dy = rnd(B, Cout, H // 2, H // 2, seed=7)
     x = torch.zeros(B, Cin, H, H, dtype=torch.float64, requires_grad=True)
