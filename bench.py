@@ -120,8 +120,8 @@ def cpu_baseline(Bc=8, iters=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="hip", choices=["hip", "aten"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

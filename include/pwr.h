@@ -90,6 +90,18 @@ int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const floa
                  const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                  int mode, int dtype, void* stream);
 
+/* pwr_conv_fwd that also writes per-channel column statistics of its output from the epilogue, so that the norm which
+ * follows the conv in model.py (forward: st_partial), or the norm backward that consumes a data gradient (nb_partial: the
+ * launch computes g = dL/d relu(norm(nb_y)); nb_state is that norm's [4][B][Cout] state), needs no reduction pass of its own.
+ * Exactly one of st_partial ([B * chunks][3][Cout] fp32: shifted sum, shifted sum of squares, the tile's shift) /
+ * nb_partial ([B * chunks][2][Cout]); chunks = pwr_conv_stats_chunks(...) > 0 (0: shape not supported -- use pwr_conv_fwd and
+ * pwr_norm_stats / pwr_norm_bwd). */
+int pwr_conv_stats_chunks(int H, int W, int Cin, int Cout, int ksize, int stride, int mode, int dtype);
+int pwr_conv_fwd_stats(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
+                       const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int mode,
+                       float* st_partial, const void* nb_y, const float* nb_state, float* nb_partial, int nb_relu, int dtype,
+                       void* stream);
+
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 
 /* dw[cout_real][cin_real][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
@@ -129,6 +141,14 @@ size_t pwr_norm_partial_bytes(int B, int HW, int C);
 int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
                    float* partial, float* state, int B, int HW, int C, int mode, float eps, float momentum, int dtype,
                    void* stream);
+/* state from the per-tile sums of pwr_conv_fwd_stats (st_partial); mode 0 / 1. */
+int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float* state, int B, int HW, int C, int mode, float eps,
+                              float momentum, void* stream);
+/* pwr_norm_bwd given the reductions of pwr_conv_fwd_stats (nb_partial). */
+int pwr_norm_bwd_from_partial(const void* g, const void* y, const float* state, const float* partial, int chunks, float* S1, float* S2,
+                              const void* addend, void* dy, float* dgamma, float* dbeta, int accumulate, int relu, int B, int HW,
+                              int C, int mode, int dtype, void* stream);
 /* dy = d/dy relu(norm(y)) applied to g (+ addend); dgamma/dbeta [C] (+)=.  S1,S2: [B,C] scratch. */
 int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);

@@ -14,6 +14,18 @@ struct ConvParams {
   float* y_nchw;          // [B,Cout,Ho,Wo] fp32 or null
   int B, H, W, Cin, Ho, Wo, Cout, CoutPad;
   int ksize, stride, pad, mode, relu_in, KCH, M;
+  // ---- optional per-channel column statistics of the OUTPUT tile, written by the epilogue (one slab entry per workgroup;
+  // a workgroup's 128 output pixels lie in one sample).  nb_partial: [(b*chunks + chunk)*2 + {0,1}][Cout] fp32.
+  // st_partial: [(b*chunks + chunk)*3 + {0,1,2}][Cout] = sum (v - k), sum (v - k)^2, k of the stored output v, with the shift
+  //             k[c] = the tile's first output row (so the sums never cancel): the statistics of the norm that FOLLOWS this
+  //             conv (replaces norm_partial_kernel; combined over chunks by norm_finalize_chunks_kernel).
+  // nb_partial: this launch is a data gradient producing g = dL/d relu(norm(y)); sums of gm and gm * xhat for the norm
+  //             backward of y (nb_y, nb_state = [4][B][Cout]): replaces norm_bwd_partial_kernel.
+  float* st_partial = nullptr;
+  const void* nb_y = nullptr;
+  const float* nb_state = nullptr;
+  float* nb_partial = nullptr;
+  int nb_relu = 1;
 };
 
 struct WgradParams {
@@ -75,6 +87,83 @@ __device__ __forceinline__ typename Vec16<T>::type nr_transform(typename Vec16<T
   return o;
 }
 
+// Column statistics of a conv epilogue (see ConvParams::st_partial / nb_partial).  Every thread of the epilogue's copy loop
+// owns one 16-byte channel slot (EP channels) for all of its rows: add() per stored vector, finish() once per workgroup.
+template <typename T>
+struct EpiStats {
+  static constexpr int EP = Mma<T>::EP;
+  typedef typename Vec16<T>::type V;
+  float s1[EP], s2[EP], a0[EP], a1[EP], a2[EP], a3[EP];
+  int kind = 0;   // 0 off, 1 forward statistics, 2 norm-backward sums
+
+  // b: sample of this workgroup's tile; n: first channel of this thread's slot (inactive if n >= Cout)
+  __device__ __forceinline__ void init(const ConvParams& p, int b, int n) {
+    kind = p.st_partial ? 1 : (p.nb_partial ? 2 : 0);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; a3[e] = 0.f; }
+    if (n >= p.Cout) return;
+    if (kind == 2) {
+      const size_t plane = (size_t)p.B * p.Cout, c = (size_t)b * p.Cout + n;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { a0[e] = p.nb_state[c + e]; a1[e] = p.nb_state[plane + c + e]; a2[e] = p.nb_state[2 * plane + c + e]; a3[e] = p.nb_state[3 * plane + c + e]; }
+    }
+  }
+  // forward statistics: shift = (approximately) the tile's first output row; e0 = its fp32 accumulators for this slot
+  __device__ __forceinline__ void set_shift(const ConvParams& p, const float* e0, int n) {
+    if (kind != 1 || n >= p.Cout) return;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) a0[e] = e0[e] + (p.bias ? p.bias[n + e] : 0.f);
+  }
+  // o: the vector just stored at output row m, channels n..n+EP-1
+  __device__ __forceinline__ void add(const ConvParams& p, const V& o, size_t m, int n) {
+    if (kind == 1) {
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { const float d = Elem<T>::to_f(o[e]) - a0[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+    } else if (kind == 2) {
+      const V yv = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.nb_y) + m * p.Cout + n);
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float yy = Elem<T>::to_f(yv[e]);
+        float gg = Elem<T>::to_f(o[e]);
+        if (p.nb_relu && !(fmaf(yy - a0[e], a2[e], a3[e]) > 0.f)) gg = 0.f;
+        s1[e] += gg;
+        s2[e] = fmaf(gg, (yy - a0[e]) * a1[e], s2[e]);
+      }
+    }
+  }
+  // CPR = 16-byte slots per tile row (threads tid % CPR == slot share a slot), NT threads.  `lds`: >= (NT/64)*CPR*2*EP floats,
+  // free for use (call after the epilogue's last barrier).  n0: first channel of the tile.
+  template <int CPR, int NT>
+  __device__ __forceinline__ void finish(const ConvParams& p, float* lds, int b, int chunk, int nchunks, int n0) {
+    if (kind == 0) return;   // (uniform)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, slot = tid % CPR;
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { lds[((wid * 2 + 0) * CPR + slot) * EP + e] = s1[e]; lds[((wid * 2 + 1) * CPR + slot) * EP + e] = s2[e]; }
+    }
+    __syncthreads();
+    float* out = kind == 1 ? p.st_partial + ((size_t)(b * nchunks + chunk) * 3) * p.Cout : p.nb_partial + ((size_t)(b * nchunks + chunk) * 2) * p.Cout;
+    for (int i = tid; i < 2 * CPR * EP; i += NT) {
+      const int which = i / (CPR * EP), c = i - which * (CPR * EP);
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) t += lds[((w * 2 + which) * CPR) * EP + c];
+      if (n0 + c < p.Cout) out[(size_t)which * p.Cout + n0 + c] = t;
+    }
+    if (kind == 1 && tid < CPR) {   // the shift (identical in all threads of a slot)
+      const int n = n0 + slot * EP;
+      if (n < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) out[(size_t)2 * p.Cout + n + e] = a0[e];
+      }
+    }
+  }
+};
+
 __device__ __forceinline__ int xcd_remap(int bid, int n) {
   // give each XCD (blocks b, b+8, ... share one) a contiguous range of tiles: neighbours share halo rows in L2
   const int q = n >> 3, r = n & 7, x = bid & 7;
@@ -86,6 +175,7 @@ static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 :
 
 // conv_patch.hip
 bool conv_patch_applicable(const ConvParams& p, int dtype);
+int conv_patch_stats_chunks(const ConvParams& p, int dtype);   // slab rows per sample of the column statistics, 0 = unsupported
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s);
 
 }  // namespace pwr

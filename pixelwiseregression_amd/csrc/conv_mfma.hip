@@ -46,22 +46,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   // norm-state pointer and the LDS offsets.  Per iteration only wave-uniform offsets are added (scalar ALU).
   const int q = tid & 3;
   const int taps = p.ksize * p.ksize;
-  // GEMM row -> (sample, output pixel).  mode 0: NHWC order.  mode 1 (data gradient of a stride-2 conv): rows are ordered by
-  // the parity class (oy & 1, ox & 1) of the output pixel first, so that a 128-row tile holds one class and only needs the
-  // taps that class can reach (1, 2, 2 or 4 of the 9) -- the other iterations are skipped below, 4x less work.
+  // GEMM row -> (sample, output pixel).  mode 0: NHWC order.  mode 1 (data gradient of a stride-2 conv): a 128-row tile
+  // holds output pixels of ONE parity class (oy & 1, ox & 1) and only needs the taps that class can reach (1, 2, 2 or 4 of
+  // the 9) -- the other iterations are skipped below, 4x less work.  Consecutive tiles cycle through the four classes so
+  // that every XCD's range of tiles carries the same mix of short and long tiles.
   const int Mq = p.M >> 2, HWi = p.H * p.W;
-  auto row_pixel = [&](int m, int& b, int& oy, int& ox) {
+  auto row_pixel = [&](int m, int& b, int& oy, int& ox) -> bool {
     if (p.mode == 0) {
+      if (m >= p.M) { b = 0; oy = 0; ox = 0; return false; }
       b = m / HoWo;
       const int rem = m - b * HoWo;
       oy = rem / p.Wo; ox = rem - oy * p.Wo;
-    } else {
-      const int cls = m / Mq, idx = m - cls * Mq;
-      b = idx / HWi;
-      const int rem = idx - b * HWi;
-      const int yq = rem / p.W;
-      oy = 2 * yq + (cls >> 1); ox = 2 * (rem - yq * p.W) + (cls & 1);
+      return true;
     }
+    const int tile = m / BM, cls = tile & 3, idx = (tile >> 2) * BM + (m - tile * BM);
+    if (idx >= Mq) { b = 0; oy = 0; ox = 0; return false; }
+    b = idx / HWi;
+    const int rem = idx - b * HWi;
+    const int yq = rem / p.W;
+    oy = 2 * yq + (cls >> 1); ox = 2 * (rem - yq * p.W) + (cls & 1);
+    return true;
   };
   const T* xrow[2];
   const float* strow[2];
@@ -70,27 +74,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + (tid >> 2) + 64 * i;
-    const bool mv = m < p.M;
-    const int mm = mv ? m : 0;
     int b, oy, ox;
-    row_pixel(mm, b, oy, ox);
+    const bool mv = row_pixel(m, b, oy, ox);
     int by, bx;
     unsigned mask = 0;
     if (p.mode == 0) {
       by = oy * p.stride - p.pad; bx = ox * p.stride - p.pad;
-      for (int t = 0; t < taps; ++t) {
-        const int ky = t / p.ksize, kx = t - ky * p.ksize;
-        const int iy = by + ky, ix = bx + kx;
-        if (mv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
-      }
+      for (int ky = 0, t = 0; ky < p.ksize; ++ky)
+        for (int kx = 0; kx < p.ksize; ++kx, ++t) {
+          const int iy = by + ky, ix = bx + kx;
+          if (mv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+        }
     } else {  // gather form of the stride-2 transposed conv: iy = (oy + pad - ky)/2 when even = by - (ky >> 1)
       by = (oy + p.pad) >> 1; bx = (ox + p.pad) >> 1;
-      for (int t = 0; t < taps; ++t) {
-        const int ky = t / p.ksize, kx = t - ky * p.ksize;
-        const int sy = oy + p.pad - ky, sx = ox + p.pad - kx;
-        const int iy = sy >> 1, ix = sx >> 1;
-        if (mv && !(sy & 1) && !(sx & 1) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
-      }
+      for (int ky = 0, t = 0; ky < p.ksize; ++ky)
+        for (int kx = 0; kx < p.ksize; ++kx, ++t) {
+          const int sy = oy + p.pad - ky, sx = ox + p.pad - kx;
+          const int iy = sy >> 1, ix = sx >> 1;
+          if (mv && !(sy & 1) && !(sx & 1) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+        }
     }
     vmask[i] = mask;
     xrow[i] = x + ((long long)(b * p.H + by) * p.W + bx) * p.Cin + q * EP;
@@ -226,6 +228,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   float* E = reinterpret_cast<float*>(smem);
   constexpr int PASSES = BM / EROWS;
   const int r = lane & 31, h = lane >> 5;
+  // column statistics (host guarantees mode 0 and Ho*Wo % 128 == 0 when requested: the tile lies in one sample)
+  constexpr int CPRS = BN / EP;
+  const int tile_b = m0 / HoWo;
+  EpiStats<T> est;
+  est.init(p, tile_b, n0 + (tid % CPRS) * EP);
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     const int wrow0 = wm * MR * 32;  // first tile row of this wave
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
           }
     }
     __syncthreads();
+    if (ps == 0) est.set_shift(p, E + (tid % CPRS) * EP, n0 + (tid % CPRS) * EP);
     if (p.y) {
       T* __restrict__ y = reinterpret_cast<T*>(p.y);
       const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
@@ -249,9 +257,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       for (int c = tid; c < EROWS * CPR; c += 256) {
         const int row = c / CPR, cc = (c - row * CPR) * EP;
         const int mg = m0 + ps * EROWS + row, n = n0 + cc;
-        if (mg < p.M && n < p.Cout) {
-          int m = mg;
-          if (p.mode != 0) { int b_, oy_, ox_; row_pixel(mg, b_, oy_, ox_); m = (b_ * p.Ho + oy_) * p.Wo + ox_; }
+        int m = mg;
+        bool mok = mg < p.M;
+        if (p.mode != 0) { int b_, oy_, ox_; mok = row_pixel(mg, b_, oy_, ox_); m = (b_ * p.Ho + oy_) * p.Wo + ox_; }
+        if (mok && n < p.Cout) {
           float v[EP];
 #pragma unroll
           for (int e = 0; e < EP; ++e) v[e] = E[row * EPITCH + cc + e];
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
 #pragma unroll
           for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(v[e]);
           *reinterpret_cast<V*>(y + (size_t)m * p.Cout + n) = o;
+          est.add(p, o, (size_t)m, n);
         }
       }
     }
@@ -275,11 +285,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
       for (int c = tid; c < EROWS * BN; c += 256) {
         const int col = c / EROWS, row = c - col * EROWS;
         const int mg = m0 + ps * EROWS + row, n = n0 + col;
-        if (mg < p.M && n < p.Cout) {
+        int m = mg;
+        bool mok = mg < p.M;
+        if (p.mode != 0) { int b_, oy_, ox_; mok = row_pixel(mg, b_, oy_, ox_); m = (b_ * p.Ho + oy_) * p.Wo + ox_; }
+        if (mok && n < p.Cout) {
           float v = E[row * EPITCH + col];
           if (p.bias) v += p.bias[n];
-          int m = mg;
-          if (p.mode != 0) { int b_, oy_, ox_; row_pixel(mg, b_, oy_, ox_); m = (b_ * p.Ho + oy_) * p.Wo + ox_; }
           const int b = m / HoWo, pix = m - b * HoWo;
           p.y_nchw[((size_t)b * p.Cout + n) * HoWo + pix] = v;
         }
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     }
     __syncthreads();
   }
+  est.template finish<CPRS, 256>(p, E, tile_b, (m0 - tile_b * HoWo) / BM, HoWo / BM, n0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -904,7 +916,9 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   if (p.CoutPad % bn) return PWR_EINVAL;
   if (conv_patch_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
-  dim3 grid((p.M + 127) / 128, p.CoutPad / bn), block(256);
+  // mode 1: four parity classes of M/4 rows each, every class padded to whole tiles
+  const int mtiles = p.mode == 0 ? (p.M + 127) / 128 : 4 * ((p.M / 4 + 127) / 128);
+  dim3 grid(mtiles, p.CoutPad / bn), block(256);
   if (bn == 128) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, 2, 2, 2>), grid, block, 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, 2, 2, 1>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((conv_fwd_kernel<T, 4, 1, 1, 1>), grid, block, 0, s, p);
@@ -957,12 +971,11 @@ extern "C" int pwr_pack_weights(const float* flat_params, void* packs, const voi
   return (int)hipGetLastError();
 }
 
-extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
+static int conv_params_fill(pwr::ConvParams& p, const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
                             const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout, int ksize,
-                            int stride, int mode, int dtype, void* stream) {
+                            int stride, int mode, int dtype) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
   if (Cin % EP || (y && Cout % EP) || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return PWR_EUNSUPPORTED;
-  pwr::ConvParams p;
   p.x = x; p.w = wpack; p.bias = bias; p.in_norm = in_norm; p.residual = residual;
   p.y = y; p.y_nchw = y_nchw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.ksize = ksize; p.pad = ksize / 2; p.mode = mode; p.relu_in = relu_in;
@@ -975,6 +988,46 @@ extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias,
   p.CoutPad = pwr_conv_out_pad(Cout);
   p.KCH = (Cin + KE - 1) / KE;
   p.M = B * p.Ho * p.Wo;
+  return 0;
+}
+
+extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
+                            const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout, int ksize,
+                            int stride, int mode, int dtype, void* stream) {
+  pwr::ConvParams p;
+  const int rc = conv_params_fill(p, x, wpack, bias, in_norm, relu_in, residual, y, y_nchw, B, H, W, Cin, Cout, ksize, stride, mode, dtype);
+  if (rc) return rc;
+  return dtype == PWR_BF16 ? pwr::launch_conv<bf16_t>(p, (hipStream_t)stream) : pwr::launch_conv<float>(p, (hipStream_t)stream);
+}
+
+// slab rows per sample that pwr_conv_fwd_stats writes for this conv shape; 0 = the shape cannot produce column statistics
+// (a 128-pixel tile would straddle samples, or the transposed mode)
+extern "C" int pwr_conv_stats_chunks(int H, int W, int Cin, int Cout, int ksize, int stride, int mode, int dtype) {
+  pwr::ConvParams p;
+  if (conv_params_fill(p, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (void*)1, nullptr, 1, H, W, Cin, Cout, ksize, stride, mode, dtype)) return 0;
+  static const bool on = [] { const char* e = getenv("PWR_CONV_STATS"); return e ? atoi(e) != 0 : true; }();
+  if (!on || mode != 0) return 0;
+  if (pwr::conv_patch_applicable(p, dtype)) return pwr::conv_patch_stats_chunks(p, dtype);
+  const int HoWo = p.Ho * p.Wo;
+  return HoWo % 128 == 0 ? HoWo / 128 : 0;
+}
+
+// pwr_conv_fwd + per-channel column statistics of the output in the epilogue (exactly one of st_partial / nb_partial):
+//   st_partial: [B*chunks][2][Cout] shifted sums of the stored output (shift = bias, or 0): forward statistics of the norm
+//               that follows (model.py conv -> norm pairs), finished by pwr_norm_finalize_partial;
+//   nb_partial: this launch is a data gradient producing g; sums of relu-masked g and g*xhat w.r.t. (nb_y, nb_state): the
+//               reductions of the norm backward, finished by pwr_norm_bwd_from_partial.
+extern "C" int pwr_conv_fwd_stats(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
+                                  const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                  int mode, float* st_partial, const void* nb_y, const float* nb_state, float* nb_partial,
+                                  int nb_relu, int dtype, void* stream) {
+  pwr::ConvParams p;
+  const int rc = conv_params_fill(p, x, wpack, bias, in_norm, relu_in, residual, y, nullptr, B, H, W, Cin, Cout, ksize, stride, mode, dtype);
+  if (rc) return rc;
+  if ((st_partial != nullptr) == (nb_partial != nullptr) || !y) return PWR_EINVAL;
+  if (pwr_conv_stats_chunks(H, W, Cin, Cout, ksize, stride, mode, dtype) == 0) return PWR_EUNSUPPORTED;
+  p.st_partial = st_partial;
+  p.nb_y = nb_y; p.nb_state = nb_state; p.nb_partial = nb_partial; p.nb_relu = nb_relu;
   return dtype == PWR_BF16 ? pwr::launch_conv<bf16_t>(p, (hipStream_t)stream) : pwr::launch_conv<float>(p, (hipStream_t)stream);
 }
 

@@ -50,11 +50,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   const int wm = wid / WN, wn = wid % WN;
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int HW = p.H * p.W;
-  int b = 0, ty0 = 0, tx0 = 0;
+  int b = 0, ty0 = 0, tx0 = 0, tr = 0, tiles_img = 1;
   if constexpr (TW == 32) {
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;   // requires H % TH == 0
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;   // requires H % TH == 0
+    tiles_img = tiles_x * tiles_y;
     b = t / tiles_img;
-    const int tr = t - b * tiles_img;
+    tr = t - b * tiles_img;
     ty0 = (tr / tiles_x) * TH; tx0 = (tr % tiles_x) * TW;
   }
   const long long L0 = (long long)t * BM, Mtot = (long long)p.B * HW;   // small maps: tile = BM consecutive NHWC pixels
@@ -254,6 +255,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   // ---- epilogue: accumulators -> LDS (fp32, 64 tile pixels at a time) -> coalesced 16-byte stores
   float* E = reinterpret_cast<float*>(smem);
   constexpr int PASSES = BM / EROWS;
+  constexpr int CPRS = BN / EP;
+  EpiStats<T> est;
+  if constexpr (TW == 32) est.init(p, b, n0 + (tid % CPRS) * EP);
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     const int wrow0 = wm * MR * 32;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
           }
     }
     __syncthreads();
+    if constexpr (TW == 32) { if (ps == 0) est.set_shift(p, E + (tid % CPRS) * EP, n0 + (tid % CPRS) * EP); }
     if (p.y) {
       T* __restrict__ y = reinterpret_cast<T*>(p.y);
       const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 #pragma unroll
           for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(v[e]);
           *reinterpret_cast<V*>(y + m * p.Cout + n) = o;
+          if constexpr (TW == 32) est.add(p, o, m, n);
         }
       }
     }
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     }
     __syncthreads();
   }
+  if constexpr (TW == 32) est.template finish<CPRS, NT>(p, E, b, tr, tiles_img, n0);
 }
 
 // small square maps of the inner hourglass levels (64 -> 64 channels): whole images per tile
@@ -332,6 +339,11 @@ bool conv_patch_applicable(const ConvParams& p, int dtype) {
   if (!(p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1)) return false;
   if (small_map(p, dtype)) return true;
   return p.W % 32 == 0 && p.H % 4 == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
+}
+
+int conv_patch_stats_chunks(const ConvParams& p, int dtype) {
+  if (!conv_patch_applicable(p, dtype) || small_map(p, dtype)) return 0;
+  return (p.H / 4) * (p.W / 32);
 }
 
 template <typename T>
@@ -357,7 +369,7 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
   if (dma && sizeof(T) == 2) {
     static const bool big = [] { const char* e = getenv("PWR_PATCH_BIG"); return e ? atoi(e) != 0 : false; }();   // measured: 61 us vs 59 us for the 4x32 tile -> off
     if constexpr (sizeof(T) == 2 && CIN == 128) {
-      if (bn == 128 && p.H % 8 == 0 && big) {
+      if (bn == 128 && p.H % 8 == 0 && big && !p.st_partial && !p.nb_partial) {
         // 8 waves, 8x32-pixel tile: the per-CU weight stream from L2 (the limiter of the 4x32 form) is halved
         dim3 g8(p.B * (p.H / 8) * (p.W / 32), p.CoutPad / bn);
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 2, 2, 2, true>), g8, dim3(512), 0, s, p);

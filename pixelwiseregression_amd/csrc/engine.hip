@@ -110,6 +110,7 @@ struct Engine {
   // shared scratch
   size_t scr_partial = 0, scr_S1 = 0, scr_S2 = 0, scr_slab = 0, scr_slab_bytes = 0;
   size_t need_partial = 0, need_sc = 0;
+  size_t scr_cpartial = 0, need_cpartial = 0;   // column statistics written by conv epilogues (pwr_conv_fwd_stats)
   std::string err;
   long long generation = 0;
   Ctx ctx;
@@ -194,11 +195,14 @@ struct Engine {
   }
 
   // ---- norm statistics of tensor t (forward) and its backward (g -> dy, in place in t.goff, + addend)
+  void norm_fwd_sizes(const Tn& t) {
+    const size_t pb = pwr_norm_partial_bytes(B, t.H * t.W, t.C);
+    if (pb > need_partial) need_partial = pb;
+    if ((size_t)B * t.C * 4 > need_sc) need_sc = (size_t)B * t.C * 4;
+  }
   void norm_fwd(const Tn& t, const NormL& n) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype;
-    const size_t pb = pwr_norm_partial_bytes(B, HW, C);
-    if (pb > need_partial) need_partial = pb;
-    if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
+    norm_fwd_sizes(t);
     const int nm = norm_mode;
     Engine* E = this;
     fwd.push_back([=](Ctx& c) {
@@ -211,9 +215,25 @@ struct Engine {
     });
   }
   // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
-  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend) {
+  // chunks > 0: the data-gradient conv that produced g already wrote the two reductions (conv_bwd's return value)
+  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
     Engine* E = this;
+    if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
+    if (chunks > 0) {
+      bwd_cur.push_back([=](Ctx& c) {
+        const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+        if (mode == 2)   // eval-mode batch norm: statistics are constants, the plain path handles it
+          return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
+                              (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), has_addend ? c.arena + addend_goff : nullptr,
+                              c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
+        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_cpartial),
+                                         chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
+                                         has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
+                                         c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
+      });
+      return;
+    }
     // measured on MI355X (C2): the split form (apply blocks combine the partials; dgamma/dbeta on the side stream) is SLOWER
     // than the plain three-launch form, 10.7 vs 9.9 ms per step -> opt-in only
     static const bool split = [] { const char* e = getenv("PWR_NORM_BWD_SPLIT"); return e ? atoi(e) != 0 : false; }();
@@ -245,7 +265,9 @@ struct Engine {
   }
 
   // ---- MFMA conv: y = conv(NR(x)) + bias (+ residual)
-  Tn conv_fwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn* residual, bool grad) {
+  // out_norm: the norm that follows the conv in model.py; its statistics come out of the conv's epilogue when the shape
+  // allows (otherwise conv, then the standalone statistics kernels)
+  Tn conv_fwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn* residual, bool grad, const NormL* out_norm = nullptr) {
     const int pad = cv.k / 2;
     const int Ho = (x.H + 2 * pad - cv.k) / cv.stride + 1, Wo = (x.W + 2 * pad - cv.k) / cv.stride + 1;
     Tn y = tensor(Ho, Wo, cv.Cout, grad);
@@ -254,16 +276,53 @@ struct Engine {
     const NormL n = has_nr ? *nr : NormL{};
     const bool has_res = residual != nullptr;
     const size_t roff = has_res ? residual->off : 0;
+    const int chunks = out_norm ? pwr_conv_stats_chunks(x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride, 0, dtype) : 0;
+    if (chunks > 0) {
+      const NormL on = *out_norm;
+      const size_t need = (size_t)B * chunks * 3 * cv.Cout * 4;
+      if (need > need_cpartial) need_cpartial = need;
+      const int nm = norm_mode, HWo = Ho * Wo;
+      Engine* E = this;
+      norm_fwd_sizes(y);
+      fwd.push_back([=](Ctx& c) {
+        const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+        float* rm = on.rm >= 0 ? c.buffers + on.rm : nullptr;
+        float* rv = on.rv >= 0 ? c.buffers + on.rv : nullptr;
+        if (mode == 2) {
+          int rc = pwr_conv_fwd(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.state) : nullptr,
+                                1, has_res ? c.arena + roff : nullptr, c.arena + y.off, nullptr, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k,
+                                cv.stride, 0, dt, c.stream);
+          if (rc) return rc;
+          return pwr_norm_stats(c.arena + y.off, c.params + on.gamma, c.params + on.beta, rm, rv, (float*)(c.arena + E->scr_partial),
+                                (float*)(c.arena + on.state), Bc, HWo, cv.Cout, mode, 1e-5f, 0.1f, dt, c.stream);
+        }
+        int rc = pwr_conv_fwd_stats(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.state) : nullptr,
+                                    1, has_res ? c.arena + roff : nullptr, c.arena + y.off, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride,
+                                    0, (float*)(c.arena + E->scr_cpartial), nullptr, nullptr, nullptr, 1, dt, c.stream);
+        if (rc) return rc;
+        return pwr_norm_finalize_partial((float*)(c.arena + E->scr_cpartial), chunks, c.params + on.gamma,
+                                         c.params + on.beta, rm, rv, (float*)(c.arena + on.state), Bc, HWo, cv.Cout, mode, 1e-5f, 0.1f,
+                                         c.stream);
+      });
+      return y;
+    }
     fwd.push_back([=](Ctx& c) {
       return pwr_conv_fwd(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.state) : nullptr,
                           1, has_res ? c.arena + roff : nullptr, c.arena + y.off,
                           nullptr, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride, 0, dt, c.stream);
     });
+    if (out_norm) norm_fwd(y, *out_norm);
     return y;
   }
   // backward of conv_fwd given y.goff complete.  Writes dW (and db if bias_grad), then dgrad into x.goff
   // (accumulating onto x.goff when accumulate_dx).  The caller applies norm_bwd afterwards when nr != null.
-  void conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx) {
+  // Returns the slab rows per sample of the norm-backward reductions that the data-gradient launch wrote for `nr`
+  // (to be passed to norm_bwd), 0 if it did not.
+  int dgrad_stats_chunks(const NormL* nr, const ConvL& cv, const Tn& y, bool accumulate_dx) const {
+    if (!nr || accumulate_dx || cv.stride != 1) return 0;
+    return pwr_conv_stats_chunks(y.H, y.W, cv.Cout, cv.Cin, cv.k, 1, 0, dtype);
+  }
+  int conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx) {
     const int Bc = B, dt = dtype;
     const bool has_nr = nr != nullptr;
     const NormL n = has_nr ? *nr : NormL{};
@@ -284,8 +343,24 @@ struct Engine {
         return rc;
       });
     });
-    if (!need_dx) return;
+    if (!need_dx) return 0;
     // data gradient: main stream
+    const int chunks = dgrad_stats_chunks(nr, cv, y, accumulate_dx);
+    if (chunks > 0) {
+      const size_t need = (size_t)B * chunks * 2 * cv.Cin * 4;
+      if (need > need_cpartial) need_cpartial = need;
+      const int nm = norm_mode;
+      bwd_cur.push_back([=](Ctx& c) {
+        const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+        if (mode == 2)
+          return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W,
+                              cv.Cout, cv.Cin, cv.k, 1, 0, dt, c.stream);
+        return pwr_conv_fwd_stats(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, Bc, y.H, y.W,
+                                  cv.Cout, cv.Cin, cv.k, 1, 0, nullptr, c.arena + x.off, (float*)(c.arena + n.state),
+                                  (float*)(c.arena + E->scr_cpartial), 1, dt, c.stream);
+      });
+      return chunks;
+    }
     bwd_cur.push_back([=](Ctx& c) {
       if (cv.stride == 1)
         return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0,
@@ -295,6 +370,7 @@ struct Engine {
                           accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k, 1,
                           1, dt, c.stream);
     });
+    return 0;
   }
 
   // ---- ResBlock (model.py:6-23)
@@ -311,21 +387,19 @@ struct Engine {
     r.cc = conv_params(Fh, x.C, 1, 1, true, true);
     if (pwr_resblock_small_supported(x.H, x.W, x.C, norm_mode, dtype)) return resblock_fused(x, r);
     norm_fwd(x, r.na);
-    r.t1 = conv_fwd(x, &r.na, r.ca, nullptr, tr);
-    norm_fwd(r.t1, r.nb);
-    r.t2 = conv_fwd(r.t1, &r.nb, r.cb, nullptr, tr);
-    norm_fwd(r.t2, r.nc);
+    r.t1 = conv_fwd(x, &r.na, r.ca, nullptr, tr, &r.nb);
+    r.t2 = conv_fwd(r.t1, &r.nb, r.cb, nullptr, tr, &r.nc);
     Tn out = conv_fwd(r.t2, &r.nc, r.cc, &x, tr);
     if (tr) {
       // reverse order: pushed first = executed last
       std::vector<Op> blk;
       std::swap(blk, bwd_cur);
-      conv_bwd(r.t2, &r.nc, r.cc, out, true, true, false);
-      norm_bwd(r.t2, r.nc, 0, false);
-      conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, true, false);
-      norm_bwd(r.t1, r.nb, 0, false);
-      conv_bwd(x, &r.na, r.ca, r.t1, false, true, false);
-      norm_bwd(x, r.na, out.goff, true);  // x.g = out.g (skip) + NRbwd(g)
+      int ch = conv_bwd(r.t2, &r.nc, r.cc, out, true, true, false);
+      norm_bwd(r.t2, r.nc, 0, false, ch);
+      ch = conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, true, false);
+      norm_bwd(r.t1, r.nb, 0, false, ch);
+      ch = conv_bwd(x, &r.na, r.ca, r.t1, false, true, false);
+      norm_bwd(x, r.na, out.goff, true, ch);  // x.g = out.g (skip) + NRbwd(g)
       append_block(blk);
     }
     return out;
@@ -421,9 +495,9 @@ struct Engine {
     h.c1 = conv_params(F, F, ks, 1, true, true); h.n1 = norm_params(F);
     h.c2 = conv_params(F, F, ks, 1, true, true); h.n2 = norm_params(F);
     h.c3 = conv_params(F, J, ks, 1, true, true);
-    h.h1 = conv_fwd(f, nullptr, h.c0, nullptr, tr); norm_fwd(h.h1, h.n0);
-    h.h2 = conv_fwd(h.h1, &h.n0, h.c1, nullptr, tr); norm_fwd(h.h2, h.n1);
-    h.h3 = conv_fwd(h.h2, &h.n1, h.c2, nullptr, tr); norm_fwd(h.h3, h.n2);
+    h.h1 = conv_fwd(f, nullptr, h.c0, nullptr, tr, &h.n0);
+    h.h2 = conv_fwd(h.h1, &h.n0, h.c1, nullptr, tr, &h.n1);
+    h.h3 = conv_fwd(h.h2, &h.n1, h.c2, nullptr, tr, &h.n2);
     const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3;
     fwd.push_back([=](Ctx& c) {
       float* dst = out_sel == 0 ? (float*)(c.arena + z_off) : c.out_D[stage_idx];
@@ -443,6 +517,9 @@ struct Engine {
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits));
     Engine* E = this;
     const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3; const size_t gT = h.gT;
+    const int nm = norm_mode;
+    const int ch3 = pwr_conv_stats_chunks(P, P, Jp, c3.Cin, c3.k, 1, 0, dtype);
+    if (ch3 > 0 && (size_t)B * ch3 * 2 * c3.Cin * 4 > need_cpartial) need_cpartial = (size_t)B * ch3 * 2 * c3.Cin * 4;
     bwd_cur.push_back([=](Ctx& c) {
       int rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + g_nchw_off), c.arena + gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
       if (rc) return rc;
@@ -453,14 +530,19 @@ struct Engine {
                               (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + c3.w, 0, Bc, h3.H, h3.W, c3.Cin, c3.Cin, Jp, Jc, c3.k, 1, splits, dt, c2.stream);
       });
       if (rc) return rc;
+      const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+      if (ch3 > 0 && mode != 2)
+        return pwr_conv_fwd_stats(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, Bc, Pc, Pc, Jp, c3.Cin,
+                                  c3.k, 1, 0, nullptr, c.arena + h3.off, (float*)(c.arena + n2.state), (float*)(c.arena + E->scr_cpartial),
+                                  1, dt, c.stream);
       return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
                           Jp, c3.Cin, c3.k, 1, 0, dt, c.stream);
     });
-    norm_bwd(h.h3, h.n2, 0, false);
-    conv_bwd(h.h2, &h.n1, h.c2, h.h3, false, true, false);
-    norm_bwd(h.h2, h.n1, 0, false);
-    conv_bwd(h.h1, &h.n0, h.c1, h.h2, false, true, false);
-    norm_bwd(h.h1, h.n0, 0, false);
+    norm_bwd(h.h3, h.n2, 0, false, ch3);
+    int ch = conv_bwd(h.h2, &h.n1, h.c2, h.h3, false, true, false);
+    norm_bwd(h.h2, h.n1, 0, false, ch);
+    ch = conv_bwd(h.h1, &h.n0, h.c1, h.h2, false, true, false);
+    norm_bwd(h.h1, h.n0, 0, false, ch);
     conv_bwd(f, nullptr, h.c0, h.h1, false, true, accumulate_df);
   }
 
@@ -488,26 +570,28 @@ struct Engine {
         const int nx = 2 * cch < F ? 2 * cch : F;
         ConvL cv = conv_params(cch, nx, ks, 1, true, true);
         NormL nn = norm_params(nx);
-        Tn y = conv_fwd(sy.back(), &sn.back(), cv, nullptr, tr);
-        norm_fwd(y, nn);
+        Tn y = conv_fwd(sy.back(), &sn.back(), cv, nullptr, tr, &nn);
         sc.push_back(cv); sn.push_back(nn); sy.push_back(y);
         cch = nx;
       }
       ConvL cl = conv_params(F, F, ks, 2, true, true);
       NormL nl = norm_params(F);
-      Tn yl = conv_fwd(sy.back(), &sn.back(), cl, nullptr, tr);
-      norm_fwd(yl, nl);
+      Tn yl = conv_fwd(sy.back(), &sn.back(), cl, nullptr, tr, &nl);
       sc.push_back(cl); sn.push_back(nl); sy.push_back(yl);
     }
     std::vector<Op> stem_bwd;
     if (tr) {
       const int ns = (int)sc.size();
       want_slab((size_t)pwr_stem_conv_wgrad_blocks(B, S) * 32 * ks * ks * 4);
+      // the gradient of the stem output comes from stage 0's 1x1 input conv (built below, run in the previous segment)
+      ConvL cin0; cin0.Cin = F; cin0.Cout = F; cin0.k = 1; cin0.stride = 1;
+      Tn x00; x00.H = P; x00.W = P; x00.C = F;
+      int ch = stages > 0 ? dgrad_stats_chunks(&sn[ns - 1], cin0, x00, false) : 0;
       for (int i = ns - 1; i >= 1; --i) {
-        norm_bwd(sy[i], sn[i], 0, false);
-        conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false);
+        norm_bwd(sy[i], sn[i], 0, false, ch);
+        ch = conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false);
       }
-      norm_bwd(sy[0], sn[0], 0, false);
+      norm_bwd(sy[0], sn[0], 0, false, ch);
       const Tn y0 = sy[0]; const ConvL c0 = sc[0];
       bwd_cur.push_back([=](Ctx& c) {
         return run_on_side(c, [=](Ctx& c2) {
@@ -613,6 +697,7 @@ struct Engine {
     // shared scratch
     scr_partial = alloc(need_partial);
     scr_S1 = alloc(need_sc); scr_S2 = alloc(need_sc);
+    scr_cpartial = alloc(need_cpartial);
     scr_slab_bytes = (scr_slab_bytes + 255) / 256 * 256;
     scr_slab = alloc(scr_slab_bytes * Ctx::kMaxSide);
     ctx.slab_stride = scr_slab_bytes;

@@ -560,6 +560,69 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   return (int)hipGetLastError();
 }
 
+namespace pwr {
+// Statistics from the per-tile sums that a conv epilogue wrote (pwr_conv_fwd_stats): `chunks` entries per sample, each
+// (sum (v - k), sum (v - k)^2, k) over HW/chunks pixels with its own shift k.  Chunks are merged like Chan et al.'s
+// parallel variance (mean and M2 per chunk) -- no cancellation anywhere.
+__global__ void norm_finalize_chunks_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            float* __restrict__ state, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                            int B, int HW, int C, int chunks, int batch_mode, float eps, float momentum) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (batch_mode ? C : B * C)) return;
+  const int b = batch_mode ? 0 : idx / C, c = batch_mode ? idx : idx - b * C;
+  const int total = batch_mode ? B * chunks : chunks;
+  const float* base = partial + ((size_t)b * chunks * 3) * C + c;
+  const float nper = (float)(HW / chunks), inv = 1.f / nper;
+  // one pass, chunks merged one after the other (equal sizes): delta = chunk mean - running mean,
+  // mean += delta / (j+1), M2 += M2_j + n * delta^2 * j / (j+1); 8 chunks' loads in flight at a time
+  float mean = 0.f, m2 = 0.f, cnt = 0.f;
+  auto merge = [&](float a, float q, float k) {
+    const float mj = k + a * inv, d = mj - mean, c1 = cnt + 1.f;
+    mean += d / c1;
+    m2 += fmaxf(q - a * a * inv, 0.f) + nper * d * d * (cnt / c1);
+    cnt = c1;
+  };
+  int j = 0;
+  for (; j + 8 <= total; j += 8) {
+    float a[8], q[8], k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = base[((size_t)(j + u) * 3 + 0) * C]; q[u] = base[((size_t)(j + u) * 3 + 1) * C]; k[u] = base[((size_t)(j + u) * 3 + 2) * C];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) merge(a[u], q[u], k[u]);
+  }
+  for (; j < total; ++j) merge(base[((size_t)j * 3 + 0) * C], base[((size_t)j * 3 + 1) * C], base[((size_t)j * 3 + 2) * C]);
+  const float n = nper * (float)total;
+  const float var = fmaxf(m2 / n, 0.f), rstd = 1.f / sqrtf(var + eps);
+  const float sc = gamma[c] * rstd, sh = beta[c];
+  const size_t plane = (size_t)B * C;
+  if (!batch_mode) {
+    state[idx] = mean; state[plane + idx] = rstd; state[2 * plane + idx] = sc; state[3 * plane + idx] = sh;
+  } else {
+    for (int bb = 0; bb < B; ++bb) {
+      const size_t o = (size_t)bb * C + c;
+      state[o] = mean; state[plane + o] = rstd; state[2 * plane + o] = sc; state[3 * plane + o] = sh;
+    }
+    if (running_mean) {  // torch.nn.BatchNorm2d: unbiased variance in the running estimate
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+  }
+}
+
+}  // namespace pwr
+
+extern "C" int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float* state, int B, int HW, int C, int mode,
+                                         float eps, float momentum, void* stream) {
+  if ((mode != 0 && mode != 1) || chunks < 1 || HW % chunks) return PWR_EINVAL;
+  const int n = mode == 1 ? C : B * C;
+  hipLaunchKernelGGL(norm_finalize_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, state,
+                     running_mean, running_var, B, HW, C, chunks, mode, eps, momentum);
+  return (int)hipGetLastError();
+}
+
 // Backward of relu(norm(y)) (relu optional).  g: upstream gradient; dy out (may alias g); addend optional (same
 // shape, added to the result: the skip branch of a ResBlock).  S1,S2: [B,C] scratch.  dgamma/dbeta: [C].
 // mode 2 (eval-mode batch norm) treats the statistics as constants.
@@ -586,6 +649,27 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
     hipMemsetAsync(S1, 0, (size_t)B * C * 4, s);
     hipMemsetAsync(S2, 0, (size_t)B * C * 4, s);
   }
+  if (dtype == PWR_BF16) {
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, false>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
+                       S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
+  } else {
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
+                       S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
+  }
+  return (int)hipGetLastError();
+}
+
+// pwr_norm_bwd with the two reductions already done by the epilogue of the data-gradient conv that produced g
+// (pwr_conv_fwd_stats, nb_partial: `chunks` slab rows per sample): 2 launches instead of 3, (g, y) read once instead of twice.
+extern "C" int pwr_norm_bwd_from_partial(const void* g, const void* y, const float* state, const float* partial, int chunks, float* S1,
+                                         float* S2, const void* addend, void* dy, float* dgamma, float* dbeta, int accumulate, int relu,
+                                         int B, int HW, int C, int mode, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256 || mode == 2) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = norm_chunks(B, HW);
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, S1, S2, dgamma, dbeta, B, HW, C, chunks,
+                     mode == 1 ? 1 : 0, accumulate);
   if (dtype == PWR_BF16) {
     hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, false>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
                        S1, S2, (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);

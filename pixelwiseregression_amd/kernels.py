@@ -306,3 +306,49 @@ def resblock_bwd_small(gout, x, t1, t2, packs_d, states):
                                         _p(packs_d[0]), _p(states[0]), _p(states[1]), _p(states[2]), _p(sums[0]), _p(sums[1]),
                                         _p(sums[2]), B, H, W, C, _dt(x), _s(x)), "pwr_resblock_bwd_small")
     return dx, dt1, dt2, sums
+
+
+def conv_stats_chunks(H, W, Cin, Cout, ksize, stride=1, mode=0, dtype=BF16):
+    return _lib.lib().pwr_conv_stats_chunks(H, W, Cin, Cout, ksize, stride, mode, dtype)
+
+
+def conv_fwd_stats(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_in=True, residual=None, nb_y=None, nb_state=None,
+                   nb_relu=True):
+    """conv_fwd + column statistics from the epilogue.  nb_y is None: forward statistics of the output (for the norm that
+    follows); else: the norm-backward sums of the produced gradient w.r.t. (nb_y, nb_state).  Returns y, partial, chunks."""
+    l = _lib.lib()
+    B, H, W, Cin = x.shape
+    pad = ksize // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    chunks = l.pwr_conv_stats_chunks(H, W, Cin, cout, ksize, stride, 0, _dt(x))
+    if chunks <= 0:
+        raise _lib.PwrError("conv shape does not support epilogue statistics")
+    y = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
+    partial = torch.full((B * chunks, 3 if nb_y is None else 2, cout), float("nan"), dtype=torch.float32, device=x.device)
+    st, nbp = (partial, None) if nb_y is None else (None, partial)
+    _lib.check(l.pwr_conv_fwd_stats(_p(x), _p(wpack), _p(bias), _p(norm), int(relu_in), _p(residual), _p(y), B, H, W, Cin, cout, ksize,
+                                    stride, 0, _p(st), _p(nb_y), _p(nb_state), _p(nbp), int(nb_relu), _dt(x), _s(x)), "pwr_conv_fwd_stats")
+    return y, partial, chunks
+
+
+def norm_finalize_partial(partial, chunks, gamma, beta, B, HW, mode=0, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    l = _lib.lib()
+    C = gamma.numel()
+    state = torch.empty(4, B, C, dtype=torch.float32, device=partial.device)
+    _lib.check(l.pwr_norm_finalize_partial(_p(partial), chunks, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                           _p(state), B, HW, C, mode, eps, momentum, _s(partial)), "pwr_norm_finalize_partial")
+    return state
+
+
+def norm_bwd_from_partial(g, y, state, partial, chunks, relu=True, addend=None, mode=0):
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    dev = y.device
+    S1 = torch.empty(B, C, dtype=torch.float32, device=dev)
+    S2 = torch.empty_like(S1)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    _lib.check(l.pwr_norm_bwd_from_partial(_p(g), _p(y), _p(state), _p(partial), chunks, _p(S1), _p(S2), _p(addend), _p(dy), _p(dgamma),
+                                           _p(dbeta), 0, int(relu), B, H * W, C, mode, _dt(y), _s(y)), "pwr_norm_bwd_from_partial")
+    return dy, dgamma, dbeta

@@ -468,3 +468,63 @@ def test_resblock_small_fused_vs_unfused(B, H):
         # bf16 roundings of t1 / t2 flip ReLUs of near-zero pre-activations: an L2 criterion, not a max-norm one
         rel_l2 = ((nchw(fdx) - xq.grad).norm() / xq.grad.norm()).item()
         assert rel_l2 < 5e-2, "fused dx vs float64: rel L2 %.3e" % rel_l2
+
+
+# ---------------------------------------------------------------- conv epilogue column statistics
+STATS_CASES = [
+    # B, H, W, Cin, Cout, k   (patch kernel: W % 32 == 0; universal: H*W % 128 == 0)
+    (2, 64, 64, 128, 128, 3), (3, 32, 32, 64, 64, 3), (2, 8, 32, 32, 64, 3), (2, 32, 32, 128, 64, 1), (3, 16, 16, 64, 128, 1),
+    (2, 64, 64, 16, 128, 3), (1, 128, 128, 32, 64, 3),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_epilogue_forward_stats(case, dtype):
+    """conv + statistics from its epilogue + finalize == conv, then the standalone norm statistics."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, k = case
+    kd = K.BF16 if dtype == torch.bfloat16 else K.F32
+    assert K.conv_stats_chunks(H, W, Cin, Cout, k, 1, 0, kd) > 0
+    x = nhwc(rnd(B, Cin, H, W, seed=1), dtype)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    bias = (rnd(Cout, seed=3) * 20).float().to(DEV)         # means far from 0: the sums must be shifted
+    gamma, beta = (1 + 0.2 * rnd(Cout, seed=4)).float().to(DEV), (0.2 * rnd(Cout, seed=5)).float().to(DEV)
+    res = nhwc(rnd(B, Cout, H, W, seed=6), dtype)
+    pack = K.pack_conv(w.float().to(DEV), 0, kd)
+    for mode in (0, 1):
+        y0, _ = K.conv_fwd(x, pack, Cout, k, 1, bias=bias, residual=res)
+        ref = K.norm_stats(y0, gamma, beta, mode=mode)
+        y1, partial, chunks = K.conv_fwd_stats(x, pack, Cout, k, 1, bias=bias, residual=res)
+        assert torch.equal(y0, y1)
+        assert not torch.isnan(partial).any()
+        st = K.norm_finalize_partial(partial, chunks, gamma, beta, B, H * W, mode=mode)
+        # mean / rstd / scale agree to fp32 summation noise (both are statistics of the same stored tensor)
+        assert_close(st.double().cpu(), ref.double().cpu(), 2e-5 if dtype == torch.float32 else 2e-4, "state (mode %d)" % mode)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_epilogue_norm_backward_sums(case, dtype):
+    """data-gradient conv + norm-backward sums from its epilogue == data gradient, then the three-launch norm backward."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, k = case
+    kd = K.BF16 if dtype == torch.bfloat16 else K.F32
+    dyn = nhwc(rnd(B, Cin, H, W, seed=1), dtype)             # gradient w.r.t. the conv that FOLLOWS the norm
+    w = rnd(Cin, Cout, k, k, seed=2, scale=(Cin * k * k) ** -0.5)   # that conv maps Cout -> Cin channels
+    pack_d = K.pack_conv(w.float().to(DEV), 1, kd)
+    y = nhwc(rnd(B, Cout, H, W, seed=3), dtype)             # pre-norm tensor of the norm being back-propagated
+    gamma, beta = (1 + 0.2 * rnd(Cout, seed=4)).float().to(DEV), (0.2 * rnd(Cout, seed=5)).float().to(DEV)
+    add = nhwc(rnd(B, Cout, H, W, seed=6), dtype)
+    for mode in (0, 1):
+        state = K.norm_stats(y, gamma, beta, mode=mode)
+        g0, _ = K.conv_fwd(dyn, pack_d, Cout, k, 1)
+        dy0, dg0, db0 = K.norm_bwd(g0, y, state, addend=add, mode=mode)
+        g1, partial, chunks = K.conv_fwd_stats(dyn, pack_d, Cout, k, 1, nb_y=y, nb_state=state)
+        assert torch.equal(g0, g1)
+        assert not torch.isnan(partial).any()
+        dy1, dg1, db1 = K.norm_bwd_from_partial(g1, y, state, partial, chunks, addend=add, mode=mode)
+        t = 2e-5 if dtype == torch.float32 else 1e-2
+        assert_close(dy1.double().cpu(), dy0.double().cpu(), t, "dy (mode %d)" % mode)
+        assert_close(dg1.double().cpu(), dg0.double().cpu(), 1e-4, "dgamma")
+        assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
