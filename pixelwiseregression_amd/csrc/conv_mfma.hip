@@ -682,40 +682,48 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
     }
   };
 
+  // per-thread constants of the loaders: element offsets relative to the (uniform) tile origin, LDS offsets, edge flags.
+  // Loads are branch-free: an out-of-image slot reads a valid address of the same row and is zeroed by a select, so all
+  // loads of a stage issue back to back.
+  int a_off[NA], a_lds[NA], b_off[NBL], b_lds[NBL];
+  bool a_in[NA], a_left[NA], a_right[NA], b_in[NBL];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int c = tid + 256 * i;
+    const int pix = c / ACH, cq = c % ACH;     // ACH is a power of two
+    const bool chok = ci0 + cq * EP < p.Cin;
+    a_in[i] = c < AP * ACH && chok;
+    a_left[i] = pix == 0; a_right[i] = pix == AP - 1;
+    a_off[i] = a_in[i] ? (pix - 1) * p.Cin + ci0 + cq * EP : 0;
+    a_lds[i] = (c < AP * ACH ? pix : 0) * PA + cq * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NBL; ++i) {
+    const int c = tid + 256 * i;
+    const int pix = c / BCH, cq = c % BCH;
+    b_in[i] = c < KP * BCH && co0 + cq * EP < p.Cout;
+    b_off[i] = b_in[i] ? pix * p.Cout + co0 + cq * EP : 0;
+    b_lds[i] = (c < KP * BCH ? pix : 0) * PB + cq * 16;
+  }
   struct Stage { V a[NA]; V b[NBL]; unsigned okmask; int bidx; bool rowok; };
   Stage sg[2];
   auto load_global = [&](Stage& S) {
     const int iy = ty + ky - 1;
     S.rowok = iy >= 0 && iy < p.H;
     S.bidx = tb;
-    S.okmask = 0;
-    const size_t rowbase = ((size_t)tb * p.H + (S.rowok ? iy : 0)) * p.W;
+    const T* xrow = x + (((long long)tb * p.H + (S.rowok ? iy : ty)) * p.W + tx * KP) * p.Cin;
+    const T* drow = dy + (((long long)tb * p.H + ty) * p.W + tx * KP) * p.Cout;
+    const bool first = tx == 0, last = tx == tiles_x - 1;
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int c = tid + 256 * i;
-      const int pix = c / ACH, cq = c % ACH;     // ACH is a power of two
-      V v = {};
-      if (c < AP * ACH) {
-        const int ix = tx * KP + pix - 1, ci = ci0 + cq * EP;
-        if (S.rowok && ix >= 0 && ix < p.W && ci < p.Cin) {
-          v = *reinterpret_cast<const V*>(x + (rowbase + ix) * p.Cin + ci);
-          S.okmask |= 1u << i;
-        }
-      }
-      S.a[i] = v;
+      const bool ok = a_in[i] && S.rowok && !(a_left[i] && first) && !(a_right[i] && last);
+      S.a[i] = *reinterpret_cast<const V*>(xrow + (ok ? a_off[i] : 0));
+      okm |= (ok ? 1u : 0u) << i;
     }
-    const size_t m0 = ((size_t)tb * p.H + ty) * p.W + (size_t)tx * KP;
+    S.okmask = okm;
 #pragma unroll
-    for (int i = 0; i < NBL; ++i) {
-      const int c = tid + 256 * i;
-      const int pix = c / BCH, cq = c % BCH;
-      V v = {};
-      if (c < KP * BCH) {
-        const int co = co0 + cq * EP;
-        if (co < p.Cout) v = *reinterpret_cast<const V*>(dy + (m0 + pix) * p.Cout + co);
-      }
-      S.b[i] = v;
-    }
+    for (int i = 0; i < NBL; ++i) S.b[i] = *reinterpret_cast<const V*>(drow + b_off[i]);
     advance();
   };
   auto store_lds = [&](Stage& S, int buf) {
@@ -724,27 +732,25 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
     load_state(S.bidx);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int c = tid + 256 * i;
-      if (c < AP * ACH) {
-        const int pix = c / ACH, cq = c % ACH;
-        V v = S.a[i];
-        if (p.in_norm && ((S.okmask >> i) & 1)) {
-          V o;
+      V v = S.a[i];
+      if (p.in_norm) {
+        V o;
 #pragma unroll
-          for (int e = 0; e < EP; ++e) {
-            float f = fmaf((float)v[e] - mu[e], sc[e], be[e]);
-            if (p.relu_in) f = fmaxf(f, 0.f);
-            o[e] = (bf16_t)f;
-          }
-          v = o;
+        for (int e = 0; e < EP; ++e) {
+          float f = fmaf((float)v[e] - mu[e], sc[e], be[e]);
+          if (p.relu_in) f = fmaxf(f, 0.f);
+          o[e] = (bf16_t)f;
         }
-        *reinterpret_cast<V*>(lA + pix * PA + cq * 16) = v;
+        v = o;
       }
+      if (!((S.okmask >> i) & 1)) v = V{};
+      if (AP * ACH >= 256 * (i + 1) || tid + 256 * i < AP * ACH) *reinterpret_cast<V*>(lA + a_lds[i]) = v;
     }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
-      const int c = tid + 256 * i;
-      if (c < KP * BCH) *reinterpret_cast<V*>(lB + (c / BCH) * PB + (c % BCH) * 16) = S.b[i];
+      V v = S.b[i];
+      if (!b_in[i]) v = V{};
+      if (KP * BCH >= 256 * (i + 1) || tid + 256 * i < KP * BCH) *reinterpret_cast<V*>(lB + b_lds[i]) = v;
     }
   };
 
@@ -766,22 +772,27 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
     if (rowok_cur) {
       const char* lA = smem + buf * (TILE_A + TILE_B);
       const char* lB = lA + TILE_A;
+      // all fragment reads of the step are issued first (16 fragments, 64 VGPRs): the MFMAs then start as their operands
+      // arrive instead of exposing one LDS round trip per group
+      V bf[2][NR], af[2][3][MR];
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        V b[NR];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) b[j] = frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
+        for (int j = 0; j < NR; ++j) bf[ss][j] = frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          V a[MR];
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int i = 0; i < MR; ++i) a[i] = frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane);
+          for (int i = 0; i < MR; ++i) af[ss][t][i] = frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane);
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < NR; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
-        }
-      }
+            for (int j = 0; j < NR; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ss][t][i], bf[ss][j], acc[t][i][j], 0, 0, 0);
     }
     if (st + 1 < nsteps) store_lds(sg[buf ^ 1], buf ^ 1);
     __syncthreads();
@@ -934,6 +945,15 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
       dim3 g3(24 * ((p.S + 7) / 8), grid.y, 1);
+      // 128 output channels: 64 (ci) x 128 (co) x 3 taps per workgroup = 96 accumulator registers -> TWO workgroups per CU,
+      // so one's norm/ReLU staging (VALU) and waits overlap the other's MFMAs; the x tile (the operand that needs VALU work)
+      // is split between them, not duplicated.  (128 x 128 x 3 = 192 registers allows one wave per SIMD only: 25 % MFMA busy.)
+      static const bool bm64 = [] { const char* e = getenv("PWR_WGRAD3_BM64"); return e ? atoi(e) != 0 : true; }();
+      if (bn == 128 && bm64) {
+        dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
+        hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2>), g64, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 2>), g3, block, 0, s, p);
       else if (bn == 64) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 1>), g3, block, 0, s, p);
       else hipLaunchKernelGGL((conv_wgrad3_kernel<4, 1, 1, 1>), g3, block, 0, s, p);

@@ -31,6 +31,6 @@ if which in ("all", "fwd"):
     t = timeit(lambda: K.conv_fwd(x, pack, F_, 3, 1))
     print(json.dumps({"kernel": "conv3x3_patch (no prologue: dgrad form)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
 if which in ("all", "wgrad"):
-    for splits in (57, 80, 85, 86, 96):
+    for splits in (40, 57, 80, 85, 86, 96, 120, 160):
         t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=st, splits=splits))
         print(json.dumps({"kernel": "conv_wgrad_tr + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
