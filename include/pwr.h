@@ -244,9 +244,6 @@ long long pwr_engine_generation(void* engine);
  * segment `seg`; segment 0 first zeroes grads[0:n_grad_floats].  Parameter gradients are written (not
  * accumulated) into the bound flat gradient buffer, in the layout of the parameters. */
 int pwr_engine_backward(void* engine, const void* const* gouts, int seg, long long n_grad_floats, void* stream);
-/* every_segment != 0 (default): the parameter gradients of a segment are complete on `stream` when pwr_engine_backward
- * returns it (what the per-segment data-parallel all-reduce needs); 0: only after the last segment. */
-int pwr_engine_set_segment_join(void* engine, int every_segment);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-step tail (train.py:139-142, 195-208) on the flat fp32 buffers.

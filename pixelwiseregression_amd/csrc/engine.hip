@@ -124,7 +124,6 @@ struct Engine {
   struct GraphEntry { std::vector<const void*> key; hipGraphExec_t exec; };
   struct GraphCache { std::vector<GraphEntry> entries; int strikes = 0, misses = 0; };
   GraphCache gc_fwd;
-  int join_every_segment = 1;
   std::vector<GraphCache> gc_bwd;
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -882,7 +881,6 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
   return rc;
 }
 extern "C" long long pwr_engine_generation(void* h) { return ((Engine*)h)->generation; }
-extern "C" int pwr_engine_set_segment_join(void* h, int every_segment) { ((Engine*)h)->join_every_segment = every_segment != 0; return 0; }
 
 // gouts: host array of 3*stage device pointers (NULL = zero gradient).  Runs backward segment `seg`
 // (0 = last stage ... num_segments-1 = stem); segment 0 also zeroes the flat gradient buffer first.
@@ -900,8 +898,14 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
     if (want > Ctx::kMaxSide) want = Ctx::kMaxSide;
     c.use_side = want > 0;
     if (c.use_side && hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess) c.use_side = false;
+    // side streams at the LOWEST priority: when a weight-gradient kernel and a kernel of the critical chain both have
+    // workgroups to place, the chain goes first and the weight gradients fill what is left
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char* pe = getenv("PWR_SIDE_PRIORITY");
+    const bool low = pe ? atoi(pe) != 0 : true;
     for (int k = 0; c.use_side && k < want; ++k) {
-      if (hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking) != hipSuccess ||
+      if (hipStreamCreateWithPriority(&c.side[k], hipStreamNonBlocking, low ? prio_lo : 0) != hipSuccess ||
           hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming) != hipSuccess) break;
       c.n_side = k + 1;
     }
@@ -920,19 +924,17 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
       rc = ops[i](c);
       if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
     }
-    // join: the parameter gradients are complete before anything later on the stream.  Needed after every segment only when
-    // somebody consumes a segment's gradients right away (the data-parallel all-reduce); otherwise once, after the last one --
-    // the next segment's critical chain does not wait for this segment's trailing weight gradients.
-    if (e->join_every_segment || seg + 1 == (int)e->bwd.size()) {
-      for (int k = 0; c.use_side && k < c.n_side; ++k) {
-        hipEventRecord(c.ev_join[k], c.side[k]);
-        hipStreamWaitEvent((hipStream_t)st, c.ev_join[k], 0);
-      }
+    // join: the segment's parameter gradients are complete before anything later on the stream (the data-parallel all-reduce of
+    // this segment; the next segment).  Joining only once per backward was measured 1 % faster but NOT reproducible run to run
+    // (2 of 6 runs diverged): kept per segment.
+    for (int k = 0; c.use_side && k < c.n_side; ++k) {
+      hipEventRecord(c.ev_join[k], c.side[k]);
+      hipStreamWaitEvent((hipStream_t)st, c.ev_join[k], 0);
     }
     return rc;
   };
   if (e->gc_bwd.size() != e->bwd.size()) e->gc_bwd.resize(e->bwd.size());
-  std::vector<const void*> key = {(const void*)(intptr_t)n_grad_floats, (const void*)(intptr_t)(c.training + 1 + 4 * e->join_every_segment)};
+  std::vector<const void*> key = {(const void*)(intptr_t)n_grad_floats, (const void*)(intptr_t)(c.training + 1)};
   for (int s = 0; s < 3 * e->stages; ++s) key.push_back(gouts[s]);
   // the backward also reads what the forward call was given: inputs (stem weight gradient, decoder) and outputs (decoder)
   key.push_back(c.img); key.push_back(c.label); key.push_back(c.mask);

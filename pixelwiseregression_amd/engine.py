@@ -134,7 +134,6 @@ class _EngineFn(torch.autograd.Function):
         plan.bind(model, target)
         n = flat_grad.numel()
         ddp = model._ddp
-        l.pwr_engine_set_segment_join(plan.h, 1 if ddp is not None else 0)   # per-segment join only for the all-reduce
         for seg in range(plan.n_seg):
             _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
             if ddp is not None and fresh:
