@@ -167,6 +167,12 @@ int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* 
                        int HW, int C, int dtype, void* stream);
 int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream);
 
+/* Dense training targets on the device (datasets.py:285-294 heat maps = Gaussian blur, default border, of the bilinear 2x2
+ * splat utils.py:37-64; datasets.py:365-383 depth-offset maps) from the normalised joints uvd [B,J,3], label_img and mask
+ * [B,P,P]: heatmaps / depthmaps [B,J,P,P] fp32, the alpha < 1 targets of the loss (train.py:197-198).  ksize odd <= 15. */
+int pwr_make_targets(const float* uvd, const float* label_img, const float* mask, float* heatmaps, float* depthmaps, int B, int J,
+                     int P, int ksize, float sigma, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ResBlock (model.py:6-23: norm, ReLU, conv1x1 C->C/2, norm, ReLU, conv3x3, norm, ReLU, conv1x1 C/2->C, + x) on the small
  * square maps of the inner hourglass levels as ONE launch per direction: one workgroup owns one sample, activations stay in

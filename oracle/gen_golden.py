@@ -258,7 +258,23 @@ def gen_metric(ref_utils, ref_datasets):
     print("metric done")
 
 
+def gen_targets(ref_utils):
+    """Bilinear splat of utils.generate_heatmap (utils.py:37-61) at fixed positions, incl. exact-integer and border cases.
+    (The Gaussian blur of utils.generate_kernel needs cv2, which is not installed: not generated here.)"""
+    P = 64
+    rng = np.random.default_rng(11)
+    uv = np.concatenate([rng.random((24, 2)) * (P - 2), np.array([[0.0, 0.0], [10.0, 20.5], [61.999, 3.25], [31.5, 31.5]])])
+    heat = np.stack([ref_utils.generate_heatmap(P, float(u), float(v)) for u, v in uv])
+    np.savez_compressed(os.path.join(OUT, "targets.npz"), P=np.int64(P), uv=uv, splat=heat)
+    print("targets done")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "targets":     # (add one fixture without regenerating the others)
+        os.makedirs(OUT, exist_ok=True)
+        _, ref_utils, _ = import_reference()
+        gen_targets(ref_utils)
+        sys.exit(0)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref_model, ref_utils, ref_datasets = import_reference()
@@ -267,3 +283,4 @@ if __name__ == "__main__":
     gen_c1(ref_model)
     gen_metric(ref_utils, ref_datasets)
     gen_init(ref_model)
+    gen_targets(ref_utils)

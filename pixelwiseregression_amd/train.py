@@ -19,13 +19,14 @@ from .engine import _get_plan, _run_forward, BF16, F32
 
 class TrainStep:
     def __init__(self, model, opt="adam", lr=1e-3, beta1=0.9, beta2=0.999, weight_decay=0.0, eps=1e-8, alpha=1.0, lambda_h=1.0,
-                 lambda_d=0.01, decay_epoch=15, lr_decay=0.2):
+                 lambda_d=0.01, decay_epoch=15, lr_decay=0.2, target_kernel_size=7, target_sigmoid=1.5):
         if opt not in ("adam", "sgd"):
             raise ValueError("opt must be 'adam' or 'sgd' (train.py:139-142)")
         self.model, self.opt = model, opt
         self.lr, self.beta1, self.beta2, self.wd, self.eps = lr, beta1, beta2, weight_decay, eps
         self.alpha, self.lambda_h, self.lambda_d = alpha, lambda_h, lambda_d
         self.decay_epoch, self.lr_decay = decay_epoch, lr_decay
+        self.target_kernel_size, self.target_sigmoid = target_kernel_size, target_sigmoid   # train.py:29-30
         self.steps, self.epochs = 0, 0
         flat = model.flat_parameters()
         self.m = torch.zeros_like(flat)
@@ -54,7 +55,9 @@ class TrainStep:
         stream = _lib.stream_ptr(dev)
         dense = self.alpha != 1.0
         if dense and (heatmaps is None or depthmaps is None):
-            raise ValueError("alpha < 1 needs the dense heatmap / depthmap targets (train.py:197-198)")
+            # the dense targets of train.py:197-198, built on the device from the joints (datasets.py:285-294, :365-383)
+            from .targets import make_targets
+            heatmaps, depthmaps = make_targets(uvd, label_img, mask, self.target_kernel_size, self.target_sigmoid)
         n_map, n_uvd = B * J * P * P, B * J * 3
         if self._scratch is None or self._scratch[0] != (B, dense):
             nb = l.pwr_loss_blocks(n_map if dense else n_uvd)
