@@ -49,46 +49,65 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 
-// dW[c][tap] partials: slab[block][c*taps + tap]
+// dW[c][tap] partials: slab[block][c*taps + tap].  A thread owns one 16-byte channel slot of dy for every PLN-th pixel of the
+// block's pixel range (coalesced 16-byte loads, coordinates stepped incrementally: no divisions in the loop); the 3x3 (k x k)
+// image neighbourhood is loaded once per pixel and shared by the slot's channels.  Pixel lanes are combined with wave shuffles,
+// the four waves through LDS, in a fixed order.
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy,
                                                          float* __restrict__ slab, int B, int S, int C0,
                                                          int pix_per_block) {
-  constexpr int ks = KS, TT = KS * KS;
-  __shared__ float red[256 * TT];
-  const int taps = ks * ks, pad = ks / 2;
-  const int lanes_c = C0;                 // threads along c
-  const int pl = 256 / lanes_c;           // pixel lanes
-  const int c = threadIdx.x % lanes_c, pj = threadIdx.x / lanes_c;
+  constexpr int TT = KS * KS, pad = KS / 2, EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];           // [4 waves][C0][TT]
+  const int NSL = C0 / EP, PLN = 256 / NSL;          // channel slots, pixel lanes (C0 / EP divides 64)
+  const int slot = threadIdx.x % NSL, pl = threadIdx.x / NSL;
   const long long npix = (long long)B * S * S;
   const long long p0 = (long long)blockIdx.x * pix_per_block;
-  float acc[TT];
+  long long pend = p0 + pix_per_block;
+  if (pend > npix) pend = npix;
+  float acc[EP][TT];
 #pragma unroll
-  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
-  if (pj < pl) {
-    for (long long pp = p0 + pj; pp < p0 + pix_per_block && pp < npix; pp += pl) {
-      const int xx = (int)(pp % S), yy = (int)((pp / S) % S), b = (int)(pp / ((long long)S * S));
-      const float g = Elem<T>::to_f(dy[(size_t)pp * C0 + c]);
+  for (int e = 0; e < EP; ++e)
 #pragma unroll
-      for (int ky = 0; ky < ks; ++ky)
+    for (int t = 0; t < TT; ++t) acc[e][t] = 0.f;
+  long long pp = p0 + pl;
+  int x = (int)(pp % S), y = (int)((pp / S) % S), b = (int)(pp / ((long long)S * S));
+#pragma unroll 2
+  for (; pp < pend; pp += PLN) {
+    const V g = *reinterpret_cast<const V*>(dy + (size_t)pp * C0 + slot * EP);
+    float v[TT];
+    const float* ib = img + (size_t)b * S * S;
 #pragma unroll
-        for (int kx = 0; kx < ks; ++kx) {
-          const int iy = yy + ky - pad, ix = xx + kx - pad;
-          const float v = (iy >= 0 && iy < S && ix >= 0 && ix < S) ? img[((size_t)b * S + iy) * S + ix] : 0.f;
-          acc[ky * ks + kx] = fmaf(g, v, acc[ky * ks + kx]);
-        }
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int iy = y + ky - pad, ix = x + kx - pad;
+        const bool ok = iy >= 0 && iy < S && ix >= 0 && ix < S;
+        const float t = ib[ok ? iy * S + ix : 0];
+        v[ky * KS + kx] = ok ? t : 0.f;
+      }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const float ge = Elem<T>::to_f(g[e]);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) acc[e][t] = fmaf(ge, v[t], acc[e][t]);
     }
+    x += PLN;
+    while (x >= S) { x -= S; if (++y == S) { y = 0; ++b; } }
   }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-  for (int t = 0; t < TT; ++t) red[threadIdx.x * TT + t] = acc[t];
+  for (int e = 0; e < EP; ++e)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      float a = acc[e][t];
+      for (int o = NSL; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      if (lane < NSL) red[(wid * C0 + slot * EP + e) * TT + t] = a;
+    }
   __syncthreads();
-  if (threadIdx.x < lanes_c) {
-    for (int t = 0; t < taps; ++t) {
-      float s = 0.f;
-      for (int j = 0; j < pl; ++j) s += red[(j * lanes_c + threadIdx.x) * TT + t];
-      slab[(size_t)blockIdx.x * C0 * taps + threadIdx.x * taps + t] = s;
-    }
-  }
+  for (int i = threadIdx.x; i < C0 * TT; i += 256)
+    slab[(size_t)blockIdx.x * C0 * TT + i] = (red[i] + red[C0 * TT + i]) + (red[2 * C0 * TT + i] + red[3 * C0 * TT + i]);
 }
 
 // out[i] (+)= sum_s slab[s*n + i]
@@ -283,14 +302,16 @@ extern "C" int pwr_stem_conv_wgrad_blocks(int B, int S) {
 
 extern "C" int pwr_stem_conv_wgrad(const float* img, const void* dy, float* slab, float* dw, int accumulate, int B, int S,
                                    int C0, int ksize, int dtype, void* stream) {
-  if (C0 > 256 || 256 % C0) return PWR_EUNSUPPORTED;
+  const int EPh = dtype == PWR_BF16 ? 8 : 4;
+  if (C0 % EPh || 64 % (C0 / EPh)) return PWR_EUNSUPPORTED;
+  const size_t shw = (size_t)4 * C0 * ksize * ksize * sizeof(float);
   const int nb = pwr_stem_conv_wgrad_blocks(B, S);
   const long long npix = (long long)B * S * S;
   const int ppb = (int)((npix + nb - 1) / nb);
   hipStream_t s = (hipStream_t)stream;
 #define PWR_STEM_W(KS_) \
-  if (dtype == PWR_BF16) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, KS_>), dim3(nb), dim3(256), 0, s, img, (const bf16_t*)dy, slab, B, S, C0, ppb); \
-  else hipLaunchKernelGGL((stem_wgrad_kernel<float, KS_>), dim3(nb), dim3(256), 0, s, img, (const float*)dy, slab, B, S, C0, ppb)
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, KS_>), dim3(nb), dim3(256), shw, s, img, (const bf16_t*)dy, slab, B, S, C0, ppb); \
+  else hipLaunchKernelGGL((stem_wgrad_kernel<float, KS_>), dim3(nb), dim3(256), shw, s, img, (const float*)dy, slab, B, S, C0, ppb)
   if (ksize == 1) { PWR_STEM_W(1); } else if (ksize == 3) { PWR_STEM_W(3); } else if (ksize == 5) { PWR_STEM_W(5); } else return PWR_EUNSUPPORTED;
   const int n = C0 * ksize * ksize;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slab, dw, nb, n, accumulate);
