@@ -180,7 +180,8 @@ int pwr_make_targets(const float* uvd, const float* label_img, const float* mask
  * Forward writes what the unfused sequence (pwr_norm_stats + pwr_conv_fwd, three times) writes: the pre-norm conv outputs
  * t1, t2 [B,H,W,C/2] (NULL to skip), the three [4][B][C] norm states and out [B,H,W,C].  wa/wb/wc: kind-0 weight packs.
  * Backward takes g_out = dL/d out and writes dt2, dt1 (the dy operands of the weight gradients of conv b / conv a), dx
- * (skip connection included) and the per-sample norm sums [B][2][C] for pwr_norm_param_grad; w*_d: kind-1 packs.
+ * (skip connection included), the per-sample norm sums [B][2][C] and (bias_sums != NULL) the per-sample column sums of g_out
+ * [B][C], all reduced over the batch by pwr_resblock_param_grads; w*_d: kind-1 packs.
  * ------------------------------------------------------------------------------------------- */
 int pwr_resblock_small_supported(int H, int W, int C, int norm_mode, int dtype);
 int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* out, const void* wa, const void* wb, const void* wc,
@@ -190,8 +191,13 @@ int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* out, const v
                            float eps, int dtype, void* stream);
 int pwr_resblock_bwd_small(const void* gout, const void* x, const void* t1, const void* t2, void* dx, void* dt1, void* dt2,
                            const void* wc_d, const void* wb_d, const void* wa_d, const float* state_a, const float* state_b,
-                           const float* state_c, float* sums_a, float* sums_b, float* sums_c, int B, int H, int W, int C,
-                           int dtype, void* stream);
+                           const float* state_c, float* sums_a, float* sums_b, float* sums_c, float* bias_sums, int B, int H, int W,
+                           int C, int dtype, void* stream);
+/* batch reduction of the per-sample sums of pwr_resblock_bwd_small in one launch: dgamma / dbeta of the three norms and, from
+ * bias_sums [B][C] (per-sample column sums of g_out; NULL to skip), the bias gradient of conv c */
+int pwr_resblock_param_grads(const float* sums_a, const float* sums_b, const float* sums_c, const float* bias_sums, float* dgamma_a,
+                             float* dbeta_a, float* dgamma_b, float* dbeta_b, float* dgamma_c, float* dbeta_c, float* dbias_c,
+                             int B, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hourglass plumbing (model.py:40, :45-47), NHWC.

@@ -495,21 +495,23 @@ struct Engine {
     if (tr) {
       std::vector<Op> blk;
       std::swap(blk, bwd_cur);
-      conv_bwd(r.t2, &r.nc, r.cc, out, true, false, false);     // side stream: dW_c, db_c (need only out.g)
+      const size_t bsum = alloc((size_t)B * x.C * 4);           // per-sample column sums of out.g (bias gradient of conv c)
+      conv_bwd(r.t2, &r.nc, r.cc, out, false, false, false);    // side stream: dW_c (needs only out.g)
       bwd_cur.push_back([=](Ctx& c) {
         return pwr_resblock_bwd_small(c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
                                       c.arena + rb.t1.goff, c.arena + rb.t2.goff, c.packs + rb.cc.pack_d, c.packs + rb.cb.pack_d,
                                       c.packs + rb.ca.pack_d, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
                                       (float*)(c.arena + rb.nc.state), (float*)(c.arena + rb.na.sums), (float*)(c.arena + rb.nb.sums),
-                                      (float*)(c.arena + rb.nc.sums), Bc, x.H, x.W, x.C, dt, c.stream);
+                                      (float*)(c.arena + rb.nc.sums), (float*)(c.arena + bsum), Bc, x.H, x.W, x.C, dt, c.stream);
       });
       conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, false, false);   // side stream: dW_b from t2.g
       conv_bwd(x, &r.na, r.ca, r.t1, false, false, false);      // side stream: dW_a from t1.g
       bwd_cur.push_back([=](Ctx& c) {
         return run_on_side(c, [=](Ctx& c2) {
-          int rc = pwr_norm_param_grad((float*)(c2.arena + rb.na.sums), c2.grads + rb.na.gamma, c2.grads + rb.na.beta, Bc, rb.na.C, 0, c2.stream);
-          if (!rc) rc = pwr_norm_param_grad((float*)(c2.arena + rb.nb.sums), c2.grads + rb.nb.gamma, c2.grads + rb.nb.beta, Bc, rb.nb.C, 0, c2.stream);
-          if (!rc) rc = pwr_norm_param_grad((float*)(c2.arena + rb.nc.sums), c2.grads + rb.nc.gamma, c2.grads + rb.nc.beta, Bc, rb.nc.C, 0, c2.stream);
+          int rc = pwr_resblock_param_grads((float*)(c2.arena + rb.na.sums), (float*)(c2.arena + rb.nb.sums), (float*)(c2.arena + rb.nc.sums),
+                                            (float*)(c2.arena + bsum), c2.grads + rb.na.gamma, c2.grads + rb.na.beta, c2.grads + rb.nb.gamma,
+                                            c2.grads + rb.nb.beta, c2.grads + rb.nc.gamma, c2.grads + rb.nc.beta, c2.grads + rb.cc.b, Bc, x.C,
+                                            c2.stream);
           return rc;
         });
       });

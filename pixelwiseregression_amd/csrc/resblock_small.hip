@@ -34,6 +34,7 @@ struct RbBwdParams {
   const char* wcd; const char* wbd; const char* wad;         // kind-1 (data-gradient) packs
   const float* sa; const float* sb; const float* sc;
   float* sums_a; float* sums_b; float* sums_c;                // [B][2][C] per-sample (sum g, sum g*xhat)
+  float* bias_sums;                                           // [B][C] per-sample column sums of g_out (bias gradient of conv c), or null
   int B;
 };
 
@@ -421,6 +422,24 @@ __global__ __launch_bounds__(256) void resblock_bwd_small_kernel(RbBwdParams p) 
       const int px = pl + 16 * k;
       if (px < HW) *reinterpret_cast<bf16x8*>(R + px * G::P128 + slot * 16) = v[k];
     }
+    if (p.bias_sums) {   // db_c[b][c] = sum over pixels of g_out (conv c's bias gradient, summed over b by rb_param_grad_kernel)
+      float s[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPX; ++k) {
+        const int px = pl + 16 * k;
+        if (px < HW) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += (float)v[k][e];
+        }
+      }
+      rb_reduce16<16>(s, red, slot);
+      if (pl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p.bias_sums[(size_t)b * 128 + slot * 8 + e] = s[e];
+      }
+    }
   }
   rb_wait_sync();
   // ---- g wrt a2 = g_out x Wc^T ; norm-backward c -> dt2
@@ -460,9 +479,47 @@ __global__ __launch_bounds__(256) void resblock_bwd_small_kernel(RbBwdParams p) 
                             p.sums_a + (size_t)b * 2 * 128, nullptr, 0, red);
 }
 
+// dst[c] = sum_b src[b * stride + c]  (fixed order), one block per job: the three norms' dgamma / dbeta and conv c's bias
+struct RbPgJobs { const float* src[7]; float* dst[7]; int stride[7]; int C[7]; int B; };
+__global__ __launch_bounds__(128) void rb_param_grad_kernel(RbPgJobs j) {
+  const int k = blockIdx.x, c = threadIdx.x;
+  if (!j.dst[k] || c >= j.C[k]) return;
+  const float* s = j.src[k] + c;
+  const int st = j.stride[k];
+  float t = 0.f;
+  int b = 0;
+  for (; b + 8 <= j.B; b += 8) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = s[(size_t)(b + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += a[u];
+  }
+  for (; b < j.B; ++b) t += s[(size_t)b * st];
+  j.dst[k][c] = t;
+}
+
 }  // namespace pwr
 
 using namespace pwr;
+
+// Batch reduction of everything pwr_resblock_bwd_small left per sample: dgamma / dbeta of the three norms ([B][2][C] sums) and
+// the bias gradient of conv c (bias_sums [B][C], NULL to skip).  One launch.
+extern "C" int pwr_resblock_param_grads(const float* sums_a, const float* sums_b, const float* sums_c, const float* bias_sums,
+                                        float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, float* dgamma_c,
+                                        float* dbeta_c, float* dbias_c, int B, int C, void* stream) {
+  if (C > 128) return PWR_EUNSUPPORTED;
+  const int Fh = C / 2;
+  RbPgJobs j;
+  const float* srcs[7] = {sums_a + C, sums_a, sums_b + Fh, sums_b, sums_c + Fh, sums_c, bias_sums};
+  float* dsts[7] = {dgamma_a, dbeta_a, dgamma_b, dbeta_b, dgamma_c, dbeta_c, bias_sums ? dbias_c : nullptr};
+  const int strides[7] = {2 * C, 2 * C, 2 * Fh, 2 * Fh, 2 * Fh, 2 * Fh, C};
+  const int Cs[7] = {C, C, Fh, Fh, Fh, Fh, C};
+  for (int k = 0; k < 7; ++k) { j.src[k] = srcs[k]; j.dst[k] = dsts[k]; j.stride[k] = strides[k]; j.C[k] = Cs[k]; }
+  j.B = B;
+  hipLaunchKernelGGL(rb_param_grad_kernel, dim3(7), dim3(128), 0, (hipStream_t)stream, j);
+  return (int)hipGetLastError();
+}
 
 extern "C" int pwr_resblock_small_supported(int H, int W, int C, int norm_mode, int dtype) {
   static const bool on = [] { const char* e = getenv("PWR_RESBLOCK_FUSED"); return e ? atoi(e) != 0 : true; }();
@@ -492,15 +549,15 @@ extern "C" int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* o
 
 extern "C" int pwr_resblock_bwd_small(const void* gout, const void* x, const void* t1, const void* t2, void* dx, void* dt1, void* dt2,
                                       const void* wc_d, const void* wb_d, const void* wa_d, const float* state_a, const float* state_b,
-                                      const float* state_c, float* sums_a, float* sums_b, float* sums_c, int B, int H, int W, int C,
-                                      int dtype, void* stream) {
+                                      const float* state_c, float* sums_a, float* sums_b, float* sums_c, float* bias_sums, int B, int H,
+                                      int W, int C, int dtype, void* stream) {
   if (!(dtype == PWR_BF16 && C == 128 && H == W && (W == 2 || W == 4 || W == 8 || W == 16))) return (int)hipErrorInvalidValue;
   RbBwdParams p;
   p.gout = (const bf16_t*)gout; p.x = (const bf16_t*)x; p.t1 = (const bf16_t*)t1; p.t2 = (const bf16_t*)t2;
   p.dx = (bf16_t*)dx; p.dt1 = (bf16_t*)dt1; p.dt2 = (bf16_t*)dt2;
   p.wcd = (const char*)wc_d; p.wbd = (const char*)wb_d; p.wad = (const char*)wa_d;
   p.sa = state_a; p.sb = state_b; p.sc = state_c;
-  p.sums_a = sums_a; p.sums_b = sums_b; p.sums_c = sums_c;
+  p.sums_a = sums_a; p.sums_b = sums_b; p.sums_c = sums_c; p.bias_sums = bias_sums;
   p.B = B;
   hipStream_t s = (hipStream_t)stream;
   if (W == 16) hipLaunchKernelGGL((resblock_bwd_small_kernel<4>), dim3(B), dim3(256), 0, s, p);

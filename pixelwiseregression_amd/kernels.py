@@ -302,10 +302,14 @@ def resblock_bwd_small(gout, x, t1, t2, packs_d, states):
     dev = x.device
     dx, dt1, dt2 = torch.empty_like(x), torch.empty_like(t1), torch.empty_like(t2)
     sums = [torch.empty(B, 2, c, dtype=torch.float32, device=dev) for c in (C, C // 2, C // 2)]
+    bsum = torch.empty(B, C, dtype=torch.float32, device=dev)
     _lib.check(l.pwr_resblock_bwd_small(_p(gout), _p(x), _p(t1), _p(t2), _p(dx), _p(dt1), _p(dt2), _p(packs_d[2]), _p(packs_d[1]),
                                         _p(packs_d[0]), _p(states[0]), _p(states[1]), _p(states[2]), _p(sums[0]), _p(sums[1]),
-                                        _p(sums[2]), B, H, W, C, _dt(x), _s(x)), "pwr_resblock_bwd_small")
-    return dx, dt1, dt2, sums
+                                        _p(sums[2]), _p(bsum), B, H, W, C, _dt(x), _s(x)), "pwr_resblock_bwd_small")
+    pg = [torch.empty(c, dtype=torch.float32, device=dev) for c in (C, C, C // 2, C // 2, C // 2, C // 2, C)]
+    _lib.check(l.pwr_resblock_param_grads(_p(sums[0]), _p(sums[1]), _p(sums[2]), _p(bsum), *[_p(t) for t in pg], B, C, _s(x)),
+               "pwr_resblock_param_grads")
+    return dx, dt1, dt2, sums, pg   # pg = dgamma_a, dbeta_a, dgamma_b, dbeta_b, dgamma_c, dbeta_c, dbias_c
 
 
 def conv_stats_chunks(H, W, Cin, Cout, ksize, stride=1, mode=0, dtype=BF16):

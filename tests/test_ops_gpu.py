@@ -441,7 +441,7 @@ def test_resblock_small_fused_vs_unfused(B, H):
     # ---- fused
     fout, ft1, ft2, fst = K.resblock_fwd_small(xd, wf, bd, gmd, bed)
     # (backward on the UNFUSED forward's tensors and states: identical ReLU masks, so only summation order differs)
-    fdx, fdt1, fdt2, fsums = K.resblock_bwd_small(gd_, xd, t1, t2, wd, [sa, sb, sc])
+    fdx, fdt1, fdt2, fsums, fpg = K.resblock_bwd_small(gd_, xd, t1, t2, wd, [sa, sb, sc])
     torch.cuda.synchronize()
 
     def close(a, b, rel, what):
@@ -454,6 +454,9 @@ def test_resblock_small_fused_vs_unfused(B, H):
     for s_, dg, db, what in ((fsums[0], dga, dba, "a"), (fsums[1], dgb, dbb, "b"), (fsums[2], dgc, dbc, "c")):
         close(s_[:, 1].sum(0), dg, 3e-2, "dgamma " + what)
         close(s_[:, 0].sum(0), db, 3e-2, "dbeta " + what)
+    for got, ref_, what in zip(fpg[:6], (dga, dba, dgb, dbb, dgc, dbc), ("dga", "dba", "dgb", "dbb", "dgc", "dbc")):
+        close(got, ref_, 3e-2, "param grads kernel " + what)
+    close(fpg[6], K.colsum_nhwc(gd_), 1e-3, "bias gradient of conv c")
 
     # ---- float64 torch ResBlock on the bf16-rounded operands
     xq = q(x, dt).requires_grad_(True)
