@@ -195,12 +195,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     int buf;
     if constexpr (DMA) {
       // stage `it` has landed once all but this wave's newest stage (it+1) are retired; after the barrier every wave's
-      // share has landed and everybody is done reading stage it-1, which the DMA for it+2 may now overwrite
+      // share has landed and everybody is done reading stage it-1, which the DMA for it+2 may now overwrite.
+      // "Done reading" needs the lgkmcnt(0): the compiler sinks the last MFMAs of step it-1 (and the wait for their fragment
+      // reads) below this barrier, and a ds_read that is merely ISSUED can still be queued in the (saturated) LDS pipe when
+      // another wave's DMA for it+2 lands on the same bytes -- seen as one wrong output channel of half a tile once per
+      // ~10^4 launches (tools/determinism*.py).
       if (it + 1 < ITERS) {
-        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

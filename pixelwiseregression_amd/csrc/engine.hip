@@ -185,9 +185,15 @@ struct Engine {
     if (own) { hipStreamSynchronize(own); hipStreamDestroy(own); hipEventDestroy(ev_in); hipEventDestroy(ev_out); own = nullptr; }
   }
 
-  size_t alloc(size_t bytes) {
+  // arena layout record (debugging aid: pwr_engine_layout)
+  struct AllocRec { size_t off, bytes; std::string tag; };
+  std::vector<AllocRec> layout;
+  std::string scope = "";
+  int cur_stage = -1;
+  size_t alloc(size_t bytes, const char* tag = "") {
     size_t o = arena_bytes;
     arena_bytes += (bytes + 255) / 256 * 256;
+    layout.push_back({o, bytes, scope + ":" + tag + "#" + std::to_string(layout.size())});
     return o;
   }
   size_t alloc_pack(size_t bytes) {
@@ -198,8 +204,11 @@ struct Engine {
   Tn tensor(int H, int W, int C, bool grad) {
     Tn t;
     t.H = H; t.W = W; t.C = C;
-    t.off = alloc((size_t)B * H * W * C * esz);
-    if (grad) t.goff = alloc((size_t)B * H * W * C * esz);
+    char tg[64];
+    snprintf(tg, sizeof tg, "act%dx%dx%d", H, W, C);
+    t.off = alloc((size_t)B * H * W * C * esz, tg);
+    tg[0] = 'g'; tg[1] = 'r'; tg[2] = 'd';
+    if (grad) t.goff = alloc((size_t)B * H * W * C * esz, tg);
     return t;
   }
   long long take_param(long long numel) {
@@ -244,8 +253,8 @@ struct Engine {
     n.gamma = take_param(C);
     n.beta = take_param(C);
     if (norm_mode == 1) { n.rm = take_buffer(); n.rv = take_buffer(); }
-    n.state = alloc((size_t)4 * B * C * 4);
-    if (training) n.sums = alloc((size_t)2 * B * C * 4);
+    n.state = alloc((size_t)4 * B * C * 4, "nstate");
+    if (training) n.sums = alloc((size_t)2 * B * C * 4, "nsums");
     return n;   // (the backward partial slab is sized per tensor in norm_bwd)
   }
   int splits_for(int M, int cin, int cout, int k) const {
@@ -257,7 +266,10 @@ struct Engine {
     const bool w3 = dtype == PWR_BF16 && k == 3 && M % 32 == 0;
     const int tiles = (w3 ? 3 : k * k) * per;
     static const int w3_target = [] { const char* e = getenv("PWR_WGRAD3_SLOTS"); return e ? atoi(e) : 256; }();
-    int s = w3 ? (w3_target / tiles) / 8 * 8 : (512 + tiles - 1) / tiles;   // w3: one wave of workgroups, whole XCD groups (no tail)
+    // w3: one wave of workgroups, whole XCD groups (no tail).  The <= 64-channel kernels fit two workgroups per CU; on the big
+    // stem maps (>= 2^18 pixels: 205 K steps per workgroup otherwise, at the tail of the step) they get two waves of them.
+    const int target = (w3 && cout <= 64 && M >= (1 << 18)) ? 2 * w3_target : w3_target;
+    int s = w3 ? (target / tiles) / 8 * 8 : (512 + tiles - 1) / tiles;
     if (w3 && s < 8) s = 8;
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
     if (s > maxs) s = maxs;
@@ -265,6 +277,11 @@ struct Engine {
     return s;
   }
 
+  // A/B switch: bit 0 = forward statistics from the conv epilogues, bit 1 = norm-backward reductions from the data-gradient epilogues
+  static int stats_mask() {
+    static const int m = [] { const char* e = getenv("PWR_CONV_STATS_MASK"); return e ? atoi(e) : 3; }();
+    return m;
+  }
   // ---- norm statistics of tensor t (forward) and its backward (g -> dy, in place in t.goff, + addend)
   void norm_fwd_sizes(const Tn& t) {
     const size_t pb = pwr_norm_partial_bytes(B, t.H * t.W, t.C);
@@ -292,8 +309,25 @@ struct Engine {
     Engine* E = this;
     if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
     if (chunks > 0) {
+      static const bool dbg = getenv("PWR_DEBUG_NB") != nullptr;
+      const bool dbg_here = dbg && (scope.find("plane") != std::string::npos || scope.find("depth") != std::string::npos);
+      const size_t dP = dbg_here ? alloc((size_t)B * chunks * 2 * C * 4, "dbg_partial") : 0;
+      const size_t dS = dbg_here ? alloc((size_t)2 * B * C * 4, "dbg_S") : 0;
+      const size_t dG = dbg_here ? alloc((size_t)B * HW * C * esz, "dbg_g") : 0;
+      const int es = esz;
       bwd_cur.push_back([=](Ctx& c) {
         const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+        if (dbg_here) {
+          hipMemcpyAsync(c.arena + dP, c.arena + E->scr_cpartial, (size_t)Bc * chunks * 2 * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
+          hipMemcpyAsync(c.arena + dG, c.arena + t.goff, (size_t)Bc * HW * C * es, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
+          int rc = pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_cpartial),
+                                         chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
+                                         has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
+                                         c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
+          hipMemcpyAsync(c.arena + dS, c.arena + E->scr_S1, (size_t)Bc * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
+          hipMemcpyAsync(c.arena + dS + (size_t)Bc * C * 4, c.arena + E->scr_S2, (size_t)Bc * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
+          return rc;
+        }
         if (mode == 2)   // eval-mode batch norm: statistics are constants, the plain path handles it
           return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                               (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), has_addend ? c.arena + addend_goff : nullptr,
@@ -347,7 +381,7 @@ struct Engine {
     const NormL n = has_nr ? *nr : NormL{};
     const bool has_res = residual != nullptr;
     const size_t roff = has_res ? residual->off : 0;
-    const int chunks = out_norm ? pwr_conv_stats_chunks(x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride, 0, dtype) : 0;
+    const int chunks = (out_norm && (stats_mask() & 1)) ? pwr_conv_stats_chunks(x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride, 0, dtype) : 0;
     if (chunks > 0) {
       const NormL on = *out_norm;
       const size_t need = (size_t)B * chunks * 3 * cv.Cout * 4;
@@ -390,7 +424,7 @@ struct Engine {
   // Returns the slab rows per sample of the norm-backward reductions that the data-gradient launch wrote for `nr`
   // (to be passed to norm_bwd), 0 if it did not.
   int dgrad_stats_chunks(const NormL* nr, const ConvL& cv, const Tn& y, bool accumulate_dx) const {
-    if (!nr || accumulate_dx || cv.stride != 1) return 0;
+    if (!nr || accumulate_dx || cv.stride != 1 || !(stats_mask() & 2)) return 0;
     return pwr_conv_stats_chunks(y.H, y.W, cv.Cout, cv.Cin, cv.k, 1, 0, dtype);
   }
   int conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx) {
@@ -528,6 +562,7 @@ struct Engine {
   // ---- Hourglass (model.py:25-47)
   Tn hourglass(const Tn& x, int lvl) {
     const bool tr = training;
+    scope = "s" + std::to_string(cur_stage) + ".hg" + std::to_string(lvl);
     const int Bc = B, dt = dtype;
     Tn a = resblock(x);
     Tn h0 = tensor(a.H / 2, a.W / 2, a.C, tr);
@@ -564,6 +599,7 @@ struct Engine {
     const bool tr = training;
     const int Bc = B, dt = dtype, Jc = J;
     Head h;
+    scope = "s" + std::to_string(stage_idx) + (out_sel == 0 ? ".plane" : ".depth");
     h.c0 = conv_params(F, F, ks, 1, true, true); h.n0 = norm_params(F);
     h.c1 = conv_params(F, F, ks, 1, true, true); h.n1 = norm_params(F);
     h.c2 = conv_params(F, F, ks, 1, true, true); h.n2 = norm_params(F);
@@ -578,12 +614,13 @@ struct Engine {
                           1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
     });
     const int Jp = (J + 7) / 8 * 8;
-    h.gT = tr ? alloc((size_t)B * P * P * Jp * esz) : 0;
+    h.gT = tr ? alloc((size_t)B * P * P * Jp * esz, "gT") : 0;
     return h;
   }
   // g_nchw_off: arena offset of the fp32 [B,J,N] gradient of the head's output map
   void head_bwd(const Tn& f, const Head& h, size_t g_nchw_off, bool accumulate_df) {
     const int Bc = B, dt = dtype, Jc = J, Pc = P;
+    scope = "s" + std::to_string(cur_stage) + (accumulate_df ? ".depth.bwd" : ".plane.bwd");
     const int Jp = (J + 7) / 8 * 8;
     const int M = B * P * P;
     const int splits = splits_for(M, F, Jp, ks);
@@ -591,7 +628,7 @@ struct Engine {
     Engine* E = this;
     const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3; const size_t gT = h.gT;
     const int nm = norm_mode;
-    const int ch3 = pwr_conv_stats_chunks(P, P, Jp, c3.Cin, c3.k, 1, 0, dtype);
+    const int ch3 = (stats_mask() & 2) ? pwr_conv_stats_chunks(P, P, Jp, c3.Cin, c3.k, 1, 0, dtype) : 0;
     if (ch3 > 0 && (size_t)B * ch3 * 2 * c3.Cin * 4 > need_cpartial) need_cpartial = (size_t)B * ch3 * 2 * c3.Cin * 4;
     bwd_cur.push_back([=](Ctx& c) {
       int rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + g_nchw_off), c.arena + gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
@@ -627,6 +664,7 @@ struct Engine {
     if (stages > 8) { err = "at most 8 stages"; return false; }
     if (J > 47) { err = "at most 47 joints"; return false; }
     Engine* E = this;
+    scope = "stem";
     // ---- stem (model.py:164-187)
     std::vector<ConvL> sc;
     std::vector<NormL> sn;
@@ -681,6 +719,8 @@ struct Engine {
     const NormL nstem = sn.back();
     for (int s = 0; s < stages; ++s) {
       StageRec& R = recs[s];
+      cur_stage = s;
+      scope = "s" + std::to_string(s) + ".in";
       Tn x0;
       ConvL cin;
       const int Cp = (2 * J + 1 + 7) / 8 * 8;
@@ -707,7 +747,8 @@ struct Engine {
       std::vector<Op> hg_bwd;
       std::swap(hg_bwd, bwd_cur);
       R.w_off = method == 0 ? take_param(J) : -1;
-      R.z = alloc((size_t)B * J * N * 4);
+      scope = "s" + std::to_string(s) + ".dec";
+      R.z = alloc((size_t)B * J * N * 4, "z");
       Head hp = head_fwd(f, R.z, 0, s);
       Head hd = head_fwd(f, 0, 1, s);
       const size_t zoff = R.z;
@@ -717,9 +758,10 @@ struct Engine {
                               c.out_uvd[s], Bc, Jc, Pc, meth, c.stream);
       });
       if (tr) {
-        R.gz = alloc((size_t)B * J * N * 4); R.gDt = alloc((size_t)B * J * N * 4);
-        R.gH = alloc((size_t)B * J * N * 4); R.gD = alloc((size_t)B * J * N * 4);
-        R.gwp = alloc((size_t)B * J * 4);
+        scope = "s" + std::to_string(s) + ".dec";
+        R.gz = alloc((size_t)B * J * N * 4, "gz"); R.gDt = alloc((size_t)B * J * N * 4, "gDt");
+        R.gH = alloc((size_t)B * J * N * 4, "gH"); R.gD = alloc((size_t)B * J * N * 4, "gD");
+        R.gwp = alloc((size_t)B * J * 4, "gwp");
         const StageRec Rc = R;
         const bool last = s == stages - 1;
         const size_t zero_uvd = alloc((size_t)B * J * 3 * 4);
@@ -768,11 +810,12 @@ struct Engine {
     if (pcur != poff.size()) { err = "parameter table longer than the network"; return false; }
     if (!err.empty()) return false;
     // shared scratch
-    scr_partial = alloc(need_partial);
-    scr_S1 = alloc(need_sc); scr_S2 = alloc(need_sc);
-    scr_cpartial = alloc(need_cpartial);
+    scope = "scratch";
+    scr_partial = alloc(need_partial, "partial");
+    scr_S1 = alloc(need_sc, "S1"); scr_S2 = alloc(need_sc, "S2");
+    scr_cpartial = alloc(need_cpartial, "cpartial");
     scr_slab_bytes = (scr_slab_bytes + 255) / 256 * 256;
-    scr_slab = alloc(scr_slab_bytes * Ctx::kMaxSide);
+    scr_slab = alloc(scr_slab_bytes * Ctx::kMaxSide, "slab");
     ctx.slab_stride = scr_slab_bytes;
     // segments in execution order: last stage first, stem last
     if (tr) {
@@ -818,6 +861,15 @@ extern "C" void pwr_engine_destroy(void* h) {
   if (e->ctx.ev_fork) hipEventDestroy(e->ctx.ev_fork);
   e->destroy_graphs();
   delete e;
+}
+// Debugging aid: the arena layout as text lines "offset bytes tag".  Returns the number of bytes needed (incl. the NUL);
+// writes at most cap bytes.
+extern "C" size_t pwr_engine_layout(void* h, char* buf, size_t cap) {
+  Engine* e = (Engine*)h;
+  std::string s;
+  for (auto& r : e->layout) s += std::to_string(r.off) + " " + std::to_string(r.bytes) + " " + r.tag + "\n";
+  if (buf && cap) { const size_t n = s.size() + 1 < cap ? s.size() + 1 : cap; memcpy(buf, s.c_str(), n); buf[n - 1] = 0; }
+  return s.size() + 1;
 }
 extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
 extern "C" size_t pwr_engine_pack_bytes(void* h) { return ((Engine*)h)->pack_bytes; }

@@ -110,3 +110,25 @@ def test_native_step_first_update_matches_reference_loop(opt, alpha):
     for _ in range(15):
         step.epoch_end()
     assert abs(step.lr - lr * 0.2) < 1e-12
+
+
+def test_train_step_is_bitwise_reproducible():
+    """Every reduction in the engine has a fixed order (no float atomics), so identical steps must give identical gradients.
+    (lr 0: the weights never change.)  A short screen; tools/determinism.py is the long one (it found a 1-in-3000-steps
+    LDS-DMA write-after-read race in the 3x3 patch conv, see csrc/conv_patch.hip)."""
+    from pixelwiseregression_amd import PixelwiseRegression
+    from pixelwiseregression_amd.synthetic import make_batch
+    from pixelwiseregression_amd.train import TrainStep
+    torch.manual_seed(0)
+    m = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, norm_method="instance").to(DEV).set_precision("bf16").train()
+    b = make_batch(16, 14, S=128, seed=5, device=DEV)
+    ts = TrainStep(m, opt="sgd", lr=0.0)
+    args = (b["img"], b["label_img"], b["mask"], b["uvd"])
+    ts(*args)
+    g0 = m.flat_grad().clone()
+    l0 = ts.loss.clone()
+    bad = torch.zeros((), device=DEV)
+    for _ in range(300):
+        ts(*args)
+        bad += (m.flat_grad() != g0).any().float() + (ts.loss != l0).any().float()
+    assert bad.item() == 0
