@@ -14,6 +14,7 @@ struct ConvParams {
   float* y_nchw;          // [B,Cout,Ho,Wo] fp32 or null
   int B, H, W, Cin, Ho, Wo, Cout, CoutPad;
   int ksize, stride, pad, mode, relu_in, KCH, M;
+  long long* stamps = nullptr;   // debugging aid (pwr_debug_set_stamps): 8 x int64 per workgroup = phase time stamps + HW ids
   // ---- optional per-channel column statistics of the OUTPUT tile, written by the epilogue (one slab entry per workgroup;
   // a workgroup's 128 output pixels lie in one sample).  nb_partial: [(b*chunks + chunk)*2 + {0,1}][Cout] fp32.
   // st_partial: [(b*chunks + chunk)*3 + {0,1,2}][Cout] = sum (v - k), sum (v - k)^2, k of the stored output v, with the shift
@@ -177,5 +178,6 @@ static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 :
 bool conv_patch_applicable(const ConvParams& p, int dtype);
 int conv_patch_stats_chunks(const ConvParams& p, int dtype);   // slab rows per sample of the column statistics, 0 = unsupported
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s);
+void set_debug_stamps(long long* ptr);
 
 }  // namespace pwr

@@ -841,13 +841,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
   for (int it = 0; it < PWR_RED_MAXITEMS; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
   const size_t stride = (size_t)taps * CinPad * CoutPad;
-  for (int k = grp; k < S; k += 32) {
-    const float* base = slab + k * stride + co;
+  if (items <= 4) {
+    // 1x1 layers: few items per slab and MANY slabs (S up to 512): keep four slabs' loads in flight per thread
+    int k = grp;
+    for (; k + 96 < S; k += 128) {
+      f32x4 v[4][4];
 #pragma unroll
-    for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
-      if (it < items) {
-        const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
-        if (ci < Cin) acc[it] += *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
+      for (int u = 0; u < 4; ++u) {
+        const float* base = slab + (size_t)(k + 32 * u) * stride + co;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          v[u][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (it < items) {
+            const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
+            if (ci < Cin) v[u][it] = *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[it] += v[u][it];
+    }
+    for (; k < S; k += 32) {
+      const float* base = slab + (size_t)k * stride + co;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (it < items) {
+          const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
+          if (ci < Cin) acc[it] += *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
+        }
+      }
+    }
+  } else {
+    for (int k = grp; k < S; k += 32) {
+      const float* base = slab + k * stride + co;
+#pragma unroll
+      for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
+        if (it < items) {
+          const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
+          if (ci < Cin) acc[it] += *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
+        }
       }
     }
   }
@@ -1019,6 +1053,10 @@ extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias,
   if (rc) return rc;
   return dtype == PWR_BF16 ? pwr::launch_conv<bf16_t>(p, (hipStream_t)stream) : pwr::launch_conv<float>(p, (hipStream_t)stream);
 }
+
+// Debugging aid: while set, every 3x3 patch-conv workgroup writes 8 int64 (s_memtime at start / patch loaded / patch staged /
+// K loop done / end, -, HW_ID, XCC_ID) to stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8].  NULL switches it off.
+extern "C" void pwr_debug_set_stamps(void* stamps) { pwr::set_debug_stamps((long long*)stamps); }
 
 // slab rows per sample that pwr_conv_fwd_stats writes for this conv shape; 0 = the shape cannot produce column statistics
 // (a 128-pixel tile would straddle samples, or the transposed mode)

@@ -19,6 +19,15 @@
 
 namespace pwr {
 
+static long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
+  if (p.stamps && threadIdx.x == 0) {
+    long long* d = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    d[slot] = (long long)__builtin_amdgcn_s_memtime();
+    if (slot == 0) { d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+  }
+}
+
 // Patch pixels are padded by one 16-byte slot: with a pitch of NSLOT*16+16 bytes the 16-lane groups of ds_read_b128
 // (32 consecutive pixels, same channel slot) fall on 16 distinct bank slots WITHOUT an XOR swizzle, so every fragment
 // address is (per-lane base) + (compile-time constant): no vector ALU work in the K loop for the A operand.
@@ -62,6 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+  stamp(p, 0);
 
   // ---- weights of iteration 0 in flight while the patch is staged
   V rb[NB];
@@ -152,7 +162,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     }
   }
   if constexpr (!DMA) store_w(0);
+  stamp(p, 1);
   __syncthreads();     // (drains the two DMA stages in flight as well)
+  stamp(p, 2);
 
   f32x16 acc[MR][NR];
 #pragma unroll
@@ -188,67 +200,115 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     bOff[j][1] = lds_off(wn * NR * 32 + j * 32 + r, 2 + h);
   }
   // fully unrolled over (ky, kx, K chunk): every LDS offset, ring stage and wait count is a compile-time constant
+  if constexpr (DMA) {
+    // Weight ring of three LDS stages filled by LDS-DMA, fragments one K step AHEAD in registers:
+    //   step `it` = [wait: stage it+1 landed (own share), all own LDS reads retired] -> barrier -> DMA for it+3 into the stage
+    //   whose fragments (step it) were read during step it-1 -> issue the 8 fragment reads of step it+1 -> 8 MFMAs of step it
+    //   on registers.
+    // So no MFMA ever waits on an LDS read issued in its own step (two waves per SIMD cannot hide that latency), a DMA has two
+    // steps to land, and a stage is overwritten only after a barrier that every wave reached with lgkmcnt(0): a ds_read that
+    // is merely ISSUED can still be queued in the LDS pipe when another wave's DMA lands on the same bytes (seen with the
+    // earlier read-in-step form as one wrong output channel of half a tile once per ~10^4 launches, tools/determinism*.py).
+    V fa[2][2][MR], fb[2][2][NR];
+    auto frag_load = [&](int it, V (&a)[2][MR], V (&bq)[2][NR]) {
+      const int tap = it / KCH, kch = it - tap * KCH;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const char* lB = wbuf + (it % 3) * WBUF_BYTES;
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int tap = it / KCH, kch = it - tap * KCH;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    int buf;
-    if constexpr (DMA) {
-      // stage `it` has landed once all but this wave's newest stage (it+1) are retired; after the barrier every wave's
-      // share has landed and everybody is done reading stage it-1, which the DMA for it+2 may now overwrite.
-      // "Done reading" needs the lgkmcnt(0): the compiler sinks the last MFMAs of step it-1 (and the wait for their fragment
-      // reads) below this barrier, and a ds_read that is merely ISSUED can still be queued in the (saturated) LDS pipe when
-      // another wave's DMA for it+2 lands on the same bytes -- seen as one wrong output channel of half a tile once per
-      // ~10^4 launches (tools/determinism*.py).
-      if (it + 1 < ITERS) {
-        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          a[ss][i] = *reinterpret_cast<const V*>(aBase[i] + (ky * PW + kx) * PITCH + kch * 64 + ss * 32);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bq[ss][j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
+      }
+    };
+    if (2 < ITERS) dma_w(2, 2);
+    frag_load(0, fa[0], fb[0]);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      // s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (simm16: vmcnt[3:0], expcnt[6:4] = 7 (no wait), lgkmcnt[11:8]): the
+      // compiler's own wait-count pass sees it and does not add an lgkmcnt(0) in front of this step's MFMAs, which would
+      // wait for the reads just issued for the NEXT step (it cannot see through an inline-asm wait).
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      if (it + 2 < ITERS) {
+        if constexpr (NBW == 2) __builtin_amdgcn_s_waitcnt(0x0072);
+        else __builtin_amdgcn_s_waitcnt(0x0071);
       } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0070);
       }
       __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      buf = it % 3;
-      if (it + 2 < ITERS) dma_w(it + 2, (it + 2) % 3);
-    } else {
-      buf = it & 1;
-      if (it + 1 < ITERS) load_w(it + 1);
-    }
-    const char* lB = wbuf + buf * WBUF_BYTES;
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      if (it + 3 < ITERS) dma_w(it + 3, it % 3);
+      if (it + 1 < ITERS) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
+      // pin the order: left alone, the scheduler sinks these reads to just before their first use (shortest live range),
+      // i.e. back into the next step, and hoists that step's MFMAs above the barrier -- the read-then-wait form again
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      V a[MR], bb[NR];
-#pragma unroll
-      for (int i = 0; i < MR; ++i)
-        a[i] = *reinterpret_cast<const V*>(aBase[i] + (ky * PW + kx) * PITCH + kch * 64 + ss * 32);
-#pragma unroll
-      for (int j = 0; j < NR; ++j) bb[j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
-#pragma unroll
-      for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
-          }
-        }
-    }
-    if constexpr (kTwoLevel) {
-      if ((it & 7) == 7 || it + 1 == ITERS) {
+      for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-          for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
+          for (int j = 0; j < NR; ++j) {
+            if constexpr (sizeof(T) == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it & 1][ss][i], fb[it & 1][ss][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][ss][i][e], fb[it & 1][ss][j][e], acc[i][j], 0, 0, 0);
+            }
+          }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kTwoLevel) {
+        if ((it & 7) == 7 || it + 1 == ITERS) {
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
+        }
       }
     }
-    if constexpr (!DMA) {
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int tap = it / KCH, kch = it - tap * KCH;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int buf = it & 1;
+      if (it + 1 < ITERS) load_w(it + 1);
+      const char* lB = wbuf + buf * WBUF_BYTES;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        V a[MR], bb[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          a[i] = *reinterpret_cast<const V*>(aBase[i] + (ky * PW + kx) * PITCH + kch * 64 + ss * 32);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) bb[j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            if constexpr (sizeof(T) == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
+            }
+          }
+      }
+      if constexpr (kTwoLevel) {
+        if ((it & 7) == 7 || it + 1 == ITERS) {
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
+        }
+      }
       if (it + 1 < ITERS) store_w(buf ^ 1);
       __syncthreads();
     }
   }
-  if constexpr (DMA) __syncthreads();
   if constexpr (kTwoLevel) {
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -256,6 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       for (int j = 0; j < NR; ++j) acc[i][j] = acc2[i][j];
   }
 
+  stamp(p, 3);
   // ---- epilogue: accumulators -> LDS (fp32, 64 tile pixels at a time) -> coalesced 16-byte stores
   float* E = reinterpret_cast<float*>(smem);
   constexpr int PASSES = BM / EROWS;
@@ -329,6 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     __syncthreads();
   }
   if constexpr (TW == 32) est.template finish<CPRS, NT>(p, E, b, tr, tiles_img, n0);
+  stamp(p, 4);
 }
 
 // small square maps of the inner hourglass levels (64 -> 64 channels): whole images per tile
@@ -369,6 +431,7 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
   static const bool dma = [] { const char* e = getenv("PWR_PATCH_DMA"); return e ? atoi(e) != 0 : true; }();
+  const_cast<ConvParams&>(p).stamps = g_stamps;
   // fp32 (parity mode) patches leave no room for a third weight stage next to a second workgroup: register staging
   if (dma && sizeof(T) == 2) {
     static const bool big = [] { const char* e = getenv("PWR_PATCH_BIG"); return e ? atoi(e) != 0 : false; }();   // measured: 61 us vs 59 us for the 4x32 tile -> off
@@ -397,6 +460,8 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
   if (p.Cin == 64) return launch_patch_cin<T, 64>(p, s);
   return launch_patch_cin<T, 32>(p, s);
 }
+
+void set_debug_stamps(long long* ptr) { g_stamps = ptr; }
 
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
   if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);

@@ -128,6 +128,7 @@ struct Engine {
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   int use_graph = -1;   // -1 undecided, 0 off, 1 on
+  bool join_each_segment = true;
 
   bool graph_ready() {
     if (use_graph < 0) {
@@ -871,6 +872,7 @@ extern "C" size_t pwr_engine_layout(void* h, char* buf, size_t cap) {
   if (buf && cap) { const size_t n = s.size() + 1 < cap ? s.size() + 1 : cap; memcpy(buf, s.c_str(), n); buf[n - 1] = 0; }
   return s.size() + 1;
 }
+extern "C" void pwr_engine_set_join(void* h, int each_segment) { ((Engine*)h)->join_each_segment = each_segment != 0; }
 extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
 extern "C" size_t pwr_engine_pack_bytes(void* h) { return ((Engine*)h)->pack_bytes; }
 extern "C" int pwr_engine_num_segments(void* h) { return (int)((Engine*)h)->bwd.size(); }
@@ -978,10 +980,11 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
       rc = ops[i](c);
       if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
     }
-    // join: the segment's parameter gradients are complete before anything later on the stream (the data-parallel all-reduce of
-    // this segment; the next segment).  Joining only once per backward was measured 1 % faster but NOT reproducible run to run
-    // (2 of 6 runs diverged): kept per segment.
-    for (int k = 0; c.use_side && k < c.n_side; ++k) {
+    // join: the parameter gradients are complete before anything later on the stream.  Per segment when the caller all-reduces
+    // each segment's slice as it finishes (data-parallel mode, pwr_engine_set_join); otherwise once, after the last segment
+    // (1 % faster: the stem's data-gradient chain does not wait for stage 0's weight gradients).
+    const bool join_now = e->join_each_segment || seg + 1 == (int)e->bwd.size();
+    for (int k = 0; join_now && c.use_side && k < c.n_side; ++k) {
       hipEventRecord(c.ev_join[k], c.side[k]);
       hipStreamWaitEvent((hipStream_t)st, c.ev_join[k], 0);
     }

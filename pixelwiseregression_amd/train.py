@@ -94,6 +94,7 @@ class TrainStep:
         plan.bind(m, grad)
         n = grad.numel()
         ddp = m._ddp
+        l.pwr_engine_set_join(plan.h, 1 if ddp is not None else 0)
         for seg in range(plan.n_seg):
             _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
             if ddp is not None:
