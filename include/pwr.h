@@ -237,6 +237,7 @@ const char* pwr_last_error(void);
 void* pwr_engine_create(const int* cfg, int B, int dtype, int training, const long long* param_off,
                         const long long* param_numel, int n_params, const long long* buffer_off, int n_buffers);
 void pwr_engine_destroy(void* engine);
+void pwr_debug_set_pingpong(int v);   /* debugging aid: force the ping-pong 3x3 conv on (1) / off (0); -1 = default */
 void pwr_debug_set_stamps(void* stamps);   /* debugging aid: per-workgroup phase time stamps of the 3x3 patch conv (8 x int64 each); NULL = off */
 size_t pwr_engine_layout(void* engine, char* buf, size_t cap);   /* debugging aid: arena layout as text lines "offset bytes tag"; returns the size needed */
 void pwr_engine_set_join(void* engine, int each_segment);   /* 1 (default): every backward segment ends with its parameter gradients complete on the stream (needed to all-reduce per segment); 0: only the last one does */

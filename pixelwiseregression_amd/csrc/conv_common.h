@@ -180,4 +180,9 @@ int conv_patch_stats_chunks(const ConvParams& p, int dtype);   // slab rows per 
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s);
 void set_debug_stamps(long long* ptr);
 
+// conv_pingpong.hip
+bool conv_pingpong_applicable(const ConvParams& p, int dtype);
+int launch_conv_pingpong(const ConvParams& p, hipStream_t s);
+void set_debug_pingpong(int v);
+
 }  // namespace pwr

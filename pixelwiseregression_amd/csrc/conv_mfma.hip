@@ -960,6 +960,7 @@ template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   if (p.CoutPad % bn) return PWR_EINVAL;
+  if (conv_pingpong_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_pingpong(p, s);
   if (conv_patch_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
   // mode 1: four parity classes of M/4 rows each, every class padded to whole tiles
   const int mtiles = p.mode == 0 ? (p.M + 127) / 128 : 4 * ((p.M / 4 + 127) / 128);
@@ -1057,6 +1058,8 @@ extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias,
 // Debugging aid: while set, every 3x3 patch-conv workgroup writes 8 int64 (s_memtime at start / patch loaded / patch staged /
 // K loop done / end, -, HW_ID, XCC_ID) to stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8].  NULL switches it off.
 extern "C" void pwr_debug_set_stamps(void* stamps) { pwr::set_debug_stamps((long long*)stamps); }
+// Debugging aid: 1 / 0 forces the ping-pong form of the 3x3 128->128 conv on / off (where it applies), -1 = the default (env PWR_PINGPONG)
+extern "C" void pwr_debug_set_pingpong(int v) { pwr::set_debug_pingpong(v); }
 
 // slab rows per sample that pwr_conv_fwd_stats writes for this conv shape; 0 = the shape cannot produce column statistics
 // (a 128-pixel tile would straddle samples, or the transposed mode)

@@ -461,7 +461,8 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
   return launch_patch_cin<T, 32>(p, s);
 }
 
-void set_debug_stamps(long long* ptr) { g_stamps = ptr; }
+void set_debug_stamps_pp(long long* ptr);
+void set_debug_stamps(long long* ptr) { g_stamps = ptr; set_debug_stamps_pp(ptr); }
 
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
   if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);
