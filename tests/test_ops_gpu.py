@@ -531,3 +531,31 @@ def test_conv_epilogue_norm_backward_sums(case, dtype):
         assert_close(dy1.double().cpu(), dy0.double().cpu(), t, "dy (mode %d)" % mode)
         assert_close(dg1.double().cpu(), dg0.double().cpu(), 1e-4, "dgamma")
         assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
+
+
+@pytest.mark.parametrize("B,H,W", [(32, 64, 64), (33, 64, 64), (5, 128, 160)])
+def test_pingpong_conv_is_bitwise_equal_to_patch_conv(B, H, W):
+    """The opt-in ping-pong form of the 3x3 128->128 conv (csrc/conv_pingpong.hip) computes every tile with the same K order and
+    the same epilogue arithmetic as conv3x3_patch_kernel: outputs and epilogue statistics must agree bit for bit (ragged tile
+    counts per workgroup included)."""
+    from pixelwiseregression_amd import kernels as K, _lib
+    l = _lib.lib()
+    torch.manual_seed(B)
+    x = torch.randn(B, H, W, 128, device=DEV).to(torch.bfloat16)
+    w = torch.randn(128, 128, 3, 3, device=DEV) * 0.03
+    pf, pd = K.pack_conv(w, 0, K.BF16), K.pack_conv(w, 1, K.BF16)
+    st = K.norm_stats(x, torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1)
+    bias = torch.randn(128, device=DEV) * 0.1
+    yv = torch.randn(B, H, W, 128, device=DEV).to(torch.bfloat16)
+    fns = [lambda: (K.conv_fwd(x, pf, 128, 3, 1, bias=bias, norm=st)[0],), lambda: (K.conv_fwd(x, pd, 128, 3, 1)[0],),
+           lambda: K.conv_fwd_stats(x, pf, 128, 3, 1, bias=bias, norm=st)[:2], lambda: K.conv_fwd_stats(x, pd, 128, 3, 1, nb_y=yv, nb_state=st)[:2]]
+    try:
+        for fn in fns:
+            l.pwr_debug_set_pingpong(0)
+            ref = [t.clone() for t in fn()]
+            l.pwr_debug_set_pingpong(1)
+            for _ in range(3):
+                for a, b in zip(fn(), ref):
+                    assert torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0))
+    finally:
+        l.pwr_debug_set_pingpong(-1)
