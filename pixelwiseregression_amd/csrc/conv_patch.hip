@@ -242,8 +242,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       if (it + 3 < ITERS) dma_w(it + 3, it % 3);
       if (it + 1 < ITERS) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
       // pin the order: left alone, the scheduler sinks these reads to just before their first use (shortest live range),
-      // i.e. back into the next step, and hoists that step's MFMAs above the barrier -- the read-then-wait form again
-      __builtin_amdgcn_sched_barrier(0);
+      // i.e. back into the next step, and hoists that step's MFMAs above the barrier -- the read-then-wait form again.
+      // bf16: the first MFMA goes out right behind the barrier and the DMA / fragment reads are issued in the shadow of the
+      // MFMAs (sched_group_barrier pipeline below); issuing all ten memory instructions first left the matrix pipe idle for
+      // ~150 cycles per step.
+      if constexpr (sizeof(T) != 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -258,6 +261,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[it & 1][ss][i][e], fb[it & 1][ss][j][e], acc[i][j], 0, 0, 0);
             }
           }
+      if constexpr (sizeof(T) == 2) {
+        constexpr int NMFMA = 2 * MR * NR, NREAD = 2 * (MR + NR);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
+        if (it + 3 < ITERS) __builtin_amdgcn_sched_group_barrier(0x010, NBW, 0);   // the LDS-DMA of stage it+3
+        if (it + 1 < ITERS) {
+#pragma unroll
+          for (int k = 1; k < NMFMA; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, (NREAD + NMFMA - 2) / (NMFMA - 1), 0);   // DS reads (as many groups as it takes)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kTwoLevel) {
         if ((it & 7) == 7 || it + 1 == ITERS) {
