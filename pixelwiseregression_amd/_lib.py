@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpwr_hip.so")
+LIB_PATH = os.environ.get("PWR_LIB", os.path.join(_HERE, "libpwr_hip.so"))   # PWR_LIB: another build of the same ABI, for A/B timing
 ABI_VERSION = 1
 
 _lib = None

@@ -665,7 +665,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
     const int rem = t0 - tb * p.H * tiles_x;
     ty = rem / tiles_x; tx = rem - ty * tiles_x;
   }
-  auto advance = [&]() { if (++tx == tiles_x) { tx = 0; if (++ty == p.H) { ty = 0; ++tb; } } };
+  // (never past the last tile of this split: the loaders run unconditionally -- a load inside a branch makes the compiler's
+  // wait-count pass fall back to vmcnt(0) at the join, which waits for the prefetch that was just issued, every step --
+  // and simply re-read the last tile when there is nothing left to fetch)
+  int issued = 0;
+  auto advance = [&]() {
+    if (++issued < nsteps) { if (++tx == tiles_x) { tx = 0; if (++ty == p.H) { ty = 0; ++tb; } } }
+  };
 
   // per-thread NR state for its channel chunk (reloaded when the batch index changes)
   const int acq = tid % ACH;
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
   auto body = [&](auto BUF, int st) {
     constexpr int buf = decltype(BUF)::value;
     const bool rowok_cur = sg[buf].rowok;
-    if (st + 2 < nsteps) load_global(sg[buf]);       // sg[buf] was already stored to LDS: refill with tile st+2
+    load_global(sg[buf]);                            // sg[buf] was already stored to LDS: refill with tile st+2 (or the last one again)
     if (rowok_cur) {
       const char* lA = smem + buf * (TILE_A + TILE_B);
       const char* lB = lA + TILE_A;
@@ -794,12 +800,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
             for (int j = 0; j < NR; ++j)
               acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ss][t][i], bf[ss][j], acc[t][i][j], 0, 0, 0);
     }
-    if (st + 1 < nsteps) store_lds(sg[buf ^ 1], buf ^ 1);
+    store_lds(sg[buf ^ 1], buf ^ 1);                 // (after the last step: a tile nobody reads)
     __syncthreads();
   };
   if (nsteps > 0) {
     load_global(sg[0]);
-    if (nsteps > 1) load_global(sg[1]);
+    load_global(sg[1]);
     store_lds(sg[0], 0);
     __syncthreads();
     for (int st = 0; st < nsteps; st += 2) {
