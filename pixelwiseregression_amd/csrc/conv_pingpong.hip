@@ -3,17 +3,22 @@
 //
 // Why: in conv3x3_patch_kernel every workgroup does [stage the input patch] -> [36 MFMA steps] -> [epilogue], and all
 // workgroups of a launch run these phases in lockstep (per-workgroup s_memtime stamps, tools/stamp_patch.py: 24 % staging,
-// 49 % K loop at ~90 % MFMA issue, 27 % epilogue): the chip alternates between a load burst with idle matrix cores, a compute
-// phase with idle memory, and a store burst.  Here ONE 8-wave workgroup per CU owns two patches in LDS (135 KB) and works on
-// two tiles half a period apart: while the four waves of one group run the K loop of their tile, the other four store the
-// previous tile (accumulators -> LDS -> coalesced 16-byte stores, norm statistics) and stage their next one (global -> registers
-// -> norm + ReLU -> LDS).  Both groups pass the same workgroup barriers (36 weight-ring steps + 1 hand-over per half period), the
-// memory group's work is cut into the intervals between them.
+// 49 % K loop, 27 % epilogue): the chip alternates between a load burst with idle matrix cores, a compute phase with idle
+// memory, and a store burst.  Here ONE 8-wave workgroup per CU owns two patches in LDS (160 KB with the weight ring) and works
+// on two tiles at once, with DEDICATED waves:
+//   * four compute waves run the K loops of all tiles of the workgroup back to back, alternating between the two patches; at
+//     the end of a tile they leave it as bf16 (+bias) in the patch they just consumed ("E") -- they never touch global memory
+//     except through the weight ring (six LDS stages of [128][64 B] filled by LDS-DMA, running on across tiles: the last stages
+//     of a tile are the first of the next), so their vmcnt accounting is exactly the ring's;
+//   * four memory waves, one period behind / ahead: store the previous tile from E (coalesced 16-byte stores + the epilogue
+//     statistics), then stage the next tile into the same patch (global -> registers -> norm + ReLU -> LDS).
+// Both groups pass the same workgroup barriers (36 ring steps + 1 hand-over per tile); the memory waves' work is cut into the
+// intervals between them and never waits for memory inside an interval (all loads are branch-free and issued several
+// intervals before their first use -- a load inside a branch makes hipcc wait vmcnt(0) at the join).
 //
-// The weight ring (three LDS stages of [128][64 B], filled by LDS-DMA, fragments one step ahead in registers) runs on without a
-// break across tiles: the computing group issues the DMA for step it+3 -- the last three of a tile are the first three of the
-// next (same weights for every tile) -- and, once it has become the memory group, retires them (counted vmcnt) before the first
-// two barriers of the other group's K loop.
+// Status (MI355X, tools/test_pingpong.py): bit-identical to conv3x3_patch_kernel on every shape tried; speed on a par with it
+// (46.8 vs 47.9 us forward, 44.7 vs 42.1 us plain at B=32; 3-9 % slower at B=64).  An interval in which the memory waves do
+// anything takes ~1.5x an idle one (tools/stamp_pp.py), and a launch pays one fill / drain period.  Opt-in (PWR_PINGPONG=1).
 #include <cstdlib>
 
 #include "conv_common.h"
@@ -153,120 +158,187 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong_kernel(ConvParams p, int
     }
   };
 
-  // ---- prologue: group 0 primes the ring and stages the first tile
-  if (g == 0) {
+  // E: the finished tile as bf16 (+bias) [128 pixels][128 + 8 channels] inside the patch that was just consumed, written by the
+  // compute waves, read by the memory waves; + the tile's first row in fp32 (the shift of the forward statistics)
+  constexpr int EPB = (BN + 8) * 2;                   // bytes per E row
+  constexpr int ESHIFT = 128 * EPB;                   // byte offset of the fp32 row
+  static_assert(ESHIFT + BN * 4 <= PATCH_BYTES, "E lives in a patch");
+  constexpr int DRAIN = 14;                           // barriers of the last (store-only) period
+
+  // ---- prologue: everybody stages the first tile (512 threads: 32 pixel lanes x 16 slots), the compute waves prime the ring
+  {
+    if (g == 0) {
 #pragma unroll
-    for (int k = 0; k < RING; ++k) dma_w(k, k, dma_lane_off);
-    V sv[NIT]; unsigned okm;
+      for (int k = 0; k < RING; ++k) dma_w(k, k, dma_lane_off);
+    }
     const TileXY q = tile_xy(first);
-    NormRegs nrm;
-    stage_load(q, sv, okm, gt >> 4, gt & 15);
-    stage_norm_load(q, nrm, gt & 15);
-    stage_write(sv, okm, nrm, 0, NIT, gt >> 4, gt & 15);
+    const int pl = tid >> 4, slot = tid & 15;
+    const T* __restrict__ xs = x + (size_t)q.b * HW * CIN;
+    float mu[EP], sc[EP], be[EP];
+    if (p.in_norm) {
+      const size_t plane = (size_t)p.B * CIN;
+      const float* st = p.in_norm + (size_t)q.b * CIN + slot * EP;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
+    }
+    constexpr int NIT0 = (PP + 31) / 32;
+    V v[NIT0]; bool ok[NIT0];
+#pragma unroll
+    for (int k = 0; k < NIT0; ++k) {
+      const int pix = pl + k * 32;
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = q.ty0 + py - 1, ix = q.tx0 + px - 1;
+      ok[k] = pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      v[k] = V{};
+      if (ok[k]) v[k] = *reinterpret_cast<const V*>(xs + ((size_t)iy * p.W + ix) * CIN + slot * EP);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT0; ++k) {
+      const int pix = pl + k * 32;
+      if (pix < PP) {
+        V o = v[k];
+        if (p.in_norm && ok[k]) {
+#pragma unroll
+          for (int e = 0; e < EP; ++e) {
+            float f = fmaf(Elem<T>::to_f(v[k][e]) - mu[e], sc[e], be[e]);
+            if (p.relu_in) f = fmaxf(f, 0.f);
+            o[e] = Elem<T>::from_f(f);
+          }
+        }
+        *reinterpret_cast<V*>(smem + pix * PITCH + slot * 16) = o;      // patch 0
+      }
+    }
   }
   __syncthreads();   // (also drains the DMA stages)
 
-  float bias_r[EP];
+  if (g == 0) {
+    // ================================================================= compute waves: K loops of all tiles, patch t & 1
+    float bias_c[2];
 #pragma unroll
-  for (int e = 0; e < EP; ++e) bias_r[e] = p.bias ? p.bias[(gt & 15) * EP + e] : 0.f;
-  f32x16 acc[2][2];
-  for (int h = 0; h <= n; ++h) {
-    if ((h & 1) == g) {
-      // =============================================================== compute role: tile first + h
-      if (h < n) {
-        const bool has_next = h + 1 < n;
+    for (int j = 0; j < 2; ++j) bias_c[j] = p.bias ? p.bias[wn * 64 + j * 32 + r] : 0.f;
+    for (int t = 0; t < n; ++t) {
+      const bool has_next = t + 1 < n;
+      const char* pbase = smem + (t & 1) * PATCH_BYTES;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      unsigned doff = dma_lane_off;
+      asm volatile("" : "+v"(doff));
+      const char* aB[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) aB[i] = pbase + ((wm * 2 + i) * PW + r) * PITCH + hh * 16;
+      auto fload = [&](int it, V (&a)[2][2], V (&bq)[2][2]) {
+        const int tap = it / KCH, kch = it - tap * KCH;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* lB = wbuf + (it % RING) * WBUF_BYTES;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[ss][i] = *reinterpret_cast<const V*>(aB[i] + (ky * PW + kx) * PITCH + kch * 64 + ss * 32);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bq[ss][j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
+        }
+      };
+      V fa[2][2][2], fb[2][2][2];
+      fload(0, fa[0], fb[0]);
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        // stage it+1 landed (own share), own LDS reads retired; in flight: the stages it+2 .. it+RING-1 (of the next tile too)
+        if (it + RING - 1 < ITERS) wait_barrier<WAIT_RING>();
+        else if (has_next) wait_barrier<WAIT_RING>();
+        else {
+          const int left = ITERS - 2 - it;
+          static_assert(RING == 6, "tail waits written out for RING - 2 = 4 stages");
+          if (left >= 3) wait_barrier<WAIT_VM0_LGKM0 + 6>();
+          else if (left == 2) wait_barrier<WAIT_VM0_LGKM0 + 4>();
+          else if (left == 1) wait_barrier<WAIT_VM0_LGKM0 + 2>();
+          else wait_barrier<WAIT_VM0_LGKM0>();
+        }
+        if (p.stamps && (it % 6 == 0 || it == ITERS - 1) && w4 == 0 && lane == 0 && t < 16)
+          p.stamps[((size_t)blockIdx.x * 16 + t) * 8 + (it == ITERS - 1 ? 6 : it / 6)] = (long long)__builtin_amdgcn_s_memtime();
+        const bool issue = it + RING < ITERS || has_next;
+        if (it + RING < ITERS) dma_w(it + RING, it % RING, doff);
+        else if (has_next) dma_w(it + RING - ITERS, it % RING, doff);
+        if (it + 1 < ITERS) fload(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it & 1][ss][i], fb[it & 1][ss][j], acc[i][j], 0, 0, 0);
+        // first MFMA right behind the barrier, the DMA and the next step's fragment reads in the shadow of the MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (issue) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+        if (it + 1 < ITERS) {
+#pragma unroll
+          for (int k = 1; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the tile -> E (bf16, + bias), in the patch just consumed (every wave's patch reads retired at barrier 35)
+      {
+        char* Eb = smem + (t & 1) * PATCH_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        // (opaque per phase: the 72 source addresses are then formed on the fly as scalar base + this offset instead of being
-        // precomputed outside the tile loop and spilled)
-        unsigned doff = dma_lane_off;
-        asm volatile("" : "+v"(doff));
-        V fa[2][2][2], fb[2][2][2];
-        frag_load(0, fa[0], fb[0]);
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-          // stage it+1 landed (own share), own LDS reads retired.  In flight: the stages it+2 .. it+RING-1 -- of this tile, and of
-          // the next one if there is one; at the tail of the last tile only what is left of it
-          if (it + RING - 1 < ITERS) wait_barrier<WAIT_RING>();
-          else if (has_next) wait_barrier<WAIT_RING>();
-          else {
-            const int left = ITERS - 2 - it;       // stages that may still be in flight (constant after unrolling)
-            static_assert(RING == 6, "tail waits written out for RING - 2 = 4 stages");
-            if (left >= 3) wait_barrier<WAIT_VM0_LGKM0 + 6>();
-            else if (left == 2) wait_barrier<WAIT_VM0_LGKM0 + 4>();
-            else if (left == 1) wait_barrier<WAIT_VM0_LGKM0 + 2>();
-            else wait_barrier<WAIT_VM0_LGKM0>();
-          }
-          if (p.stamps && (it % 6 == 0 || it == ITERS - 1) && w4 == 0 && lane == 0 && h < 16)
-            p.stamps[((size_t)blockIdx.x * 16 + h) * 8 + (it == ITERS - 1 ? 6 : it / 6)] = (long long)__builtin_amdgcn_s_memtime();
-          if (it + RING < ITERS) dma_w(it + RING, it % RING, doff);
-          else if (has_next) dma_w(it + RING - ITERS, it % RING, doff);
-          if (it + 1 < ITERS) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it & 1][ss][i], fb[it & 1][ss][j], acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        wait_barrier<WAIT_LGKM0>();           // hand-over
-      } else {
-#pragma unroll 1
-        for (int k = 0; k <= ITERS; ++k) wait_barrier<WAIT_LGKM0>();
+            for (int e = 0; e < 16; ++e) {
+              const int row = (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+              const int col = wn * 64 + j * 32 + r;
+              const float vv = acc[i][j][e] + bias_c[j];
+              *reinterpret_cast<T*>(Eb + row * EPB + col * 2) = Elem<T>::from_f(vv);
+              if (i == 0 && e == 0) { if (wm == 0 && hh == 0) *reinterpret_cast<float*>(Eb + ESHIFT + col * 4) = vv; }
+            }
       }
-    } else {
-      // =============================================================== memory role: store tile first + h - 1, stage tile first + h + 1
-      const bool do_epi = h >= 1, do_stage = h + 1 < n;
-      // opaque copy of the thread index: keeps the address arithmetic of this role INSIDE the role (hoisted out of the tile
-      // loop it would stay live across the other role's K loop, whose registers are all spoken for)
-      int gtv = gt;
-      asm volatile("" : "+v"(gtv));
-      const int pl = gtv >> 4, slot = gtv & 15;
+      wait_barrier<WAIT_LGKM0>();             // hand-over: E of tile t is complete
+    }
+#pragma unroll 1
+    for (int k = 0; k < DRAIN; ++k) wait_barrier<WAIT_LGKM0>();
+  } else {
+    // ================================================================= memory waves
+    // period t (the compute waves work on tile t): store tile t-1 from E in patch (t-1) & 1, then stage tile t+1 into that patch.
+    // Nothing here may wait for memory inside an interval: every load is issued >= 2 intervals before its first use.
+    int gtv = gt;
+    asm volatile("" : "+v"(gtv));
+    const int pl = gtv >> 4, slot = gtv & 15;
+    T* __restrict__ y = reinterpret_cast<T*>(p.y);
+    const int kind = p.st_partial ? 1 : (p.nb_partial ? 2 : 0);
+    for (int t = 0; t <= n; ++t) {
+      const bool do_epi = t >= 1, do_stage = t + 1 < n, last = t == n;
+      char* pb = smem + ((t + 1) & 1) * PATCH_BYTES;            // == patch (t-1) & 1
+      const float* Ef = reinterpret_cast<const float*>(pb);
       TileXY qe = {0, 0, 0, 0}, qs = {0, 0, 0, 0};
-      if (do_epi) qe = tile_xy(first + h - 1);
-      if (do_stage) qs = tile_xy(first + h + 1);
-      // The memory role never waits for memory inside an interval (the other group's K loop would wait at the barrier with it):
-      // every load is issued at least two intervals before its first use.
+      // (tiles that do not exist fall back to the first one: every load below is issued UNCONDITIONALLY from a valid address --
+      // a load inside a branch makes the compiler wait vmcnt(0) at the join, i.e. for the load it just issued, inside the interval)
+      qe = tile_xy(do_epi ? first + t - 1 : first);
+      qs = tile_xy(do_stage ? first + t + 1 : first);
       EpiStats<T> est;
-      T* __restrict__ y = reinterpret_cast<T*>(p.y);
-      const int kind = p.st_partial ? 1 : (p.nb_partial ? 2 : 0);
-      V yv[8];                                      // kind 2: the forward activations of this thread's 8 output vectors
-      auto out_row = [&](int ps, int qn) {          // NHWC pixel index of this thread's vector in pass ps, quarter qn
-        const int ml = ps * EROWS + ((gtv + 256 * qn) >> 4);
+      V yv[8];
+      const T* __restrict__ nby = kind == 2 ? reinterpret_cast<const T*>(p.nb_y) : x;                       // same shape as the output
+      const float* __restrict__ nbst = kind == 2 ? p.nb_state : reinterpret_cast<const float*>(p.w);       // >= 4 * B * 128 floats
+      const float* __restrict__ innorm = p.in_norm ? p.in_norm : reinterpret_cast<const float*>(p.w);
+      auto out_row = [&](int u) {                     // NHWC pixel of this thread's u-th vector (tile pixel 16 u + pl)
+        const int ml = 16 * u + pl;
         return (size_t)qe.b * HW + (size_t)(qe.ty0 + ml / TW) * p.W + qe.tx0 + ml % TW;
       };
-      auto write_E = [&](int ps) {
-        if (wm == ps) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                E[row * EPITCH + wn * 64 + j * 32 + r] = acc[i][j][e];
-              }
-        }
-      };
-      auto copy_chunk = [&](int ps, int qn) {       // rows of pass ps, quarter qn: one 16-byte vector per thread
-        const int row = (gtv + 256 * qn) >> 4, cc = slot * EP;
-        const size_t m = out_row(ps, qn);
-        V o;
-#pragma unroll
-        for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(E[row * EPITCH + cc + e] + bias_r[e]);
-        *reinterpret_cast<V*>(y + m * p.Cout + cc) = o;
+      auto copy_vec = [&](int u) {
+        const int ml = 16 * u + pl;
+        const V o = *reinterpret_cast<const V*>(pb + ml * EPB + slot * 16);
+        *reinterpret_cast<V*>(y + out_row(u) * p.Cout + slot * EP) = o;
         if (kind == 1) {
 #pragma unroll
           for (int e = 0; e < EP; ++e) { const float d = Elem<T>::to_f(o[e]) - est.a0[e]; est.s1[e] += d; est.s2[e] = fmaf(d, d, est.s2[e]); }
         } else if (kind == 2) {
-          const V yq = yv[ps * 4 + qn];
+          const V yq = yv[u];
 #pragma unroll
           for (int e = 0; e < EP; ++e) {
             const float yy = Elem<T>::to_f(yq[e]);
@@ -277,89 +349,99 @@ __global__ __launch_bounds__(512) void conv3x3_pingpong_kernel(ConvParams p, int
           }
         }
       };
-      // I_0 .. : (this group's DMA stages for the other group's first RING - 1 steps retire one per barrier; no other
-      // vector-memory operation of these waves before the last of them)
-      if (do_epi) write_E(0);
-      wait_barrier<WAIT_VM0_LGKM0 + 8>();                                   // B_0
-      wait_barrier<WAIT_VM0_LGKM0 + 6>();                                   // B_1
-      wait_barrier<WAIT_VM0_LGKM0 + 4>();                                   // B_2
-      wait_barrier<WAIT_VM0_LGKM0 + 2>();                                   // B_3
-      wait_barrier<WAIT_VM0_LGKM0>();                                       // B_4
-      if (do_epi) {
-        est.init(p, qe.b, slot * EP);                                       // (kind 2: loads the norm state of the sample)
-        if (kind == 2) {
+      int nb = 0;                                     // barriers passed in this period
+      auto bar = [&]() { wait_barrier<WAIT_LGKM0>(); ++nb; };
+      // I_0: loads of the store phase
+      {
+        est.kind = kind;
+        const size_t plane = (size_t)p.B * p.Cout, c0 = (size_t)qe.b * p.Cout + slot * EP;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) yv[u] = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.nb_y) + out_row(u >> 2, u & 3) * p.Cout + slot * EP);
+        for (int e = 0; e < EP; ++e) {
+          est.s1[e] = 0.f; est.s2[e] = 0.f;
+          est.a0[e] = nbst[c0 + e]; est.a1[e] = nbst[plane + c0 + e]; est.a2[e] = nbst[2 * plane + c0 + e]; est.a3[e] = nbst[3 * plane + c0 + e];
         }
-      }
-      wait_barrier<WAIT_LGKM0>();                                           // B_5
-      wait_barrier<WAIT_LGKM0>();                                           // B_6
-      wait_barrier<WAIT_LGKM0>();                                           // B_7
-      if (do_epi) {
-        if (kind == 1) {
 #pragma unroll
-          for (int e = 0; e < EP; ++e) est.a0[e] = E[slot * EP + e] + bias_r[e];     // the shift: the tile's first output row
-        }
-        copy_chunk(0, 0);
+        for (int u = 0; u < 8; ++u) yv[u] = *reinterpret_cast<const V*>(nby + out_row(u) * p.Cout + slot * EP);
       }
-      wait_barrier<WAIT_LGKM0>();                                           // B_8
-      if (do_epi) copy_chunk(0, 1);
-      wait_barrier<WAIT_LGKM0>();                                           // B_9
-      if (do_epi) copy_chunk(0, 2);
-      wait_barrier<WAIT_LGKM0>();                                           // B_10
-      if (do_epi) copy_chunk(0, 3);
-      wait_barrier<WAIT_LGKM0>();                                           // B_11
-      if (do_epi) write_E(1);
-      wait_barrier<WAIT_LGKM0>();                                           // B_12
-      if (do_epi) copy_chunk(1, 0);
-      wait_barrier<WAIT_LGKM0>();                                           // B_13
-      if (do_epi) copy_chunk(1, 1);
-      wait_barrier<WAIT_LGKM0>();                                           // B_14
-      if (do_epi) copy_chunk(1, 2);
-      wait_barrier<WAIT_LGKM0>();                                           // B_15
-      if (do_epi) copy_chunk(1, 3);
-      wait_barrier<WAIT_LGKM0>();                                           // B_16
-      // column statistics of the tile (EpiStats::finish, split at its barrier); 16 slots x EP channels, 4 waves
+      bar(); bar(); bar();                            // B_0 .. B_2
+      if (do_epi && kind == 1) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) est.a0[e] = *reinterpret_cast<const float*>(pb + ESHIFT + (slot * EP + e) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { if (do_epi) copy_vec(u); bar(); }     // B_3 .. B_10
       if (do_epi && kind != 0) {
 #pragma unroll
         for (int o = 16; o < 64; o <<= 1)
 #pragma unroll
           for (int e = 0; e < EP; ++e) { est.s1[e] += __shfl_xor(est.s1[e], o, 64); est.s2[e] += __shfl_xor(est.s2[e], o, 64); }
         if (lane < 16) {
+          float* Es = reinterpret_cast<float*>(pb);
 #pragma unroll
-          for (int e = 0; e < EP; ++e) { E[((w4 * 2 + 0) * 16 + slot) * EP + e] = est.s1[e]; E[((w4 * 2 + 1) * 16 + slot) * EP + e] = est.s2[e]; }
+          for (int e = 0; e < EP; ++e) { Es[((w4 * 2 + 0) * 16 + slot) * EP + e] = est.s1[e]; Es[((w4 * 2 + 1) * 16 + slot) * EP + e] = est.s2[e]; }
         }
       }
-      wait_barrier<WAIT_LGKM0>();                                           // B_17
+      bar();                                          // B_11
       if (do_epi && kind != 0) {
         float* out = kind == 1 ? p.st_partial + ((size_t)(qe.b * tiles_img + qe.tr) * 3) * p.Cout
                                : p.nb_partial + ((size_t)(qe.b * tiles_img + qe.tr) * 2) * p.Cout;
         const int which = gtv >> 7, c = gtv & 127;
-        float t = 0.f;
+        float tt = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) t += E[((wv * 2 + which) * 16) * EP + c];
-        out[(size_t)which * p.Cout + c] = t;
+        for (int wv = 0; wv < 4; ++wv) tt += Ef[((wv * 2 + which) * 16) * EP + c];
+        out[(size_t)which * p.Cout + c] = tt;
         if (kind == 1 && gtv < 16) {
 #pragma unroll
           for (int e = 0; e < EP; ++e) out[(size_t)2 * p.Cout + slot * EP + e] = est.a0[e];
         }
       }
-      wait_barrier<WAIT_LGKM0>();                                           // B_18
+      bar();                                          // B_12
+      // staging of tile t+1, thinly sliced (an interval that takes longer than the compute waves' K step stalls them at the
+      // barrier): two loads per interval from B_12 on, one normalised 16-byte LDS write per interval from B_21 on
       V sv[NIT]; unsigned okm = 0;
       NormRegs nrm;
-      if (do_stage) { stage_load(qs, sv, okm, pl, slot); stage_norm_load(qs, nrm, slot); }
-      wait_barrier<WAIT_LGKM0>();                                           // B_19
-#pragma unroll 1
-      for (int k = 20; k < 32; ++k) wait_barrier<WAIT_LGKM0>();             // B_20 .. B_31 (the loads are in flight)
-      if (do_stage) stage_write(sv, okm, nrm, 0, 4, pl, slot);
-      wait_barrier<WAIT_LGKM0>();                                           // B_32
-      if (do_stage) stage_write(sv, okm, nrm, 4, 7, pl, slot);
-      wait_barrier<WAIT_LGKM0>();                                           // B_33
-      if (do_stage) stage_write(sv, okm, nrm, 7, 10, pl, slot);
-      wait_barrier<WAIT_LGKM0>();                                           // B_34
-      if (do_stage) stage_write(sv, okm, nrm, 10, NIT, pl, slot);
-      wait_barrier<WAIT_LGKM0>();                                           // B_35
-      wait_barrier<WAIT_LGKM0>();                                           // hand-over
+      const T* __restrict__ xs = x + (size_t)qs.b * HW * CIN;
+      auto sload = [&](int k) {
+        const int pix = pl + k * 16;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = qs.ty0 + py - 1, ix = qs.tx0 + px - 1;
+        const bool ok = pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);       // (clamped: always a valid address)
+        sv[k] = *reinterpret_cast<const V*>(xs + ((size_t)cy * p.W + cx) * CIN + slot * EP);
+        okm |= (ok ? 1u : 0u) << k;
+      };
+      auto swrite = [&](int k) {
+        const int pix = pl + k * 16;
+        if (pix < PP) {
+          V o = sv[k];
+          if (p.in_norm) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+              float f = fmaf(Elem<T>::to_f(sv[k][e]) - nrm.mu[e], nrm.sc[e], nrm.be[e]);
+              if (p.relu_in) f = fmaxf(f, 0.f);
+              o[e] = Elem<T>::from_f(f);
+            }
+          }
+          if (!((okm >> k) & 1)) o = V{};
+          *reinterpret_cast<V*>(pb + pix * PITCH + slot * 16) = o;
+        }
+      };
+      {
+        const size_t plane = (size_t)p.B * CIN;
+        const float* st = innorm + (size_t)qs.b * CIN + slot * EP;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { nrm.mu[e] = st[e]; nrm.sc[e] = st[2 * plane + e]; nrm.be[e] = st[3 * plane + e]; }
+        sload(0);
+      }
+      bar();                                          // B_13
+      if (last) continue;                             // (DRAIN == 14 barriers in the store-only period)
+#pragma unroll
+      for (int k = 14; k < 36; ++k) {                 // B_14 .. B_35
+        if (k - 14 < 6) { sload(2 * (k - 14) + 1); sload(2 * (k - 14) + 2); }       // loads 1 .. 12 in the intervals before B_14 .. B_19
+        if (do_stage && k >= 22 && k - 22 < NIT) swrite(k - 22);                      // writes 0 .. 12 before B_22 .. B_34
+        bar();
+      }
+      bar();                                          // hand-over
     }
   }
 }
@@ -370,12 +452,7 @@ static int g_pingpong_override = -1;
 void set_debug_pingpong(int v) { g_pingpong_override = v; }
 
 bool conv_pingpong_applicable(const ConvParams& p, int dtype) {
-  // Measured on MI355X (tools/test_pingpong.py, tools/stamp_pp.py; bitwise equal to conv3x3_patch_kernel on every shape tried):
-  // 111 us vs 50 us at B=32 (4 tiles per CU), 198 vs 93 us at B=64.  A K step takes ~405 clocks while the memory group has
-  // nothing to do, but 700 - 2500 in the intervals where it works: role switching costs ~100 scratch reloads per half period
-  // (256 registers are not enough for both roles' invariants), and a scratch reload waits for every older store of the wave.
-  // The schedule itself also pays one fill / drain half period per launch (5 for 4 tiles).  Opt-in until the roles are split
-  // into dedicated waves (no switching) -- next round.
+  // opt-in: see the status note at the top of this file
   static const bool env_on = [] { const char* e = getenv("PWR_PINGPONG"); return e ? atoi(e) != 0 : false; }();
   const bool on = g_pingpong_override < 0 ? env_on : g_pingpong_override != 0;
   if (!on || dtype != PWR_BF16) return false;
