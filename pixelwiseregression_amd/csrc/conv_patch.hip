@@ -31,7 +31,10 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 // Patch pixels are padded by one 16-byte slot: with a pitch of NSLOT*16+16 bytes the 16-lane groups of ds_read_b128
 // (32 consecutive pixels, same channel slot) fall on 16 distinct bank slots WITHOUT an XOR swizzle, so every fragment
 // address is (per-lane base) + (compile-time constant): no vector ALU work in the K loop for the A operand.
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32>
+// KS = 1: the same kernel as a 1x1 convolution (no halo, taps = 1): the whole K extent of a tile's input is then resident after
+// ONE round of loads (8 per thread, all in flight together) -- the universal kernel exposes a global-load round trip per K step,
+// which for these memory-bound layers (the ResBlocks' bottleneck convs, the stage-input conv) meant ~2 TB/s.
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int KS = 3>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
@@ -40,7 +43,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   constexpr int TH = WM * MR;                     // tile rows of the TW == 32 form
   constexpr int RH = TW == 32 ? TH : (TW * TW < BM ? TW : BM / TW);   // rows of one sub-block
   constexpr int SUBPIX = RH * TW, SUB = BM / SUBPIX;                  // 128-pixel tile = SUB sub-blocks of RH x TW pixels
-  constexpr int PH = RH + 2, PW = TW + 2, PP = PH * PW, NPIX = SUB * PP;
+  constexpr int HALO = KS / 2;
+  constexpr int PH = RH + 2 * HALO, PW = TW + 2 * HALO, PP = PH * PW, NPIX = SUB * PP;
   constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
   constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
   constexpr int PITCH = NSLOT * 16 + 16;         // bytes per patch pixel (padded, see above)
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       }
     }
   };
-  if constexpr (DMA) { dma_w(0, 0); dma_w(1, 1); } else { load_w(0); }
+  if constexpr (DMA) { dma_w(0, 0); if (1 < KS * KS * KCH) dma_w(1, 1); } else { load_w(0); }
 
   // ---- stage the patch: thread -> fixed sub-block and 16-byte channel slot, pixels pl + k*PL of that sub-block
   {
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     for (int k = 0; k < NIT; ++k) {
       const int pix = pl + k * PL;
       const int py = pix / PW, px = pix - py * PW;
-      const int iy = sy0 + py - 1, ix = sx0 + px - 1;
+      const int iy = sy0 + py - HALO, ix = sx0 + px - HALO;
       ok[k] = sv && pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       v[k] = V{};
       if (ok[k]) v[k] = *reinterpret_cast<const V*>(xs + ((size_t)iy * p.W + ix) * CIN + slot * EP);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   }
 
   const int r = lane & 31, h = lane >> 5;
-  constexpr int ITERS = 9 * KCH;
+  constexpr int ITERS = KS * KS * KCH;
   const char* aBase[MR];
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     V fa[2][2][MR], fb[2][2][NR];
     auto frag_load = [&](int it, V (&a)[2][MR], V (&bq)[2][NR]) {
       const int tap = it / KCH, kch = it - tap * KCH;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = tap / KS, kx = tap - ky * KS;
       const char* lB = wbuf + (it % 3) * WBUF_BYTES;
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int tap = it / KCH, kch = it - tap * KCH;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = tap / KS, kx = tap - ky * KS;
       const int buf = it & 1;
       if (it + 1 < ITERS) load_w(it + 1);
       const char* lB = wbuf + buf * WBUF_BYTES;
@@ -416,13 +420,21 @@ static bool small_map(const ConvParams& p, int dtype) {
   return p.W == 4 || p.W == 8 || p.W == 16;
 }
 
+static bool conv1x1_applicable(const ConvParams& p, int dtype) {
+  static const bool on = [] { const char* e = getenv("PWR_PATCH_1X1"); return e ? atoi(e) != 0 : true; }();
+  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.W % 32 == 0 && p.H % 4 == 0 &&
+         (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && p.y != nullptr;
+}
+
 bool conv_patch_applicable(const ConvParams& p, int dtype) {
+  if (conv1x1_applicable(p, dtype)) return true;
   if (!(p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1)) return false;
   if (small_map(p, dtype)) return true;
   return p.W % 32 == 0 && p.H % 4 == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
 }
 
 int conv_patch_stats_chunks(const ConvParams& p, int dtype) {
+  if (conv1x1_applicable(p, dtype)) return (p.H / 4) * (p.W / 32);
   if (!conv_patch_applicable(p, dtype) || small_map(p, dtype)) return 0;
   return (p.H / 4) * (p.W / 32);
 }
@@ -479,7 +491,23 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
 void set_debug_stamps_pp(long long* ptr);
 void set_debug_stamps(long long* ptr) { g_stamps = ptr; set_debug_stamps_pp(ptr); }
 
+template <int CIN>
+static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
+  const int bn = pick_bn(p.Cout);
+  dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 2, true, 32, 1>), grid, block, 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 1, true, 32, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 4, 1, 1, 1, true, 32, 1>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
+  if (conv1x1_applicable(p, dtype)) {
+    const_cast<ConvParams&>(p).stamps = g_stamps;
+    if (p.Cin == 128) return launch_patch_1x1<128>(p, s);
+    if (p.Cin == 64) return launch_patch_1x1<64>(p, s);
+    return launch_patch_1x1<32>(p, s);
+  }
   if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);
   return dtype == PWR_BF16 ? launch_patch_t<bf16_t>(p, s) : launch_patch_t<float>(p, s);
 }
