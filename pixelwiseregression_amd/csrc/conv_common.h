@@ -132,6 +132,22 @@ struct EpiStats {
       }
     }
   }
+  // the same with the forward activations of the vector (kind 2) already in registers
+  __device__ __forceinline__ void add_pre(const ConvParams& p, const V& o, const V& yv) {
+    if (kind == 1) {
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { const float d = Elem<T>::to_f(o[e]) - a0[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+    } else if (kind == 2) {
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float yy = Elem<T>::to_f(yv[e]);
+        float gg = Elem<T>::to_f(o[e]);
+        if (p.nb_relu && !(fmaf(yy - a0[e], a2[e], a3[e]) > 0.f)) gg = 0.f;
+        s1[e] += gg;
+        s2[e] = fmaf(gg, (yy - a0[e]) * a1[e], s2[e]);
+      }
+    }
+  }
   // CPR = 16-byte slots per tile row (threads tid % CPR == slot share a slot), NT threads.  `lds`: >= (NT/64)*CPR*2*EP floats,
   // free for use (call after the epilogue's last barrier).  n0: first channel of the tile.
   template <int CPR, int NT>

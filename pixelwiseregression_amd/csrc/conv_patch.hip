@@ -342,8 +342,36 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   constexpr int CPRS = BN / EP;
   EpiStats<T> est;
   if constexpr (TW == 32) est.init(p, b, n0 + (tid % CPRS) * EP);
+  // TW == 32: everything the copy loop needs from global memory is fetched NOW, branch-free (a load inside a branch makes hipcc
+  // wait vmcnt(0) at the join; unused streams read one dummy vector), and arrives while the accumulators go to LDS: bias, the
+  // residual vectors, and -- for the norm-backward sums -- the forward activations.  Fetched inside the loop, each of its 4
+  // iterations per pass exposed a global round trip (the nb form cost 11 us more than the plain one).
+  constexpr int NCI = (EROWS * CPRS + NT - 1) / NT;        // copy-loop iterations per pass
+  static_assert(TW != 32 || (EROWS * CPRS) % NT == 0, "whole iterations");
+  V ypre[NCI], rpre[NCI];                                   // (per pass: both passes at once cost the second workgroup per CU)
+  float bias_r[EP];
+  const T* __restrict__ nby = est.kind == 2 ? reinterpret_cast<const T*>(p.nb_y) : reinterpret_cast<const T*>(p.w);
+  const T* __restrict__ resp = p.residual ? reinterpret_cast<const T*>(p.residual) : reinterpret_cast<const T*>(p.w);
+  if constexpr (TW == 32) {
+    const int n = n0 + (tid % CPRS) * EP;
+    const float* bp = p.bias ? p.bias + (n < p.Cout ? n : 0) : reinterpret_cast<const float*>(p.w);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
+  }
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
+    if constexpr (TW == 32) {
+      const int n = n0 + (tid % CPRS) * EP;
+      const bool nok = n < p.Cout;
+#pragma unroll
+      for (int it = 0; it < NCI; ++it) {
+        const int ml = ps * EROWS + (tid + it * NT) / CPRS;
+        const size_t m = (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+        const size_t idx = nok ? m * p.Cout + n : 0;
+        ypre[it] = *reinterpret_cast<const V*>(nby + (est.kind == 2 ? idx : 0));
+        rpre[it] = *reinterpret_cast<const V*>(resp + (p.residual ? idx : 0));
+      }
+    }
     const int wrow0 = wm * MR * 32;
     if (wrow0 / EROWS == ps) {
       const int er0 = wrow0 - ps * EROWS;
@@ -358,18 +386,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
           }
     }
     __syncthreads();
-    if constexpr (TW == 32) { if (ps == 0) est.set_shift(p, E + (tid % CPRS) * EP, n0 + (tid % CPRS) * EP); }
+    if constexpr (TW == 32) {
+      if (ps == 0 && est.kind == 1) {
+        const int n = n0 + (tid % CPRS) * EP;
+        if (n < p.Cout) {
+#pragma unroll
+          for (int e = 0; e < EP; ++e) est.a0[e] = E[(tid % CPRS) * EP + e] + bias_r[e];     // the shift (set_shift with the bias in registers)
+        }
+      }
+    }
     if (p.y) {
       T* __restrict__ y = reinterpret_cast<T*>(p.y);
       const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
       constexpr int CPR = BN / EP;
+      if constexpr (TW == 32) {
+#pragma unroll
+        for (int it = 0; it < NCI; ++it) {
+          const int c = tid + it * NT;
+          const int row = c / CPR, cc = (c - row * CPR) * EP;
+          const int ml = ps * EROWS + row, n = n0 + cc;
+          const size_t m = (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+          if (n < p.Cout) {
+            float v[EP];
+#pragma unroll
+            for (int e = 0; e < EP; ++e) v[e] = E[row * EPITCH + cc + e] + bias_r[e];
+            if (res) {
+#pragma unroll
+              for (int e = 0; e < EP; ++e) v[e] += Elem<T>::to_f(rpre[it][e]);
+            }
+            V o;
+#pragma unroll
+            for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(v[e]);
+            *reinterpret_cast<V*>(y + m * p.Cout + n) = o;
+            est.add_pre(p, o, ypre[it]);
+          }
+        }
+      } else {
       for (int c = tid; c < EROWS * CPR; c += NT) {
         const int row = c / CPR, cc = (c - row * CPR) * EP;
         const int ml = ps * EROWS + row, n = n0 + cc;
         size_t m;
         bool mvalid = true;
-        if constexpr (TW == 32) m = (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
-        else { m = (size_t)(L0 + ml); mvalid = L0 + ml < Mtot; }
+        m = (size_t)(L0 + ml); mvalid = L0 + ml < Mtot;
         if (n < p.Cout && mvalid) {
           float v[EP];
 #pragma unroll
@@ -387,8 +445,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 #pragma unroll
           for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(v[e]);
           *reinterpret_cast<V*>(y + m * p.Cout + n) = o;
-          if constexpr (TW == 32) est.add(p, o, m, n);
         }
+      }
       }
     }
     if (p.y_nchw) {
