@@ -131,9 +131,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     const T* __restrict__ xs = x + (size_t)sb * HW * CIN;
     float mu[EP], sc[EP], be[EP];
     const bool nr = p.in_norm != nullptr;
-    if (nr) {
-      const size_t plane = (size_t)p.B * CIN;
-      const float* st = p.in_norm + (size_t)sb * CIN + slot * EP;
+    {
+      // (branch-free as well: without a norm the three vectors come from the weight pack and are not used)
+      const size_t plane = nr ? (size_t)p.B * CIN : 0;
+      const float* st = nr ? p.in_norm + (size_t)sb * CIN + slot * EP : reinterpret_cast<const float*>(p.w);
 #pragma unroll
       for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
     }
@@ -145,15 +146,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       const int py = pix / PW, px = pix - py * PW;
       const int iy = sy0 + py - HALO, ix = sx0 + px - HALO;
       ok[k] = sv && pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      v[k] = V{};
-      if (ok[k]) v[k] = *reinterpret_cast<const V*>(xs + ((size_t)iy * p.W + ix) * CIN + slot * EP);
+      // branch-free: an out-of-image pixel reads a clamped (valid) address and is zeroed below -- all loads issue back to back
+      const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+      v[k] = *reinterpret_cast<const V*>(xs + ((size_t)cy * p.W + cx) * CIN + slot * EP);
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int pix = pl + k * PL;
       if (pix < PP) {
         V o = v[k];
-        if (nr && ok[k]) {
+        if (nr) {
 #pragma unroll
           for (int e = 0; e < EP; ++e) {
             float f = fmaf(Elem<T>::to_f(v[k][e]) - mu[e], sc[e], be[e]);
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
             o[e] = Elem<T>::from_f(f);
           }
         }
+        if (!ok[k]) o = V{};
         *reinterpret_cast<V*>(patch + (sub * PP + pix) * PITCH + slot * 16) = o;
       }
     }
