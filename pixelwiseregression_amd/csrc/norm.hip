@@ -301,6 +301,15 @@ __global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restri
       float s1 = 0.f, s2 = 0.f;
       const float* pp = partial + ((size_t)b * nchunks * 2) * C + c;
       int k = 0;
+      // 32 chunks' loads in flight at a time (the chain kernel this is: 16 blocks, one L2 round trip per batch), summed in the
+      // same order as before
+      for (; k + 32 <= nchunks; k += 32) {
+        float a[32], q[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { a[u] = pp[((size_t)(k + u) * 2 + 0) * C]; q[u] = pp[((size_t)(k + u) * 2 + 1) * C]; }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { s1 += a[u]; s2 += q[u]; }
+      }
       for (; k + 8 <= nchunks; k += 8) {
         float a[8], q[8];
 #pragma unroll
@@ -583,6 +592,15 @@ __global__ void norm_finalize_chunks_kernel(const float* __restrict__ partial, c
     cnt = c1;
   };
   int j = 0;
+  for (; j + 32 <= total; j += 32) {       // 32 chunks' loads in flight at a time, merged in the same order as before
+    float a[32], q[32], k[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      a[u] = base[((size_t)(j + u) * 3 + 0) * C]; q[u] = base[((size_t)(j + u) * 3 + 1) * C]; k[u] = base[((size_t)(j + u) * 3 + 2) * C];
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) merge(a[u], q[u], k[u]);
+  }
   for (; j + 8 <= total; j += 8) {
     float a[8], q[8], k[8];
 #pragma unroll
