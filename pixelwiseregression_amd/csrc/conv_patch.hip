@@ -494,8 +494,18 @@ bool conv_patch_applicable(const ConvParams& p, int dtype) {
   return p.W % 32 == 0 && p.H % 4 == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
 }
 
+// 128 -> (33..64) channels on big maps (the stem's 64 <- 128 data gradient at 128x128): 8 x 32-pixel tiles, 8 waves, ONE workgroup per
+// CU -- with 64 output channels a 4 x 32 tile does half the MFMA work per staged patch, the 8 x 32 tile stages 1.33x instead of 1.6x
+// the input and streams the weights once per 256 pixels
+static bool big64(const ConvParams& p, int dtype) {
+  static const bool on = [] { const char* e = getenv("PWR_PATCH_BIG64"); return e ? atoi(e) != 0 : false; }();   // measured: 103 vs 97 us isolated, 6.95 vs 6.90 ms/step -> off
+  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && pick_bn(p.Cout) == 64 &&
+         p.H % 8 == 0 && p.W % 32 == 0 && p.H * p.W >= 128 * 128;
+}
+
 int conv_patch_stats_chunks(const ConvParams& p, int dtype) {
   if (conv1x1_applicable(p, dtype)) return (p.H / 4) * (p.W / 32);
+  if (big64(p, dtype)) return (p.H / 8) * (p.W / 32);
   if (!conv_patch_applicable(p, dtype) || small_map(p, dtype)) return 0;
   return (p.H / 4) * (p.W / 32);
 }
@@ -528,6 +538,13 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
         // 8 waves, 8x32-pixel tile: the per-CU weight stream from L2 (the limiter of the 4x32 form) is halved
         dim3 g8(p.B * (p.H / 8) * (p.W / 32), p.CoutPad / bn);
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 2, 2, 2, true>), g8, dim3(512), 0, s, p);
+        return (int)hipGetLastError();
+      }
+    }
+    if constexpr (sizeof(T) == 2 && CIN == 128) {
+      if (big64(p, PWR_BF16)) {
+        dim3 g8(p.B * (p.H / 8) * (p.W / 32), p.CoutPad / bn);
+        hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 2, 2, 1, true>), g8, dim3(512), 0, s, p);
         return (int)hipGetLastError();
       }
     }

@@ -34,3 +34,6 @@ case("1x1 128->128 @64 (+NR)", 64, 128, 128, 1)
 case("3x3 s2 128->128 @128->64 (+NR, stats)", 128, 128, 128, 3, stride=2, stats=True)
 case("1x1 128->64 @32", 32, 128, 64, 1, stats=True)
 case("1x1 64->128 @32 (+residual)", 32, 64, 128, 1, residual=True)
+case("3x3 128->64 @128 (plain: the stem's data gradient)", 128, 128, 64, 3, norm=False)
+case("3x3 64->32 @128 (plain)", 128, 64, 32, 3, norm=False)
+case("3x3 64->128 @128 (+NR, stats)", 128, 64, 128, 3, stats=True)
