@@ -967,6 +967,7 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   if (p.CoutPad % bn) return PWR_EINVAL;
   if (conv_pingpong_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_pingpong(p, s);
+  if (conv_tr2_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_tr2(p, s);
   if (conv_patch_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
   // mode 1: four parity classes of M/4 rows each, every class padded to whole tiles
   const int mtiles = p.mode == 0 ? (p.M + 127) / 128 : 4 * ((p.M / 4 + 127) / 128);

@@ -34,7 +34,11 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 // KS = 1: the same kernel as a 1x1 convolution (no halo, taps = 1): the whole K extent of a tile's input is then resident after
 // ONE round of loads (8 per thread, all in flight together) -- the universal kernel exposes a global-load round trip per K step,
 // which for these memory-bound layers (the ResBlocks' bottleneck convs, the stage-input conv) meant ~2 TB/s.
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int KS = 3>
+// GEO = 2 + 2 py + px: the data gradient of a STRIDE-2 3x3 conv for the output pixels of parity (py, px): dx[2a+py, 2c+px] reads
+// dy[a + oy, c + ox] for 1, 2, 2 or 4 taps (py = 0: ky = 1; py = 1: ky = 2 at oy = 0 and ky = 0 at oy = 1; same in x) -- a stride-1
+// patch conv over dy with a (1+py) x (1+px) window whose output is scattered to every second pixel.  Four launches (one per class)
+// replace the gather form of the universal kernel (180 us isolated for the stem's 128 <- 128 layer at 128x128).
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
@@ -43,10 +47,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   constexpr int TH = WM * MR;                     // tile rows of the TW == 32 form
   constexpr int RH = TW == 32 ? TH : (TW * TW < BM ? TW : BM / TW);   // rows of one sub-block
   constexpr int SUBPIX = RH * TW, SUB = BM / SUBPIX;                  // 128-pixel tile = SUB sub-blocks of RH x TW pixels
-  constexpr int HALO = KS / 2;
-  constexpr int PH = RH + 2 * HALO, PW = TW + 2 * HALO, PP = PH * PW, NPIX = SUB * PP;
+  constexpr bool TR = GEO >= 2;
+  constexpr int CPY = TR ? ((GEO - 2) >> 1) : 0, CPX = TR ? ((GEO - 2) & 1) : 0;
+  constexpr int HALO = GEO == 0 ? 1 : 0;
+  constexpr int NTY = TR ? CPY + 1 : (GEO == 0 ? 3 : 1), NTX = TR ? CPX + 1 : (GEO == 0 ? 3 : 1);     // taps per axis
+  constexpr int PH = RH + (TR ? CPY : 2 * HALO), PW = TW + (TR ? CPX : 2 * HALO), PP = PH * PW, NPIX = SUB * PP;
+  static_assert(!TR || TW == 32, "the transposed classes use the 4 x 32 tile");
   constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
   constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
+  // weight stage (tap-major index into the pack) of K step `it`; the window offset of its tap inside the patch is (it's ty, tx)
+  auto wstage = [](int it) {
+    const int tap = it / KCH, kch = it - tap * KCH;
+    const int ty = tap / NTX, tx = tap - ty * NTX;
+    int wt;
+    if (GEO == 0) wt = ty * 3 + tx;
+    else if (GEO == 1) wt = 0;
+    else wt = (CPY ? (ty == 0 ? 2 : 0) : 1) * 3 + (CPX ? (tx == 0 ? 2 : 0) : 1);
+    return wt * KCH + kch;
+  };
   constexpr int PITCH = NSLOT * 16 + 16;         // bytes per patch pixel (padded, see above)
   constexpr int PATCH_BYTES = NPIX * PITCH;
   constexpr int WBUF_BYTES = BN * 64;
@@ -112,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       }
     }
   };
-  if constexpr (DMA) { dma_w(0, 0); if (1 < KS * KS * KCH) dma_w(1, 1); } else { load_w(0); }
+  if constexpr (DMA) { dma_w(wstage(0), 0); if (1 < NTY * NTX * KCH) dma_w(wstage(1), 1); } else { load_w(wstage(0)); }
 
   // ---- stage the patch: thread -> fixed sub-block and 16-byte channel slot, pixels pl + k*PL of that sub-block
   {
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   }
 
   const int r = lane & 31, h = lane >> 5;
-  constexpr int ITERS = KS * KS * KCH;
+  constexpr int ITERS = NTY * NTX * KCH;
   const char* aBase[MR];
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     V fa[2][2][MR], fb[2][2][NR];
     auto frag_load = [&](int it, V (&a)[2][MR], V (&bq)[2][NR]) {
       const int tap = it / KCH, kch = it - tap * KCH;
-      const int ky = tap / KS, kx = tap - ky * KS;
+      const int ky = tap / NTX, kx = tap - ky * NTX;     // window offset of the tap inside the patch
       const char* lB = wbuf + (it % 3) * WBUF_BYTES;
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
         for (int j = 0; j < NR; ++j) bq[ss][j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
       }
     };
-    if (2 < ITERS) dma_w(2, 2);
+    if (2 < ITERS) dma_w(wstage(2), 2);
     frag_load(0, fa[0], fb[0]);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       }
       __builtin_amdgcn_s_barrier();
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      if (it + 3 < ITERS) dma_w(it + 3, it % 3);
+      if (it + 3 < ITERS) dma_w(wstage(it + 3), it % 3);
       if (it + 1 < ITERS) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
       // pin the order: left alone, the scheduler sinks these reads to just before their first use (shortest live range),
       // i.e. back into the next step, and hoists that step's MFMAs above the barrier -- the read-then-wait form again.
@@ -295,9 +313,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int tap = it / KCH, kch = it - tap * KCH;
-      const int ky = tap / KS, kx = tap - ky * KS;
+      const int ky = tap / NTX, kx = tap - ky * NTX;     // window offset of the tap inside the patch
       const int buf = it & 1;
-      if (it + 1 < ITERS) load_w(it + 1);
+      if (it + 1 < ITERS) load_w(wstage(it + 1));
       const char* lB = wbuf + buf * WBUF_BYTES;
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -338,6 +356,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       for (int j = 0; j < NR; ++j) acc[i][j] = acc2[i][j];
   }
 
+  // NHWC pixel index of tile pixel ml in the output (TW == 32 forms)
+  auto out_m = [&](int ml) -> size_t {
+    if constexpr (TR) return (size_t)b * 4 * HW + (size_t)(2 * (ty0 + ml / TW) + CPY) * (2 * p.W) + 2 * (tx0 + ml % TW) + CPX;
+    else return (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+  };
   stamp(p, 3);
   // ---- epilogue: accumulators -> LDS (fp32, 64 tile pixels at a time) -> coalesced 16-byte stores
   float* E = reinterpret_cast<float*>(smem);
@@ -369,7 +392,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 #pragma unroll
       for (int it = 0; it < NCI; ++it) {
         const int ml = ps * EROWS + (tid + it * NT) / CPRS;
-        const size_t m = (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+        const size_t m = out_m(ml);
         const size_t idx = nok ? m * p.Cout + n : 0;
         ypre[it] = *reinterpret_cast<const V*>(nby + (est.kind == 2 ? idx : 0));
         rpre[it] = *reinterpret_cast<const V*>(resp + (p.residual ? idx : 0));
@@ -408,7 +431,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
           const int c = tid + it * NT;
           const int row = c / CPR, cc = (c - row * CPR) * EP;
           const int ml = ps * EROWS + row, n = n0 + cc;
-          const size_t m = (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+          const size_t m = out_m(ml);
           if (n < p.Cout) {
             float v[EP];
 #pragma unroll
@@ -576,6 +599,32 @@ static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
   if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 2, true, 32, 1>), grid, block, 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 1, true, 32, 1>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 4, 1, 1, 1, true, 32, 1>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+// data gradient of a stride-2 3x3 conv (ConvParams::mode 1: x = dy [B,H,W,Cin], output [B,2H,2W,Cout]) as four parity-class launches
+bool conv_tr2_applicable(const ConvParams& p, int dtype) {
+  static const bool on = [] { const char* e = getenv("PWR_PATCH_TR2"); return e ? atoi(e) != 0 : true; }();
+  return on && dtype == PWR_BF16 && p.mode == 1 && p.ksize == 3 && p.Cin == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr &&
+         !p.y_nchw && !p.st_partial && !p.nb_partial && !p.in_norm;
+}
+
+template <int GEO>
+static void launch_tr2_class(const ConvParams& p, hipStream_t s) {
+  const int bn = pick_bn(p.Cout);
+  dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, GEO>), grid, block, 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 2, 2, 2, 1, true, 32, GEO>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 4, 1, 1, 1, true, 32, GEO>), grid, block, 0, s, p);
+}
+
+int launch_conv_tr2(const ConvParams& p0, hipStream_t s) {
+  ConvParams p = p0;
+  p.stamps = nullptr;
+  launch_tr2_class<5>(p, s);     // (the four-tap class first: the longest)
+  launch_tr2_class<4>(p, s);
+  launch_tr2_class<3>(p, s);
+  launch_tr2_class<2>(p, s);
   return (int)hipGetLastError();
 }
 

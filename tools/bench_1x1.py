@@ -37,3 +37,10 @@ case("1x1 64->128 @32 (+residual)", 32, 64, 128, 1, residual=True)
 case("3x3 128->64 @128 (plain: the stem's data gradient)", 128, 128, 64, 3, norm=False)
 case("3x3 64->32 @128 (plain)", 128, 64, 32, 3, norm=False)
 case("3x3 64->128 @128 (+NR, stats)", 128, 64, 128, 3, stats=True)
+def case_tr2(name):
+    dy = torch.randn(B, 64, 64, 128, device=dev).to(torch.bfloat16)
+    w = torch.randn(128, 128, 3, 3, device=dev) * 0.03
+    pk = K.pack_conv(w, 2, K.BF16)
+    t = timeit(lambda: K.conv_fwd(dy, pk, 128, 3, 1, mode=1))
+    print("%-44s %7.1f us   %6.1f TFLOP/s" % (name, t, 2.0 * B * 64 * 64 * 128 * 128 * 9 / t / 1e6))
+case_tr2("stride-2 data gradient 128<-128 @64->128")
