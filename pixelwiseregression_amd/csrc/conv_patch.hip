@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   constexpr int NB = (BN * 4 + NT - 1) / NT;
   constexpr int EROWS = 64, EPITCH = BN + 4;
   constexpr int EPI_BYTES = EROWS * EPITCH * 4;
-  constexpr int NSTAGE = DMA ? 3 : 2;             // weight ring: LDS-DMA runs two K steps ahead
+  constexpr int NSTAGE = DMA ? (GEO == 1 ? KCH : 3) : 2;   // weight ring: LDS-DMA runs two K steps ahead (1x1: ALL <= 4 stages resident)
   constexpr int LDS_BYTES = (PATCH_BYTES + NSTAGE * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + NSTAGE * WBUF_BYTES) : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   char* patch = smem;
@@ -130,7 +130,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       }
     }
   };
-  if constexpr (DMA) { dma_w(wstage(0), 0); if (1 < NTY * NTX * KCH) dma_w(wstage(1), 1); } else { load_w(wstage(0)); }
+  if constexpr (DMA) {
+    if constexpr (GEO == 1) {
+      // 1x1: the whole K extent of the weights (<= 4 stages) goes to LDS now; the K loop then has no DMA, no waits, no barriers
+#pragma unroll
+      for (int k = 0; k < KCH; ++k) dma_w(wstage(k), k);
+    } else {
+      dma_w(wstage(0), 0);
+      if (1 < NTY * NTX * KCH) dma_w(wstage(1), 1);
+    }
+  } else {
+    load_w(wstage(0));
+  }
 
   // ---- stage the patch: thread -> fixed sub-block and 16-byte channel slot, pixels pl + k*PL of that sub-block
   {
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     auto frag_load = [&](int it, V (&a)[2][MR], V (&bq)[2][NR]) {
       const int tap = it / KCH, kch = it - tap * KCH;
       const int ky = tap / NTX, kx = tap - ky * NTX;     // window offset of the tap inside the patch
-      const char* lB = wbuf + (it % 3) * WBUF_BYTES;
+      const char* lB = wbuf + (GEO == 1 ? it : it % 3) * WBUF_BYTES;
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
 #pragma unroll
@@ -248,23 +259,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
         for (int j = 0; j < NR; ++j) bq[ss][j] = *reinterpret_cast<const V*>(lB + bOff[j][ss]);
       }
     };
-    if (2 < ITERS) dma_w(wstage(2), 2);
+    if constexpr (GEO != 1) { if (2 < ITERS) dma_w(wstage(2), 2); }
     frag_load(0, fa[0], fb[0]);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       // s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (simm16: vmcnt[3:0], expcnt[6:4] = 7 (no wait), lgkmcnt[11:8]): the
       // compiler's own wait-count pass sees it and does not add an lgkmcnt(0) in front of this step's MFMAs, which would
       // wait for the reads just issued for the NEXT step (it cannot see through an inline-asm wait).
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      if (it + 2 < ITERS) {
-        if constexpr (NBW == 2) __builtin_amdgcn_s_waitcnt(0x0072);
-        else __builtin_amdgcn_s_waitcnt(0x0071);
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0070);
+      if constexpr (GEO != 1) {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (it + 2 < ITERS) {
+          if constexpr (NBW == 2) __builtin_amdgcn_s_waitcnt(0x0072);
+          else __builtin_amdgcn_s_waitcnt(0x0071);
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+        __builtin_amdgcn_s_barrier();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (it + 3 < ITERS) dma_w(wstage(it + 3), it % 3);
       }
-      __builtin_amdgcn_s_barrier();
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      if (it + 3 < ITERS) dma_w(wstage(it + 3), it % 3);
       if (it + 1 < ITERS) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
       // pin the order: left alone, the scheduler sinks these reads to just before their first use (shortest live range),
       // i.e. back into the next step, and hoists that step's MFMAs above the barrier -- the read-then-wait form again.
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       if constexpr (sizeof(T) == 2) {
         constexpr int NMFMA = 2 * MR * NR, NREAD = 2 * (MR + NR);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
-        if (it + 3 < ITERS) __builtin_amdgcn_sched_group_barrier(0x010, NBW, 0);   // the LDS-DMA of stage it+3
+        if (GEO != 1 && it + 3 < ITERS) __builtin_amdgcn_sched_group_barrier(0x010, NBW, 0);   // the LDS-DMA of stage it+3
         if (it + 1 < ITERS) {
 #pragma unroll
           for (int k = 1; k < NMFMA; ++k) {
