@@ -129,6 +129,8 @@ def main():
                     help="native: pixelwiseregression_amd.train.TrainStep (loss + AdamW kernels on the flat buffers); "
                          "torch: autograd + torch.optim.AdamW, the reference's loop verbatim")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) | gloo (debug)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the data-parallel path (process group, per-segment all-reduce) even with one rank -- exercises RCCL on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share cuda:0 (with --dist-backend gloo) to exercise the data-parallel path on a 1-GPU box")
     args = ap.parse_args()
@@ -143,9 +145,11 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -156,7 +160,7 @@ def main():
     torch.manual_seed(0)
     model = PixelwiseRegression(J, stage=STAGE, label_size=P, features=F_, level=LEVEL, norm_method="instance")
     model = model.to(dev).set_precision(args.precision).set_backend(args.backend).train()
-    if world > 1:
+    if use_dist:
         from pixelwiseregression_amd.ddp import DataParallel
         DataParallel(model)
     native = args.backend == "hip" and args.harness == "native"
@@ -182,7 +186,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -194,7 +198,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -226,7 +230,7 @@ def main():
                                    "features 128, level 4, stage 2, instance norm" % args.precision,
                        "global_batch": world * B_PER_GPU, "backend": args.backend,
                        "harness": args.harness if args.backend == "hip" else "torch",
-                       "parallelism": "dp%d" % world if world > 1 else "single"},
+                       "parallelism": "dp%d" % world if use_dist else "single"},
             "infer_frames_per_s": world * B_PER_GPU / dt_inf,
             "final_loss": final_loss,
         }
@@ -246,7 +250,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 
