@@ -70,6 +70,13 @@ CONV_CASES = [
     (1, 128, 128, 64, 128, 3, 1),
     (2, 4, 32, 128, 128, 3, 1),
     (1, 8, 96, 32, 16, 3, 1),
+    # 1x1 convs through the LDS-patch kernel (bf16, W % 32 == 0, H % 4 == 0): bottleneck shapes of the ResBlocks, the stage-input
+    # conv with its zero-padded 32-channel concat, 32- / 64- / 128-wide output tiles
+    (2, 64, 64, 128, 64, 1, 1),
+    (2, 64, 64, 64, 128, 1, 1),
+    (3, 32, 32, 128, 128, 1, 1),
+    (2, 8, 64, 32, 128, 1, 1),
+    (2, 32, 32, 128, 24, 1, 1),
     # small square maps (whole images per tile): ragged last tile, several tiles, 2 N tiles
     (3, 2, 2, 64, 64, 3, 1),
     (40, 2, 2, 64, 64, 3, 1),
@@ -119,7 +126,8 @@ def test_conv_forward_nchw_out(dtype, J, H, Cin):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3), (2, 64, 64, 128, 128, 3), (3, 5, 7, 64, 128, 3),
                                   (2, 16, 16, 128, 64, 1), (1, 4, 4, 16, 16, 3), (2, 32, 32, 128, 16, 3),
-                                  (3, 4, 4, 16, 16, 3), (3, 2, 2, 16, 16, 3), (3, 8, 8, 16, 16, 3), (3, 4, 4, 16, 32, 1)])
+                                  (3, 4, 4, 16, 16, 3), (3, 2, 2, 16, 16, 3), (3, 8, 8, 16, 16, 3), (3, 4, 4, 16, 32, 1),
+                                  (2, 64, 64, 128, 64, 1), (2, 32, 32, 64, 128, 1), (2, 32, 64, 128, 32, 1)])
 def test_conv_dgrad_stride1(case, dtype):
     """data gradient = pwr_conv_fwd on dy with the kind-1 (flipped, transposed) weight pack."""
     from pixelwiseregression_amd import kernels as K
@@ -477,7 +485,7 @@ def test_resblock_small_fused_vs_unfused(B, H):
 STATS_CASES = [
     # B, H, W, Cin, Cout, k   (patch kernel: W % 32 == 0; universal: H*W % 128 == 0)
     (2, 64, 64, 128, 128, 3), (3, 32, 32, 64, 64, 3), (2, 8, 32, 32, 64, 3), (2, 32, 32, 128, 64, 1), (3, 16, 16, 64, 128, 1),
-    (2, 64, 64, 16, 128, 3), (1, 128, 128, 32, 64, 3),
+    (2, 64, 64, 16, 128, 3), (1, 128, 128, 32, 64, 3), (2, 64, 64, 64, 128, 1), (2, 32, 64, 128, 32, 1),
 ]
 
 
