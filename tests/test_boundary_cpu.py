@@ -127,3 +127,39 @@ def test_metric_tail_matches_reference_golden(golden_dir):
         xyz = uvd2xyz(rec.numpy(), fx, fy, hu, hv)
         np.testing.assert_allclose(xyz, g[name + "_xyz"], rtol=1e-5, atol=1e-3)
         np.testing.assert_allclose(mean_joint_error(xyz, g[name + "_xyz_gt"]), g[name + "_err"], rtol=1e-5, atol=1e-3)
+
+
+def test_engine_plan_builds_without_a_gpu_and_names_its_arena():
+    """The launch plan is built on the host (no HIP call): the parameter table of the module must be consumed exactly, the plan has
+    stage + 1 backward segments, and pwr_engine_layout names every arena buffer (debugging aid used by tools/determinism_arena.py)."""
+    import ctypes
+    import torch
+    from pixelwiseregression_amd import PixelwiseRegression, _lib
+    l = _lib.lib()
+    for joints, P, B in ((14, 64, 32), (21, 64, 8), (4, 16, 2)):
+        m = PixelwiseRegression(joints, stage=2, label_size=P, features=128, level=4, norm_method="instance")
+        cfg = (ctypes.c_int * 8)(joints, 2, P, 128, 4, 3, 0, 0)
+        offs = [o for (o, _) in m._offsets.values()]
+        nums = [int(torch.Size(s).numel()) for (_, s) in m._offsets.values()]
+        n = len(offs)
+        h = l.pwr_engine_create(cfg, B, 1, 1, (ctypes.c_longlong * n)(*offs), (ctypes.c_longlong * n)(*nums), n, None, 0)
+        assert h, l.pwr_last_error()
+        try:
+            assert l.pwr_engine_num_segments(h) == 3
+            arena = l.pwr_engine_arena_bytes(h)
+            need = l.pwr_engine_layout(h, None, 0)
+            buf = ctypes.create_string_buffer(need)
+            l.pwr_engine_layout(h, buf, need)
+            recs = [line.split(" ", 2) for line in buf.value.decode().splitlines()]
+            assert len(recs) > 100
+            end = 0
+            for off, nbytes, tag in recs:
+                assert int(off) >= end and int(off) % 256 == 0, tag      # buffers are disjoint, in order, 256-byte aligned
+                end = int(off) + int(nbytes)
+            assert end <= arena
+            assert any("scratch:cpartial" in t for _, _, t in recs) and any(".plane:" in t for _, _, t in recs)
+        finally:
+            l.pwr_engine_destroy(h)
+    # a parameter table that does not match the architecture is refused
+    bad = (ctypes.c_longlong * n)(*([nums[0] + 1] + nums[1:]))
+    assert not l.pwr_engine_create(cfg, 2, 1, 1, (ctypes.c_longlong * n)(*offs), bad, n, None, 0)
