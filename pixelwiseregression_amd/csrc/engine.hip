@@ -112,6 +112,10 @@ struct Engine {
   size_t scr_partial = 0, scr_S1 = 0, scr_S2 = 0, scr_slab = 0, scr_slab_bytes = 0;
   size_t need_partial = 0, need_sc = 0;
   size_t scr_cpartial = 0, need_cpartial = 0;   // column statistics written by conv epilogues (pwr_conv_fwd_stats)
+  // The ONE producer/consumer pair of such statistics that spans two backward segments (two C ABI calls, with the all-reduce and
+  // Python in between): stage 0's input-conv data gradient writes the norm-backward reductions of the stem's last norm, the stem
+  // segment's first op reads them.  It has a buffer of its own so that nothing else can ever touch it in between.
+  size_t scr_handoff = 0, need_handoff = 0;
   std::string err;
   long long generation = 0;
   Ctx ctx;
@@ -305,9 +309,10 @@ struct Engine {
   }
   // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
   // chunks > 0: the data-gradient conv that produced g already wrote the two reductions (conv_bwd's return value)
-  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0) {
+  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0, bool handoff = false) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
     Engine* E = this;
+    const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
     if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
     if (chunks > 0) {
       static const bool dbg = getenv("PWR_DEBUG_NB") != nullptr;
@@ -319,9 +324,9 @@ struct Engine {
       bwd_cur.push_back([=](Ctx& c) {
         const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
         if (dbg_here) {
-          hipMemcpyAsync(c.arena + dP, c.arena + E->scr_cpartial, (size_t)Bc * chunks * 2 * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
+          hipMemcpyAsync(c.arena + dP, c.arena + E->*cpart, (size_t)Bc * chunks * 2 * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
           hipMemcpyAsync(c.arena + dG, c.arena + t.goff, (size_t)Bc * HW * C * es, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
-          int rc = pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_cpartial),
+          int rc = pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart),
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
                                          c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
@@ -333,7 +338,7 @@ struct Engine {
           return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                               (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), has_addend ? c.arena + addend_goff : nullptr,
                               c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
-        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_cpartial),
+        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart),
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
                                          c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
@@ -428,7 +433,8 @@ struct Engine {
     if (!nr || accumulate_dx || cv.stride != 1 || !(stats_mask() & 2)) return 0;
     return pwr_conv_stats_chunks(y.H, y.W, cv.Cout, cv.Cin, cv.k, 1, 0, dtype);
   }
-  int conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx) {
+  int conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx,
+               bool handoff = false) {
     const int Bc = B, dt = dtype;
     const bool has_nr = nr != nullptr;
     const NormL n = has_nr ? *nr : NormL{};
@@ -454,8 +460,10 @@ struct Engine {
     const int chunks = dgrad_stats_chunks(nr, cv, y, accumulate_dx);
     if (chunks > 0) {
       const size_t need = (size_t)B * chunks * 2 * cv.Cin * 4;
-      if (need > need_cpartial) need_cpartial = need;
+      if (handoff) { if (need > need_handoff) need_handoff = need; }
+      else if (need > need_cpartial) need_cpartial = need;
       const int nm = norm_mode;
+      const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
       bwd_cur.push_back([=](Ctx& c) {
         const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
         if (mode == 2)
@@ -463,7 +471,7 @@ struct Engine {
                               cv.Cout, cv.Cin, cv.k, 1, 0, dt, c.stream);
         return pwr_conv_fwd_stats(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, Bc, y.H, y.W,
                                   cv.Cout, cv.Cin, cv.k, 1, 0, nullptr, c.arena + x.off, (float*)(c.arena + n.state),
-                                  (float*)(c.arena + E->scr_cpartial), 1, dt, c.stream);
+                                  (float*)(c.arena + E->*cpart), 1, dt, c.stream);
       });
       return chunks;
     }
@@ -692,26 +700,7 @@ struct Engine {
       sc.push_back(cl); sn.push_back(nl); sy.push_back(yl);
     }
     std::vector<Op> stem_bwd;
-    if (tr) {
-      const int ns = (int)sc.size();
-      want_slab((size_t)pwr_stem_conv_wgrad_blocks(B, S) * 32 * ks * ks * 4);
-      // the gradient of the stem output comes from stage 0's 1x1 input conv (built below, run in the previous segment)
-      ConvL cin0; cin0.Cin = F; cin0.Cout = F; cin0.k = 1; cin0.stride = 1;
-      Tn x00; x00.H = P; x00.W = P; x00.C = F;
-      int ch = stages > 0 ? dgrad_stats_chunks(&sn[ns - 1], cin0, x00, false) : 0;
-      for (int i = ns - 1; i >= 1; --i) {
-        norm_bwd(sy[i], sn[i], 0, false, ch);
-        ch = conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false);
-      }
-      norm_bwd(sy[0], sn[0], 0, false, ch);
-      const Tn y0 = sy[0]; const ConvL c0 = sc[0];
-      bwd_cur.push_back([=](Ctx& c) {
-        return run_on_side(c, [=](Ctx& c2) {
-          return pwr_stem_conv_wgrad(c2.img, c2.arena + y0.goff, (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c2.stream);
-        });
-      });
-      std::swap(stem_bwd, bwd_cur);
-    }
+    int stem_in_chunks = 0;   // slab rows per sample that stage 0's input-conv data gradient writes for the stem's last norm
     // ---- stages
     struct StageRec { size_t z, gz, gDt, gH, gD, gwp; long long w_off; };
     std::vector<StageRec> recs(stages);
@@ -795,7 +784,7 @@ struct Engine {
         bwd_cur.insert(bwd_cur.end(), hg_bwd.begin(), hg_bwd.end());
         // stage-input conv backward
         if (s == 0) {
-          conv_bwd(ystem, &nstem, cin, x0, true, true, false);
+          stem_in_chunks = conv_bwd(ystem, &nstem, cin, x0, true, true, false, /*handoff=*/true);
         } else {
           const int sp = s - 1;
           const StageRec Rp = recs[sp];
@@ -808,6 +797,27 @@ struct Engine {
         std::swap(stage_bwd[s], bwd_cur);
       }
     }
+    scope = "stem.bwd";
+    if (tr) {
+      if (!bwd_cur.empty()) { err = "internal: backward list not empty before the stem"; return false; }
+      const int ns = (int)sc.size();
+      want_slab((size_t)pwr_stem_conv_wgrad_blocks(B, S) * 32 * ks * ks * 4);
+      // the gradient of the stem output comes from stage 0's 1x1 input conv (built above, run in the previous segment):
+      // stem_in_chunks is what that launch really writes (its conv_bwd's return value), in the hand-off buffer
+      int ch = stem_in_chunks;
+      for (int i = ns - 1; i >= 1; --i) {
+        norm_bwd(sy[i], sn[i], 0, false, ch, /*handoff=*/i == ns - 1);
+        ch = conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false);
+      }
+      norm_bwd(sy[0], sn[0], 0, false, ch);
+      const Tn y0 = sy[0]; const ConvL c0 = sc[0];
+      bwd_cur.push_back([=](Ctx& c) {
+        return run_on_side(c, [=](Ctx& c2) {
+          return pwr_stem_conv_wgrad(c2.img, c2.arena + y0.goff, (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c2.stream);
+        });
+      });
+      std::swap(stem_bwd, bwd_cur);
+    }
     if (pcur != poff.size()) { err = "parameter table longer than the network"; return false; }
     if (!err.empty()) return false;
     // shared scratch
@@ -815,6 +825,7 @@ struct Engine {
     scr_partial = alloc(need_partial, "partial");
     scr_S1 = alloc(need_sc, "S1"); scr_S2 = alloc(need_sc, "S2");
     scr_cpartial = alloc(need_cpartial, "cpartial");
+    scr_handoff = alloc(need_handoff, "stem_handoff");
     scr_slab_bytes = (scr_slab_bytes + 255) / 256 * 256;
     scr_slab = alloc(scr_slab_bytes * Ctx::kMaxSide, "slab");
     ctx.slab_stride = scr_slab_bytes;

@@ -62,14 +62,42 @@ class _Plan:
             pass
 
 
+MAX_PLANS = 4          # per module: e.g. (train B), (eval B), (ragged last eval batch), one spare
+
+
+def _plan_budget_bytes(dev):
+    """Arena bytes the cached plans of one module may hold together (least recently used plans beyond it are dropped):
+    PWR_PLAN_BUDGET_GB, default half of the device's memory."""
+    import os
+    env = os.environ.get("PWR_PLAN_BUDGET_GB")
+    if env:
+        return int(float(env) * (1 << 30))
+    try:
+        return torch.cuda.get_device_properties(dev).total_memory // 2
+    except Exception:
+        return 64 << 30
+
+
 def _get_plan(model, B, dtype, need_grad):
+    """The plan of (batch, dtype, grad) for this module, most recently used last.  A plan owns an activation arena of
+    2-54 GB, so the cache is bounded: at most MAX_PLANS plans and _plan_budget_bytes() of arena; older ones are evicted
+    (a ragged last validation batch no longer doubles the footprint for the rest of the run)."""
     if model._engine is None:
         model._engine = {}
+    cache = model._engine
     key = (B, dtype, need_grad)
-    plan = model._engine.get(key)
+    plan = cache.pop(key, None)
     if plan is None:
         plan = _Plan(model, B, dtype, need_grad)
-        model._engine[key] = plan
+    cache[key] = plan                      # dicts keep insertion order: re-inserting makes it the most recent
+    budget = _plan_budget_bytes(model._flat.device)
+    while len(cache) > 1 and (len(cache) > MAX_PLANS or sum(p.arena.numel() for p in cache.values()) > budget):
+        old_key = next(iter(cache))
+        if old_key == key:
+            break
+        old = cache.pop(old_key)
+        torch.cuda.current_stream(model._flat.device).synchronize()    # its launches may still be in flight
+        del old
     return plan
 
 
@@ -102,8 +130,10 @@ class _EngineFn(torch.autograd.Function):
         outs = _run_forward(model, plan, img, label_img, mask)
         ctx.model, ctx.plan = model, plan
         ctx.generation = _lib.lib().pwr_engine_generation(plan.h)
-        ctx.inputs = (img, label_img, mask)      # keep alive: the backward re-reads them
-        ctx.outs = outs
+        # The backward re-reads the inputs and the outputs.  They go through save_for_backward, NOT onto ctx as attributes:
+        # `ctx.outs = outs` would form the cycle output -> grad_fn -> ctx -> output, which the garbage collector cannot
+        # break (six outputs share one grad_fn), and every training forward would leak its output maps.
+        ctx.save_for_backward(img, label_img, mask, *outs)
         return tuple(outs)
 
     @staticmethod
@@ -113,11 +143,13 @@ class _EngineFn(torch.autograd.Function):
         if l.pwr_engine_generation(plan.h) != ctx.generation:
             raise _lib.PwrError("backward() after another forward() of the same (batch, dtype) plan: the engine keeps one "
                                 "set of activations per plan. Call backward before the next training forward.")
-        dev = ctx.outs[0].device
+        saved = ctx.saved_tensors
+        outs = saved[3:]
+        dev = outs[0].device
         stream = _lib.stream_ptr(dev)
         keep = []
         ptrs = []
-        for g, o in zip(gouts, ctx.outs):
+        for g, o in zip(gouts, outs):
             if g is None:
                 ptrs.append(None)
             else:

@@ -138,7 +138,6 @@ class PixelwiseRegression(nn.Module):
         self.stages = nn.ModuleList(stages)
         b.xavier()
         self._precision = os.environ.get("PWR_PRECISION", "fp32")
-        self._backend = os.environ.get("PWR_BACKEND", "hip")
         self._flat = None
         self._flat_grad = None
         self._engine = None
@@ -191,6 +190,7 @@ class PixelwiseRegression(nn.Module):
         self._sviews = None
         self._trig = None
         self._param_list = params
+        self._byte_offsets = [4 * o for (o, _) in self._offsets.values()]
         self._engine = None
 
     def _set_buffer(self, dotted, tensor):
@@ -202,10 +202,13 @@ class PixelwiseRegression(nn.Module):
 
     def _check_flat(self):
         """Parameters must still alias the flat buffer (deepcopy / manual .data assignment break that)."""
-        ps = self._param_list
-        last_off = self._flat.numel() - ps[-1].numel()
-        if ps[0].data_ptr() != self._flat.data_ptr() or ps[-1].data_ptr() != self._flat.data_ptr() + 4 * last_off:
-            self._flatten()
+        base = self._flat.data_ptr()
+        # EVERY parameter is checked (~340 integer compares, tens of microseconds of host time that the GPU hides): a manual
+        # `.data =` or load_state_dict(assign=True) on a middle parameter would otherwise train on stale weights silently
+        for p, o in zip(self._param_list, self._byte_offsets):
+            if p.data_ptr() != base + o:
+                self._flatten()
+                return
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -218,7 +221,7 @@ class PixelwiseRegression(nn.Module):
         new.load_state_dict(self.state_dict())
         new = new.to(self._flat.device)
         new.train(self.training)
-        new._precision, new._backend = self._precision, self._backend
+        new._precision = self._precision
         for (_, a), (_, b) in zip(self.named_parameters(), new.named_parameters()):
             b.requires_grad_(a.requires_grad)
         return new
@@ -272,22 +275,11 @@ class PixelwiseRegression(nn.Module):
         self._precision = precision
         return self
 
-    def set_backend(self, backend):
-        """'hip' (default, the product) or 'aten' (PyTorch-ROCm library ops; A/B and debugging only --
-        it still needs a GPU and still uses the HIP decoder)."""
-        if backend not in ("hip", "aten"):
-            raise ValueError(backend)
-        self._backend = backend
-        return self
-
     # ------------------------------------------------------------------ forward
     def forward(self, img, label_img, mask):
         if not img.is_cuda:
             from ._lib import PwrError
             raise PwrError("PixelwiseRegression (MI355X build) runs on the GPU only; move the module and the "
                            "inputs to 'cuda'. There is no CPU fallback.")
-        if self._backend == "aten":
-            from ._aten_backend import aten_forward
-            return aten_forward(self, img, label_img, mask)
         from .engine import engine_forward
         return engine_forward(self, img, label_img, mask)

@@ -49,6 +49,13 @@ class TrainStep:
         B, J, P = img.shape[0], m.joints, m.label_size
         dtype = BF16 if (m._precision == "bf16" or torch.is_autocast_enabled()) else F32
         m._check_flat()
+        flat = m.flat_parameters()
+        if self.m.device != flat.device or self.m.numel() != flat.numel():
+            # model.to(...) / a re-flatten moved the parameters: optimizer state on the old buffer would be applied to the
+            # wrong device or the wrong elements
+            raise _lib.PwrError("TrainStep: the module's flat parameter buffer changed (device %s -> %s, %d -> %d elements) after the "
+                                "optimizer state was created; build a new TrainStep after model.to(...) / load of another architecture"
+                                % (self.m.device, flat.device, self.m.numel(), flat.numel()))
         img, label_img, mask, uvd = (t.contiguous().float() for t in (img, label_img, mask, uvd))
         plan = _get_plan(m, B, dtype, True)
         outs = _run_forward(m, plan, img, label_img, mask)
@@ -104,7 +111,6 @@ class TrainStep:
             ddp.wait()
             scale = 1.0 / ddp.world
         self.steps += 1
-        flat = m.flat_parameters()
         if self.opt == "adam":
             _lib.check(l.pwr_adamw_step(flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), n, self.lr, self.beta1,
                                         self.beta2, self.eps, self.wd, self.steps, scale, stream), "pwr_adamw_step")
@@ -112,4 +118,4 @@ class TrainStep:
             _lib.check(l.pwr_sgd_step(flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), n, self.lr, self.beta1, self.wd,
                                       1 if self.steps == 1 else 0, scale, stream), "pwr_sgd_step")
         self._keep = (outs, img, label_img, mask, uvd)      # alive until the next step: the stream may still read them
-        return self.loss
+        return self.loss.clone()      # a fresh tensor per step (self.loss is overwritten by the next step)

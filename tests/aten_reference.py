@@ -1,11 +1,12 @@
-"""A/B backend: the conv stack through PyTorch-ROCm library ops (MIOpen / ATen) on the GPU, with the
-HIP decoder.  NOT the product path -- it exists so that bench.py and the tests can put the native
-engine next to "what stock PyTorch does on the same MI355X".  Needs a GPU like everything else.
+"""Test / A-B instrument, NOT part of the product package: the conv stack of a pixelwiseregression_amd.PixelwiseRegression
+module evaluated through PyTorch-ROCm library ops (MIOpen / ATen) on the GPU, with the HIP decoder.  The tests and
+tools/bench_aten.py use it to put the native engine next to "what stock PyTorch does on the same MI355X".
+The product module has no backend switch: `model(...)` always runs the HIP engine.
 """
 import torch
 import torch.nn.functional as F
 
-from .ops import decode
+from pixelwiseregression_amd.ops import decode
 
 
 def _norm(m, node, x):

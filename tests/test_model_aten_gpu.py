@@ -1,4 +1,4 @@
-"""GPU: the A/B 'aten' backend (PyTorch-ROCm conv stack + HIP decoder) against the reference's golden
+"""GPU: tests/aten_reference.py (PyTorch-ROCm conv stack + HIP decoder, a test instrument) against the reference's golden
 vectors.  This pins the boundary wiring (state_dict -> forward) independently of the native conv engine."""
 import os
 
@@ -18,9 +18,10 @@ def test_aten_backend_tiny_golden(golden_dir, name):
                             features=int(g["cfg_features"]), level=int(g["cfg_level"]), kernel_size=int(g["cfg_kernel_size"]),
                             norm_method=str(g["cfg_norm_method"]), heatmap_method=str(g["cfg_heatmap_method"]))
     m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
-    m = m.to(dev).set_backend("aten")
+    m = m.to(dev)
+    from aten_reference import aten_forward
     batch = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
-    res = m(batch["img"], batch["label_img"], batch["mask"])
+    res = aten_forward(m, batch["img"], batch["label_img"], batch["mask"])
     loss = 0
     for s, (p, D, uvd) in enumerate(res):
         np.testing.assert_allclose(uvd.detach().cpu().numpy(), g["a100_s%d_uvd" % s], atol=5e-4)

@@ -88,4 +88,15 @@ if bool(have):
                                                                         dd[:, 1].unique().tolist()[:10])
             if dd.shape[0]:
                 j = tuple(dd[0].tolist()); line += "  e.g. %.6g vs %.6g" % (float(xf[j]), float(yf[j]))
+        elif name in ("z", "gz", "gDt", "gH", "gD"):
+            xf, yf = x.view(torch.float32).view(B, 14, -1), y.view(torch.float32).view(B, 14, -1)
+            dd = (xf != yf).nonzero()
+            line += "  elements %d; samples %s joints %s pixels %s" % (dd.shape[0], dd[:, 0].unique().tolist()[:6], dd[:, 1].unique().tolist()[:10],
+                                                                      dd[:, 2].unique().tolist()[:10])
+            if dd.shape[0]:
+                j = tuple(dd[0].tolist()); line += "  e.g. %.6g vs %.6g" % (float(xf[j]), float(yf[j]))
+        elif name in ("gwp",):
+            xf, yf = x.view(torch.float32), y.view(torch.float32)
+            dd = (xf != yf).nonzero().flatten()
+            line += "  entries %s" % dd.tolist()[:8]
         print(line)
