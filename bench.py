@@ -13,8 +13,13 @@ over RCCL per backward segment.  Rank 0 prints ONE JSON line; besides the contra
   roofline      -- the dominant kernel (the 128->128 3x3 implicit-GEMM conv of the heads: 72 % of the conv
                    FLOPs), timed live with HIP events at the workload's shape, against the dense bf16 MFMA peak
   roofline_decoder -- the soft-argmax decoder (HBM bound) forward at the same batch, for reference
-  cpu_baseline  -- the CPU oracle ("port" of the reference's op sequence) timed on this host's cores
+  cpu_baseline  -- the CPU oracle ("port" of the reference's op sequence) timed on this host's cores, BASELINE.md section 3
+                   protocol (config batch, os.cpu_count() threads, 3 warm-up + 10 timed steps, median)
   infer_frames_per_s -- forward+decode only (no_grad), same batch
+  accuracy      -- the second half of BASELINE.json's metric: mean 3D joint error (mm, train.py:254-285) on held-out rendered
+                   synthetic hands after --accuracy-steps training steps, for the bf16 engine (the benched configuration) and
+                   the fp32 parity engine from the same initial weights (outside the timed region)
+  step_mfma_frac -- conv FLOPs of one train step (3 x 20.88 GFLOP/frame) / step time / dense bf16 MFMA peak
 """
 import argparse
 import json
@@ -29,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 J, S, P, F_, LEVEL, STAGE, B_PER_GPU = 14, 128, 64, 128, 4, 2, 32
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3        # f32-input MFMA (= the fp32 vector peak), same guide
 PEAK_HBM_GBS = 8000.0
 
 
@@ -42,12 +48,15 @@ def train_loss(results, batch, alpha=1.0, lambda_h=1.0, lambda_d=0.01):
     return loss
 
 
-def time_head_conv(dev, B, iters=20):
-    """The dominant kernel at the workload's shape: x [B,64,64,128] bf16 -> conv3x3 128->128 (+ fused norm/ReLU prologue)."""
+def time_head_conv(dev, B, iters=20, precision="bf16"):
+    """The dominant kernel at the workload's shape: x [B,64,64,128] -> conv3x3 128->128 (+ fused norm/ReLU prologue), in the
+    engine's precision (bf16 MFMA, or the exact-f32 MFMA of the parity mode)."""
     from pixelwiseregression_amd import kernels as K
-    x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
+    x = torch.randn(B, P, P, F_, device=dev)
+    if precision == "bf16":
+        x = x.to(torch.bfloat16)
     w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
-    pack = K.pack_conv(w, 0, K.BF16)
+    pack = K.pack_conv(w, 0, K.BF16 if precision == "bf16" else K.F32)
     gamma, beta = torch.ones(F_, device=dev), torch.zeros(F_, device=dev)
     st = K.norm_stats(x, gamma, beta, mode=0)
     bias = torch.zeros(F_, device=dev)
@@ -86,12 +95,26 @@ def time_decoder(dev, B, iters=20):
     return t, nbytes
 
 
-def cpu_baseline(Bc=8, iters=2):
-    """CPU oracle train step (fwd + loss + bwd + AdamW) on a bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(Bc=B_PER_GPU, warmup=3, iters=10, budget_s=60.0):
+    """CPU oracle on a bounded sample of the same workload, BASELINE.md section 3 protocol: the config's batch, fp32,
+    torch.set_num_threads(os.cpu_count()), `warmup` + `iters` timed train steps (fwd + loss of train.py:197-205 + bwd + AdamW),
+    median; inference (no_grad forward + decode) separately.  If the host is so slow that this would exceed `budget_s`, the
+    iteration counts are cut (never below 1 + 3) and the `sample` text says so."""
+    import statistics
     from oracle import model_ref
     from pixelwiseregression_amd import PixelwiseRegression
     from pixelwiseregression_amd.synthetic import make_batch
-    cores = min(os.cpu_count() or 1, 32)     # more threads than that only adds contention at this batch size
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = PixelwiseRegression(J, stage=STAGE, label_size=P, features=F_, level=LEVEL, norm_method="instance")
@@ -101,20 +124,50 @@ def cpu_baseline(Bc=8, iters=2):
     batch = make_batch(Bc, J, S=S, seed=1234, dense_targets=True)
 
     def step():
+        t = time.perf_counter()
         opt.zero_grad()
         res = model_ref.forward(params, rc, batch["img"], batch["label_img"], batch["mask"], training=True)
         loss = model_ref.train_loss(res, batch["uvd"], batch["heatmaps"], batch["depthmaps"], alpha=1.0)
         loss.backward()
         opt.step()
+        return time.perf_counter() - t
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    def infer():
+        t = time.perf_counter()
+        with torch.no_grad():
+            model_ref.forward(params, rc, batch["img"], batch["label_img"], batch["mask"], training=False)
+        return time.perf_counter() - t
+
+    t_first = step()
+    if t_first * (warmup + iters) > budget_s:
+        warmup, iters = 1, max(3, min(iters, int(budget_s / t_first) - 1))
+    for _ in range(warmup - 1):
         step()
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": Bc / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps (fwd+loss+bwd+AdamW) of the CPU oracle at batch %d, same architecture and 128x128 crops, fp32, %d threads"
-                      % (iters, Bc, cores)}
+    ts = [step() for _ in range(iters)]
+    dt = statistics.median(ts)
+    infer()
+    ti = statistics.median([infer() for _ in range(3)])
+    return {"value": Bc / dt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+            "infer_value": Bc / ti,
+            "sample": "median of %d timed train steps (fwd+loss+bwd+AdamW) after %d warm-up of the CPU oracle at batch %d (the config's), "
+                      "same architecture and 128x128 crops, fp32, %d threads; inference = median of 3 no_grad forwards"
+                      % (iters, warmup, Bc, cores)}
+
+
+def accuracy_block(steps, dev):
+    """mean 3D joint error (mm) after `steps` training steps on streamed synthetic hands, bf16 vs fp32 engine (same init)."""
+    from pixelwiseregression_amd.evaluate import train_and_validate
+    out = {"steps": steps, "task": "rendered synthetic hands (synthetic.make_pose_batch), NYU intrinsics, cube 150 mm, batch %d, AdamW lr 1e-3, "
+                                   "4 held-out batches; metric = train.py:254-285" % B_PER_GPU}
+    for prec in ("bf16", "fp32"):
+        r = train_and_validate(prec, steps, B=B_PER_GPU, J=J, S=S, lr=1e-3, eval_every=max(50, steps // 4), dev=dev, features=F_, level=LEVEL,
+                               stage=STAGE)
+        out["mm_error_" + prec] = r["final_mm"]
+        out["mm_error_untrained"] = r["curve"][0]["mm"][-1]
+        out["curve_" + prec] = [(c["step"], round(c["mm"][-1], 3)) for c in r["curve"]]
+        out["final_train_loss_" + prec] = sum(r["train_loss"][-20:]) / 20
+    out["bf16_over_fp32"] = out["mm_error_bf16"] / out["mm_error_fp32"]
+    return out
 
 
 def main():
@@ -123,8 +176,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--backend", default="hip", choices=["hip", "aten"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accuracy-steps", type=int, default=300,
+                    help="training steps of the accuracy block (mm error, bf16 and fp32 engines; rank 0 at N=1 only); 0 = skip")
     ap.add_argument("--harness", default="native", choices=["native", "torch"],
                     help="native: pixelwiseregression_amd.train.TrainStep (loss + AdamW kernels on the flat buffers); "
                          "torch: autograd + torch.optim.AdamW, the reference's loop verbatim")
@@ -159,20 +213,18 @@ def main():
     from pixelwiseregression_amd.synthetic import make_batch
     torch.manual_seed(0)
     model = PixelwiseRegression(J, stage=STAGE, label_size=P, features=F_, level=LEVEL, norm_method="instance")
-    model = model.to(dev).set_precision(args.precision).set_backend(args.backend).train()
+    model = model.to(dev).set_precision(args.precision).train()
     if use_dist:
         from pixelwiseregression_amd.ddp import DataParallel
         DataParallel(model)
-    native = args.backend == "hip" and args.harness == "native"
+    native = args.harness == "native"
     if native:
         from pixelwiseregression_amd.train import TrainStep
         trainer = TrainStep(model, opt="adam", lr=1e-4, beta1=0.9, beta2=0.999, weight_decay=0.0, alpha=1.0, lambda_h=1.0, lambda_d=0.01)
-    elif args.backend == "hip":
+    else:
         flat = torch.nn.Parameter(model.flat_parameters())
         flat.grad = model.flat_grad()
         opt = torch.optim.AdamW([flat], lr=1e-4, betas=(0.9, 0.999), weight_decay=0, fused=True)
-    else:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0)
     batch = make_batch(B_PER_GPU, J, S=S, seed=1234 + rank, device=dev, dense_targets=True)
 
     def step():
@@ -228,25 +280,35 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: NYU 14-joint, 128x128 depth crops, batch 32 per GPU, train (AdamW, %s), "
                                    "features 128, level 4, stage 2, instance norm" % args.precision,
-                       "global_batch": world * B_PER_GPU, "backend": args.backend,
-                       "harness": args.harness if args.backend == "hip" else "torch",
+                       "global_batch": world * B_PER_GPU, "backend": "hip", "harness": args.harness,
                        "parallelism": "dp%d" % world if use_dist else "single"},
             "infer_frames_per_s": world * B_PER_GPU / dt_inf,
             "final_loss": final_loss,
         }
-        if args.backend == "hip":
-            t, flops = time_head_conv(dev, B_PER_GPU)
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
-            if os.path.exists(tj):     # HBM bytes per launch from the rocprofv3 PMC passes (see the file for the command)
-                traffic = json.load(open(tj)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
-            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_patch_kernel<bf16,Cin128,128x128 tile> 3x3 128->128 @64x64, B=%d (+fused norm/ReLU)" % B_PER_GPU,
-                               "achieved": flops / t / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": flops / t / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic, "us_per_launch": t * 1e6,
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        step_flops = 3 * 20.88e9 * B_PER_GPU            # 20.88 GFLOP/frame forward at C2, x3 for training
+        out["step_mfma_frac"] = step_flops / (dt / args.steps) / (peak * 1e12)
+        if True:   # (kept as a block: the roofline probes run on every rank-0 report)
+            t, flops = time_head_conv(dev, B_PER_GPU, precision=args.precision)
+            # HBM bytes per launch: NOT measured in this run -- replayed from the committed rocprofv3 PMC passes of the same kernel
+            # and shape (PMC collection needs its own rocprofv3 runs); `traffic_source` names the file
+            traffic, traffic_source = None, None
+            for tj in ("r2_traffic.json", "r1_traffic.json"):
+                fp = os.path.join(ROOT, "profiles", tj)
+                if os.path.exists(fp):
+                    traffic = None if args.precision != "bf16" else json.load(open(fp)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
+                    traffic_source = "profiles/" + tj
+                    if traffic is not None:
+                        break
+            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3 128->128 @64x64, B=%d (+fused norm/ReLU), %s operands" % (B_PER_GPU, args.precision),
+                               "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                               "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": t * 1e6,
                                "flop_per_launch": flops}
             td, nb = time_decoder(dev, B_PER_GPU)
             out["roofline_decoder"] = {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": td * 1e6}
+        if world == 1 and not use_dist and args.accuracy_steps > 0:
+            out["accuracy"] = accuracy_block(args.accuracy_steps, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

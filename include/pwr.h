@@ -36,6 +36,8 @@ extern "C" {
 /* ABI version of this header; pwr_abi_version() must return the same number. */
 #define PWR_ABI_VERSION 1
 int pwr_abi_version(void);
+/* debugging aid: dst = src (bytes % 16 == 0) iff *flag != 0, decided on the device (tools/race_hunt.py) */
+int pwr_debug_copy_if(const int* flag, const void* src, void* dst, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder (SURVEY.md section 8 a-D)

@@ -269,11 +269,73 @@ def gen_targets(ref_utils):
     print("targets done")
 
 
+def gen_wellcond(ref_model):
+    """WELL-CONDITIONED gradient fixtures: (config, weights seed, rendered-hand batch) triples on which the reference's own
+    fp32 gradient is within 6e-5 (per tensor, relative to the tensor's largest entry) of its float64 evaluation -- no ReLU /
+    max-pool / arg-max decision sits at a near-tie -- so that a hard per-tensor bound can be asserted on the engine
+    (tests/test_parity_holes_gpu.py).  Innermost hourglass maps are 8x8 (a, c) and 4x4 (b)."""
+    from weights_util import fill_state_dict
+    from pixelwiseregression_amd.synthetic import make_batch, make_pose_batch
+    rec = {}
+    for tag, (stage, level, alpha) in (("a", (2, 1, 0.5)), ("b", (2, 2, 1.0)), ("c", (1, 1, 0.5))):
+        cfg = dict(joints=4, stage=stage, label_size=32, features=32, level=level, kernel_size=3, norm_method="instance",
+                   heatmap_method="softmax")
+        proto = ref_model.PixelwiseRegression(4, **{k: v for k, v in cfg.items() if k != "joints"})
+        sd = fill_state_dict(proto.state_dict(), seed=7)
+        batch = make_batch(2, 4, S=64, seed=99, dense_targets=True)
+        pb = make_pose_batch(2, 4, 64, seed=5)
+        batch.update({k: pb[k] for k in ("img", "label_img", "mask", "uvd")})
+        o32, g32, _ = _run_model(ref_model, cfg, sd, batch, alpha)
+        o64, g64, _ = _run_model(ref_model, cfg, sd, batch, alpha, double=True)
+        gm = max(np.abs(v).max() for v in g64.values())
+        worst = max(np.abs(g32[k] - g64[k]).max() / np.abs(g64[k]).max() for k in g32 if np.abs(g64[k]).max() > 1e-6 * gm)
+        assert worst < 6e-5, (tag, worst)
+        pre = tag + "_"
+        rec.update({pre + "cfg_" + k: np.array(v) for k, v in cfg.items()})
+        rec[pre + "alpha"] = np.float64(alpha)
+        rec[pre + "weights_seed"] = np.array(7)
+        rec[pre + "ref32_vs_f64_worst"] = np.float64(worst)
+        rec.update({pre + "in_" + k: v.numpy() for k, v in batch.items()})
+        rec.update({pre + "f32_" + k: v for k, v in o32.items()})
+        rec.update({pre + "f64_" + k: v for k, v in o64.items()})
+        rec.update({pre + "f32_grad_" + k: v for k, v in g32.items()})
+        rec.update({pre + "f64_grad_" + k: v for k, v in g64.items()})       # kept in float64
+        print("wellcond", tag, "reference fp32 vs f64, worst tensor: %.2e" % worst)
+    np.savez_compressed(os.path.join(OUT, "wellcond.npz"), **rec)
+
+
+def gen_checkpoint(ref_model, ref_utils):
+    """A checkpoint file written by the REFERENCE's own utils.save_model (utils.py:302-307) from a reference module, plus that
+    module's outputs on a fixed batch: the build must load the file with strict=True and reproduce the outputs."""
+    from weights_util import fill_state_dict
+    from pixelwiseregression_amd.synthetic import make_pose_batch
+    kw = dict(stage=2, label_size=16, features=32, level=2, kernel_size=3, norm_method="batch", heatmap_method="softmax")
+    torch.manual_seed(4321)
+    m = ref_model.PixelwiseRegression(4, **kw)
+    sd = fill_state_dict(m.state_dict(), seed=13)
+    sd = {k: (v if "num_batches_tracked" not in k else torch.tensor(17)) for k, v in sd.items()}
+    m.load_state_dict(sd)
+    path = os.path.join(OUT, "reference_checkpoint.pt")
+    ref_utils.save_model(m, path, seed=4321, model_param=kw)
+    batch = make_pose_batch(2, 4, 32, seed=8)
+    m.eval()
+    with torch.no_grad():
+        res = m(batch["img"], batch["label_img"], batch["mask"])
+    rec = {"in_" + k: batch[k].numpy() for k in ("img", "label_img", "mask")}
+    for s_, (p_, D_, uvd_) in enumerate(res):
+        rec["s%d_p" % s_], rec["s%d_D" % s_], rec["s%d_uvd" % s_] = p_.numpy(), D_.numpy(), uvd_.numpy()
+    np.savez_compressed(os.path.join(OUT, "reference_checkpoint_outputs.npz"), **rec)
+    print("checkpoint written by the reference:", os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "targets":     # (add one fixture without regenerating the others)
+    if len(sys.argv) > 1:     # (add named fixtures without regenerating the others): targets | wellcond | checkpoint
         os.makedirs(OUT, exist_ok=True)
-        _, ref_utils, _ = import_reference()
-        gen_targets(ref_utils)
+        torch.set_num_threads(8)
+        ref_model, ref_utils, _ = import_reference()
+        for what in sys.argv[1:]:
+            {"targets": lambda: gen_targets(ref_utils), "wellcond": lambda: gen_wellcond(ref_model),
+             "checkpoint": lambda: gen_checkpoint(ref_model, ref_utils)}[what]()
         sys.exit(0)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -284,3 +346,5 @@ if __name__ == "__main__":
     gen_metric(ref_utils, ref_datasets)
     gen_init(ref_model)
     gen_targets(ref_utils)
+    gen_wellcond(ref_model)
+    gen_checkpoint(ref_model, ref_utils)

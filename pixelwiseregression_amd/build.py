@@ -32,7 +32,17 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=(), lib=None, obj=None):
+    """extra_flags / lib / obj: build a VARIANT of the library beside the product one (A/B experiments, e.g.
+    build(extra_flags=["-fno-slp-vectorize"], lib=".../libpwr_hip_noslp.so", obj=".../_obj_noslp"); load it with PWR_LIB)."""
+    global FLAGS, LIB, OBJ
+    if extra_flags or lib or obj:
+        saved = (FLAGS, LIB, OBJ)
+        FLAGS, LIB, OBJ = FLAGS + list(extra_flags), lib or LIB, obj or OBJ
+        try:
+            return build(force, verbose)
+        finally:
+            FLAGS, LIB, OBJ = saved
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "pwr.h"))
@@ -61,7 +71,7 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s + ".o") for s in _sources()]
+    objs = [os.path.join(OBJ, s_ + ".o") for s_ in _sources()]
     if jobs or not os.path.exists(LIB) or force:
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

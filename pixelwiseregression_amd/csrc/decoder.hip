@@ -13,6 +13,8 @@
 // loads and kept in registers between the reduction and the element-wise tail; L and m
 // ([B,1,P,P]) are shared by the J maps of a sample and are served by L2.  Algorithmic traffic:
 // forward 12 B/pixel/map (z, D in; p out), backward 28 B (p, z, D, gH, gD in; gz, gD out).
+#include <cstdlib>
+
 #include "pwr_common.h"
 
 namespace pwr {
@@ -155,7 +157,15 @@ __global__ __launch_bounds__(NT) void decode_fwd_generic(const float* __restrict
 //   g_D = gD_in + gd * p * m*m / S
 // gH / gD_in may be null (treated as zeros).  gw_part is [B*J] (reduced over b by decode_gw_reduce).
 // ---------------------------------------------------------------------------------------------
-template <int NT, int NV>
+// wave-uniform scalars (gU, uvd, w): with SC1 they are fetched by agent-scope relaxed atomic loads (global_load ... sc1: served by
+// L2, bypassing the scalar data cache and the vector L1) instead of the s_load the compiler picks for uniform read-only addresses
+template <bool SC1>
+__device__ __forceinline__ float uniform_load(const float* p) {
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+template <int NT, int NV, bool SC1 = false>
 __global__ __launch_bounds__(NT) void decode_bwd_cached(const float* __restrict__ p, const float* __restrict__ z,
                                                         const float* __restrict__ D, const float* __restrict__ L,
                                                         const float* __restrict__ m, const float* __restrict__ w,
@@ -172,9 +182,10 @@ __global__ __launch_bounds__(NT) void decode_bwd_cached(const float* __restrict_
   const int col0 = (tid * 4) % P;
   const int rows_per_step = (NT * 4) / P;
   const int row0 = (tid * 4) / P;
-  const float gu = gU[(size_t)map * 3 + 0], gv = gU[(size_t)map * 3 + 1], gd = gU[(size_t)map * 3 + 2];
-  const float d = uvd[(size_t)map * 3 + 2];
-  const float wj = (method == 0) ? w[j] : 1.f;
+  const float gu = uniform_load<SC1>(gU + (size_t)map * 3 + 0), gv = uniform_load<SC1>(gU + (size_t)map * 3 + 1),
+              gd = uniform_load<SC1>(gU + (size_t)map * 3 + 2);
+  const float d = uniform_load<SC1>(uvd + (size_t)map * 3 + 2);
+  const float wj = (method == 0) ? uniform_load<SC1>(w + j) : 1.f;
 
   f32x4 pv[NV], gp[NV], pm2[NV];
   float r1[2] = {0.f, 0.f};  // S (without eps), T (sum method)
@@ -333,7 +344,10 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
   if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int N = P * P, maps = B * J;
-  if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
+  static const int sc1 = [] { const char* e = getenv("PWR_DEC_SCALAR_SC1"); return e ? atoi(e) : 0; }();   // experiment switch (tools/race_hunt.py)
+  if (sc1 && P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, true>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  else if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
   else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);

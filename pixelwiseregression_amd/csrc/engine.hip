@@ -46,7 +46,11 @@ struct Ctx {
   // so independent layers' weight gradients overlap each other as well as the main chain.
   static constexpr int kMaxSide = 4;
   hipStream_t side[kMaxSide] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
+  // Fork events: a pool used round-robin, one event per side-stream op in flight, instead of ONE event re-recorded for every op
+  // (legal by the API -- a wait captures the record that precedes it -- but then every wait of a step hangs off one object).
+  static constexpr int kForkPool = 64;
+  hipEvent_t ev_fork[kForkPool] = {}, ev_join[kMaxSide] = {};
+  int n_fork = 0, fork_rr = 0;
   int n_side = 0, side_rr = 0;
   size_t slab_off = 0, slab_stride = 0;   // byte offset of the current stream's slab inside the slab scratch
   bool use_side = true;
@@ -57,8 +61,10 @@ static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
   if (!c.use_side || c.n_side == 0) return op(c);
   const int k = c.side_rr;
   c.side_rr = (k + 1) % c.n_side;
-  hipEventRecord(c.ev_fork, (hipStream_t)c.stream);
-  hipStreamWaitEvent(c.side[k], c.ev_fork, 0);
+  hipEvent_t ev = c.ev_fork[c.fork_rr];
+  c.fork_rr = (c.fork_rr + 1) % c.n_fork;
+  hipEventRecord(ev, (hipStream_t)c.stream);
+  hipStreamWaitEvent(c.side[k], ev, 0);
   void* main_stream = c.stream;
   c.stream = c.side[k];
   c.slab_off = (size_t)k * c.slab_stride;
@@ -870,7 +876,7 @@ extern "C" void pwr_engine_destroy(void* h) {
     hipStreamSynchronize(e->ctx.side[k]);
     hipEventDestroy(e->ctx.ev_join[k]); hipStreamDestroy(e->ctx.side[k]);
   }
-  if (e->ctx.ev_fork) hipEventDestroy(e->ctx.ev_fork);
+  for (int k = 0; k < e->ctx.n_fork; ++k) hipEventDestroy(e->ctx.ev_fork[k]);
   e->destroy_graphs();
   delete e;
 }
@@ -964,7 +970,11 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
     int want = env ? atoi(env) : 2;
     if (want > Ctx::kMaxSide) want = Ctx::kMaxSide;
     c.use_side = want > 0;
-    if (c.use_side && hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess) c.use_side = false;
+    for (int k = 0; c.use_side && k < Ctx::kForkPool; ++k) {
+      if (hipEventCreateWithFlags(&c.ev_fork[k], hipEventDisableTiming) != hipSuccess) break;
+      c.n_fork = k + 1;
+    }
+    if (c.n_fork == 0) c.use_side = false;
     // side streams at the LOWEST priority: when a weight-gradient kernel and a kernel of the critical chain both have
     // workgroups to place, the chain goes first and the weight gradients fill what is left
     int prio_lo = 0, prio_hi = 0;

@@ -49,3 +49,113 @@ def make_batch(B, J, S=128, seed=1234, device="cpu", dense_targets=False):
         out["heatmaps"] = heat
         out["depthmaps"] = (uvd[:, :, 2, None, None] - label_img) * mask
     return {k: v.to(device) for k, v in out.items()}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A LEARNABLE synthetic task: rendered "hands" whose joint targets are a function of the image.
+# make_batch() above draws the targets independently of the image (fine for timing and parity, useless for accuracy:
+# nothing but the mean can be learnt).  make_pose_batch() renders a kinematic template -- a palm and five fingers as
+# capsules with a cylindrical depth profile -- under a random in-plane rotation, scale, shift, tilt and per-finger
+# curl, and returns what /root/reference/datasets.py:378-403 hands to the training loop:
+#   img, label_img, mask, box_size, cube_size, com, uvd (normalised as in datasets.py:378-381), so that the metric tail
+#   of train.py:254-285 (recover_uvd -> uvd2xyz -> mean joint error in mm) applies unchanged.
+# The few random pose parameters come from a CPU torch.Generator (same seed -> same batch on every machine); the
+# rendering is elementwise torch math on `device`.
+# ------------------------------------------------------------------------------------------------------------------
+def hand_template(J):
+    """Template joint positions in hand units (palm centre at the origin, fingers pointing 'up' = -y) and the index of each
+    joint's parent along its finger (-1: the palm centre)."""
+    import math
+    n_f = 5
+    per = max(1, -(-(J - 1) // n_f))          # joints per finger
+    ang = [-62.0, -26.0, 0.0, 24.0, 52.0]
+    reach = [0.62, 0.92, 1.0, 0.93, 0.78]
+    pos, parent = [(0.0, 0.0)], [-1]
+    # ordered ring by ring (all first knuckles, then all second joints, ...), truncated to J
+    for k in range(per):
+        for f in range(n_f):
+            if len(pos) >= J:
+                break
+            r = reach[f] * (0.42 + 0.58 * (k + 1) / per)
+            a = math.radians(ang[f])
+            pos.append((r * math.sin(a), -r * math.cos(a)))
+            parent.append(0 if k == 0 else 1 + (k - 1) * n_f + f)
+    return torch.tensor(pos, dtype=torch.float32), parent
+
+
+def make_pose_batch(B, J, S=128, seed=0, device="cpu", dataset="NYU", cube_size=150.0):
+    from .metric import INTRINSICS
+    g = torch.Generator().manual_seed(int(seed))
+    P = S // 2
+    fx, fy, hu, hv = INTRINSICS[dataset]
+    tmpl, parent = hand_template(J)
+    n_f = 5
+    finger_of = [-1] + [(j - 1) % n_f for j in range(1, J)]
+    ring_of = [0] + [(j - 1) // n_f + 1 for j in range(1, J)]
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    theta = (rnd(B) * 60 - 30) * (3.14159265 / 180)                  # in-plane rotation, like datasets.py:225
+    scale = 0.46 + 0.12 * rnd(B)                                     # hand length as a fraction of the crop
+    shift = (rnd(B, 2) - 0.5) * 0.12                                 # palm centre off the crop centre
+    tilt = (rnd(B, 2) - 0.5) * 0.8                                   # depth gradient across the hand
+    curl = 0.55 + 0.45 * rnd(B, n_f)                                 # per-finger length factor (1 = straight)
+    bend = (rnd(B, n_f) - 0.5) * (20 * 3.14159265 / 180)             # per-finger in-plane deviation
+    fo = torch.tensor([f if f >= 0 else 0 for f in finger_of])
+    is_f = torch.tensor([1.0 if f >= 0 else 0.0 for f in finger_of])
+    # joint positions in hand units: finger joints scaled by the finger's curl and rotated by its bend about the palm centre
+    pj = tmpl[None].repeat(B, 1, 1)
+    cf = torch.where(is_f[None] > 0, curl[:, fo], torch.ones(B, J))
+    bf = bend[:, fo] * is_f[None]
+    x = pj[..., 0] * cf
+    y = pj[..., 1] * cf
+    xr = x * torch.cos(bf) - y * torch.sin(bf)
+    yr = x * torch.sin(bf) + y * torch.cos(bf)
+    # curled fingers come towards the camera (smaller depth), more so at the tip
+    ring = torch.tensor(ring_of, dtype=torch.float32)
+    dz = -(1.0 - cf) * 0.9 * ring[None] / max(1.0, float(max(ring_of)))
+    ct, st = torch.cos(theta)[:, None], torch.sin(theta)[:, None]
+    xs = (xr * ct - yr * st) * scale[:, None] + shift[:, None, 0]     # crop units, centre = 0, range about +-0.5
+    ys = (xr * st + yr * ct) * scale[:, None] + shift[:, None, 1] + 0.17
+    d = tilt[:, None, 0] * xs + tilt[:, None, 1] * ys + dz * 0.5 + (rnd(B, 1) - 0.5) * 0.2
+    uvd = torch.stack([xs, ys, d], dim=2)                             # normalised like datasets.py:378-381
+    # ---- render on the device: capsules parent -> joint, cylindrical depth profile, nearest surface wins
+    uvd_d = uvd.to(device)
+    px = ((torch.arange(S, dtype=torch.float32, device=device) - S // 2) / (S - 1))
+    X = px[None, None, None, :]
+    Y = px[None, None, :, None]
+    a_idx = torch.tensor([p if p >= 0 else 0 for p in parent], device=device)
+    A = uvd_d[:, a_idx]                                               # [B,J,3] segment start (the palm's own segment is a point)
+    Bv = uvd_d
+    ax, ay, az = A[..., 0, None, None], A[..., 1, None, None], A[..., 2, None, None]
+    ex, ey, ez = (Bv[..., 0] - A[..., 0])[..., None, None], (Bv[..., 1] - A[..., 1])[..., None, None], (Bv[..., 2] - A[..., 2])[..., None, None]
+    den = (ex * ex + ey * ey).clamp_min(1e-12)
+    t = (((X - ax) * ex + (Y - ay) * ey) / den).clamp(0, 1)
+    dist2 = (X - ax - t * ex) ** 2 + (Y - ay - t * ey) ** 2           # [B,J,S,S]
+    rad = torch.full((J,), 0.055, device=device)
+    rad[0] = 0.19                                                     # the palm
+    rad = rad[None, :, None, None] * (scale.to(device) / 0.5)[:, None, None, None]
+    inside = dist2 < rad * rad
+    surf = az + t * ez - 0.6 * torch.sqrt((rad * rad - dist2).clamp_min(0))
+    surf = torch.where(inside, surf, torch.full_like(surf, 1e9))
+    depth = surf.min(dim=1).values                                    # [B,S,S]
+    hand = depth < 1e8
+    depth = depth.clamp(-0.95, 0.95)
+    depth = torch.where(depth == 0, torch.full_like(depth, 1e-3), depth)
+    img = (depth * hand.float())[:, None]
+    label_img = torch.nn.functional.avg_pool2d(img, 2)
+    mask = (label_img != 0).float()
+    com_z = 550.0 + 300.0 * rnd(B)
+    com = torch.stack([hu + (rnd(B) - 0.5) * 200, hv + (rnd(B) - 0.5) * 150, com_z], dim=1)
+    box = (cube_size / com_z * fx).int() + (cube_size / com_z * fy).int()        # datasets.py:243-246
+    return {"img": img, "label_img": label_img, "mask": mask, "uvd": uvd_d, "box_size": box.float(),
+            "cube_size": torch.full((B,), float(cube_size)), "com": com}
+
+
+def joint_error_mm(uvd_pred, batch, dataset="NYU"):
+    """Per-sample mean 3D joint error in mm of normalised predictions [B,J,3] against the batch's targets, exactly the
+    validation metric of train.py:254-285: recover_uvd -> uvd2xyz -> mean over joints of the Euclidean distance."""
+    from .metric import INTRINSICS, recover_uvd, uvd2xyz, mean_joint_error
+    intr = INTRINSICS[dataset]
+    box, cube, com = batch["box_size"].cpu(), batch["cube_size"].cpu(), batch["com"].cpu()
+    true_xyz = uvd2xyz(recover_uvd(batch["uvd"].detach().float().cpu().clone(), box, com, cube).numpy(), *intr)
+    pred_xyz = uvd2xyz(recover_uvd(uvd_pred.detach().float().cpu().clone(), box, com, cube).numpy(), *intr)
+    return mean_joint_error(pred_xyz, true_xyz)

@@ -163,3 +163,61 @@ def test_engine_plan_builds_without_a_gpu_and_names_its_arena():
     # a parameter table that does not match the architecture is refused
     bad = (ctypes.c_longlong * n)(*([nums[0] + 1] + nums[1:]))
     assert not l.pwr_engine_create(cfg, 2, 1, 1, (ctypes.c_longlong * n)(*offs), bad, n, None, 0)
+
+
+def test_reference_written_checkpoint_loads_strict(golden_dir):
+    """A .pt written by the reference's own utils.save_model (utils.py:302-307; generated by oracle/gen_golden.py from a
+    reference module) loads into the build's module with strict=True through load_model, key for key and bit for bit."""
+    from pixelwiseregression_amd import load_model
+    path = os.path.join(golden_dir, "reference_checkpoint.pt")
+    raw = torch.load(path, map_location="cpu")
+    m = PixelwiseRegression(4, **raw["model_param"])
+    seed, param = load_model(m, path, eval_mode=True)
+    assert seed == 4321 and param == raw["model_param"] and not m.training
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(raw["state_dict"].keys())
+    for k, v in raw["state_dict"].items():
+        assert torch.equal(sd[k].cpu(), v), k
+    assert int(sd["conv.1.num_batches_tracked"]) == 17
+
+
+def test_plan_cache_is_bounded():
+    """engine._get_plan keeps at most MAX_PLANS plans per module (a ragged last batch must not pin a second arena forever).
+    Exercised with a stub plan class: no GPU needed."""
+    from pixelwiseregression_amd import engine
+
+    class FakePlan:
+        def __init__(self, model, B, dtype, need_grad):
+            self.arena = torch.empty(B * 1000, dtype=torch.uint8)
+    real, real_budget = engine._Plan, engine._plan_budget_bytes
+    engine._Plan, engine._plan_budget_bytes = FakePlan, (lambda dev: 10 ** 12)
+    try:
+        m = PixelwiseRegression(4, stage=1, label_size=16, features=32, level=1, norm_method="instance")
+        sync = torch.cuda.current_stream
+        torch.cuda.current_stream = lambda dev=None: type("S", (), {"synchronize": staticmethod(lambda: None)})()
+        try:
+            for B in (1, 2, 3, 4, 5, 6):
+                engine._get_plan(m, B, 0, False)
+            assert len(m._engine) == engine.MAX_PLANS and (1, 0, False) not in m._engine and (6, 0, False) in m._engine
+            engine._get_plan(m, 3, 0, False)                       # touching a plan makes it the most recent
+            engine._get_plan(m, 7, 0, False)
+            assert (3, 0, False) in m._engine and (4, 0, False) not in m._engine
+            engine._plan_budget_bytes = lambda dev: 9000            # byte budget: only what fits stays
+            engine._get_plan(m, 8, 0, False)
+            assert list(m._engine) == [(8, 0, False)]
+        finally:
+            torch.cuda.current_stream = sync
+    finally:
+        engine._Plan, engine._plan_budget_bytes = real, real_budget
+
+
+def test_check_flat_detects_a_detached_middle_parameter():
+    m = PixelwiseRegression(4, stage=1, label_size=16, features=32, level=1, norm_method="instance")
+    flat0 = m.flat_parameters()
+    mid = m._param_list[len(m._param_list) // 2]
+    mid.data = mid.data.clone() * 0 + 3.0           # a manual .data assignment on a middle parameter
+    m._check_flat()
+    assert m.flat_parameters() is not flat0, "re-flattened"
+    o = m._byte_offsets[len(m._param_list) // 2] // 4
+    assert float(m.flat_parameters()[o]) == 3.0     # ... and the new values are in the flat buffer
+    assert all(p.data_ptr() == m.flat_parameters().data_ptr() + b for p, b in zip(m._param_list, m._byte_offsets))
