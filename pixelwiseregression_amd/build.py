@@ -15,8 +15,15 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libpwr_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar f32 adds / muls into v_pk_add_f32 / v_pk_mul_f32 with op_sel
+# operand selection (e.g. "v_pk_add_f32 v[24:25], v[126:127], v[128:129] op_sel:[0,1]": low result = src0.lo + src1.HI).  In
+# decode_bwd_cached exactly that form produced, about once per 7000 train steps on some MI355X boxes and only while MFMA
+# weight-gradient kernels of another stream shared the CU, a low-half result in which the src1.hi addend was missing for lanes
+# 48-63 (six captures).  Without the vectoriser no cross-half op_sel form is emitted anywhere in the library
+# (tests/test_boundary_cpu.py checks the shipped code objects), the events are gone on the boxes that showed them, and the train
+# step takes the same time (packed f32 math beside MFMAs is an anti-lever on this chip anyway, MI355X_MICROARCH.md).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-         "-Wno-unused-result", "-ffp-contract=off"]
+         "-Wno-unused-result", "-ffp-contract=off", "-fno-slp-vectorize"]
 
 
 def _sources():

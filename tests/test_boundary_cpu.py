@@ -221,3 +221,19 @@ def test_check_flat_detects_a_detached_middle_parameter():
     o = m._byte_offsets[len(m._param_list) // 2] // 4
     assert float(m.flat_parameters()[o]) == 3.0     # ... and the new values are in the flat buffer
     assert all(p.data_ptr() == m.flat_parameters().data_ptr() + b for p, b in zip(m._param_list, m._byte_offsets))
+
+
+def test_no_cross_half_packed_f32_in_shipped_code_objects():
+    """Static regression test of the round-2 reproducibility fix: the gfx950 code objects inside
+    libpwr_hip.so contain no packed f32 instruction whose low result reads a source's high register (op_sel:[..1..]) -- the
+    compiler-generated (SLP) form caught producing a wrong addend in lanes 48-63 beside MFMA kernels of another stream."""
+    import importlib.util
+    from pixelwiseregression_amd import _lib, build
+    assert "-fno-slp-vectorize" in build.FLAGS
+    spec = importlib.util.spec_from_file_location("codeobj_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                "tools", "codeobj_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.scan(_lib.LIB_PATH)
+    assert r["functions"] > 100 and r["instructions"] > 100000, r       # the scan really saw the library's kernels
+    assert r["packed_f32_cross_half_op_sel"] == 0, r

@@ -1,0 +1,64 @@
+"""Disassemble the gfx950 code objects embedded in libpwr_hip.so and report instruction forms.
+
+    python tools/codeobj_scan.py [lib.so]         # prints counts of packed-f32 forms per kernel family
+
+Used by tests/test_boundary_cpu.py as the static regression test of the round-2 reproducibility fix: the shipped library must
+contain no packed f32 instruction whose LOW result selects a source's HIGH register (op_sel:[..1..]) -- the instruction form that
+was caught producing a wrong addend in lanes 48-63.
+"""
+import os, re, struct, subprocess, sys, tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(lib):
+    """Yields (triple, bytes) of every device code object in the library's .hip_fatbin section."""
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+        data = open(fat, "rb").read()
+    pos = data.find(MAGIC)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", data, pos + len(MAGIC))[0]
+        q = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            triple = data[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if size:
+                yield triple, data[pos + off:pos + off + size]
+        pos = data.find(MAGIC, pos + len(MAGIC))
+
+
+def disassemble(lib):
+    """Concatenated llvm-objdump -d text of all gfx950 code objects."""
+    out = []
+    for triple, blob in code_objects(lib):
+        if "gfx950" not in triple:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob); f.flush()
+            out.append(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True,
+                                      check=True).stdout)
+    return "\n".join(out)
+
+
+PK = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+# op_sel:[a,b(,c)] selects, for the LOW result, which register of each source pair is read; any 1 = a high register feeds the low result
+CROSS = re.compile(r"op_sel:\[[01,]*1[01,]*\]")
+
+
+def scan(lib):
+    txt = disassemble(lib)
+    n_kernels = len(re.findall(r"^[0-9a-f]+ <[^>]+>:", txt, flags=re.M))
+    pk = [l for l in txt.splitlines() if PK.search(l)]
+    cross = [l for l in pk if CROSS.search(l)]
+    return {"functions": n_kernels, "instructions": txt.count("\n"), "packed_f32": len(pk), "packed_f32_cross_half_op_sel": len(cross),
+            "examples": [c.split("//")[0].strip() for c in cross[:5]]}
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "pixelwiseregression_amd", "libpwr_hip.so")
+    print(lib, scan(lib))
