@@ -278,6 +278,23 @@ int pwr_adamw_step(float* p, const float* g, float* m, float* v, long long n, fl
 int pwr_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay, int first,
                  float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline on the device: /root/reference/datasets.py:243-299 for a batch of raw depth frames
+ * already in HBM.  OpenCV calls restated from the published algorithms (oracle/preprocess_ref.py is the CPU twin).
+ * ------------------------------------------------------------------------------------------- */
+/* datasets.py:243-252 + cv2.resize (:296): depth [B,H,W] fp32 raw frames; geo [B,3] int = {first row, first column, side} of the
+ * crop window (utils.center_crop, utils.py:167-173; the window may leave the frame: zeros); com_z, cube [B] double; out [B,S,S]
+ * fp32 = resized crop in millimetres relative to the COM (0 = background / outside the cube). */
+int pwr_crop_resize(const float* depth, const int* geo, const double* com_z, const double* cube, float* out, int B, int H, int W, int S,
+                    void* stream);
+/* utils.random_rotated (utils.py:66-82) image part + the `img_resize * scale` of datasets.py:282: dst = cv2.warpAffine(src, M) * scale;
+ * minv [B,6] double = the INVERTED 2x3 matrices (dst -> src), scale [B] float; src, dst [B,S,S], not aliased. */
+int pwr_warp_affine(const float* src, const double* minv, const float* scale, float* dst, int B, int S, void* stream);
+/* datasets.py:297-299, 378-380: label = cv2.resize(img, (P,P)); mask = label != 0; img_n = img / cube; label_n = label / cube.
+ * img [B,S,S]; cube [B] float; img_n [B,S,S]; label_n, mask [B,P,P]. */
+int pwr_label_mask_normalize(const float* img, const float* cube, float* img_n, float* label_n, float* mask, int B, int S, int P,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

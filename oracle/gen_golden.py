@@ -304,6 +304,78 @@ def gen_wellcond(ref_model):
     np.savez_compressed(os.path.join(OUT, "wellcond.npz"), **rec)
 
 
+def gen_preprocess(ref_utils, ref_datasets):
+    """The reference's HandDataset.process_single_data (datasets.py:182-403) run on synthetic raw depth frames, with `cv2`
+    stubbed by the oracle's restatements of cv2.resize / getRotationMatrix2D / warpAffine / GaussianBlur (cv2 is not installed
+    here).  What this pins: everything the reference does AROUND those calls -- crop window, depth threshold, COM centring,
+    the shift / scale / rotation augmentation of image and joints, label image, mask, dense targets, normalisation, and the
+    un-augmented fallback.  The random draws of the reference (python `random`) are recorded so that the same augmentation can
+    be handed to the device pipeline."""
+    import random
+    from oracle import preprocess_ref as PR, targets_ref as TR
+    cv2 = sys.modules["cv2"]
+    cv2.resize = lambda img, dsize: PR.resize_linear(img, dsize)
+    cv2.getRotationMatrix2D = PR.rotation_matrix
+    cv2.warpAffine = lambda img, M, dsize: PR.warp_affine(img, M, dsize)
+    cv2.GaussianBlur = lambda img, ks, sig: TR.gaussian_blur(np.asarray(img, dtype=np.float64), ks[0], sig)
+    fx, fy, hu, hv = 588.037, 587.075, 320.0, 240.0          # NYU, datasets.py:693
+    H, W, J, S, P = 480, 640, 14, 128, 64
+
+    class Synth(ref_datasets.HandDataset):
+        def __init__(self, augment):
+            for k, v in dict(fx=fx, fy=fy, halfu=hu, halfv=hv, path="", sigmoid=1.5, image_size=S, kernel_size=7, label_size=P, test_only=False,
+                             using_rotation=augment, using_scale=augment, using_shift=augment, using_flip=False, cube_size=150,
+                             joint_number=J, config=None, process_mode="uvd", dataset="train", augmentation=augment).items():
+                setattr(self, k, v)
+
+        def load_from_text(self, text):
+            return text          # the "text" IS the (image, joint_uvd, com, cube) tuple here
+
+    rng = np.random.default_rng(77)
+    rec = {"intrinsics": np.array([fx, fy, hu, hv]), "S": np.int64(S), "P": np.int64(P)}
+    n = 6
+    frames = []
+    for i in range(n):
+        # a synthetic depth frame: background 0, a hand-sized blob of smooth depth around the COM, clutter behind it
+        cz = 550.0 + 300.0 * rng.random()
+        cu, cv_ = 200 + 240 * rng.random(), 150 + 180 * rng.random()
+        yy, xx = np.mgrid[0:H, 0:W]
+        rad = 150.0 / cz * fx * (0.45 + 0.2 * rng.random())
+        blob = ((xx - cu) ** 2 + (yy - cv_) ** 2) < rad ** 2
+        depth = np.where(blob, cz + 60 * np.sin(xx / 17.0 + i) * np.cos(yy / 23.0) + 0.1 * (xx - cu), 0.0)
+        depth = np.where((xx > cu + 0.5 * rad) & (yy > cv_) & (~blob) & (xx < cu + 1.4 * rad), cz + 400.0, depth)     # far clutter: cut by the cube
+        depth = depth.astype(np.float32)
+        ang = rng.random(J) * 2 * np.pi
+        rr = rad * 0.5 * np.sqrt(rng.random(J))
+        juvd = np.stack([cu + rr * np.cos(ang), cv_ + rr * np.sin(ang), cz + 50 * (rng.random(J) - 0.5)], axis=1)
+        com = np.array([cu + 3 * (rng.random() - 0.5), cv_ + 3 * (rng.random() - 0.5), cz])
+        frames.append((depth, juvd, com, 150))
+    for aug in (False, True):
+        ds = Synth(aug)
+        for i, fr in enumerate(frames):
+            random.seed(1000 + i)
+            draws = []
+            real = random.random
+            random.random = lambda: (draws.append(real()) or draws[-1])
+            try:
+                out = ds.process_single_data((fr[0].copy(), fr[1].copy(), fr[2].copy(), fr[3]))
+            finally:
+                random.random = real
+            names = ("img", "label_img", "mask", "box_size", "cube_size", "com", "uvd", "heatmaps", "depthmaps")
+            pre = "%s%d_" % ("aug" if aug else "plain", i)
+            for nm, t in zip(names, out):
+                rec[pre + nm] = t.numpy()
+            rec[pre + "draws"] = np.array(draws)
+        print("preprocess", "augmented" if aug else "plain", "done")
+    for i, fr in enumerate(frames):
+        rec["raw%d_depth" % i] = fr[0].astype(np.float16)       # (values are exactly representable? no: store as float32 below)
+        rec["raw%d_depth" % i] = fr[0]
+        rec["raw%d_joints" % i] = fr[1]
+        rec["raw%d_com" % i] = fr[2]
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **rec)
+    print("preprocess fixture:", os.path.getsize(os.path.join(OUT, "preprocess.npz")), "bytes")
+
+
 def gen_checkpoint(ref_model, ref_utils):
     """A checkpoint file written by the REFERENCE's own utils.save_model (utils.py:302-307) from a reference module, plus that
     module's outputs on a fixed batch: the build must load the file with strict=True and reproduce the outputs."""
@@ -332,10 +404,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:     # (add named fixtures without regenerating the others): targets | wellcond | checkpoint
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(8)
-        ref_model, ref_utils, _ = import_reference()
+        ref_model, ref_utils, ref_datasets = import_reference()
         for what in sys.argv[1:]:
             {"targets": lambda: gen_targets(ref_utils), "wellcond": lambda: gen_wellcond(ref_model),
-             "checkpoint": lambda: gen_checkpoint(ref_model, ref_utils)}[what]()
+             "checkpoint": lambda: gen_checkpoint(ref_model, ref_utils),
+             "preprocess": lambda: gen_preprocess(ref_utils, ref_datasets)}[what]()
         sys.exit(0)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -348,3 +421,4 @@ if __name__ == "__main__":
     gen_targets(ref_utils)
     gen_wellcond(ref_model)
     gen_checkpoint(ref_model, ref_utils)
+    gen_preprocess(ref_utils, ref_datasets)

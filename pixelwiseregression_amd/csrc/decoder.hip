@@ -30,11 +30,15 @@ __device__ __forceinline__ float grid_coord(int idx, int P) {
 // Register-resident path: N == NT*NV*4, P % 4 == 0 and (NT*4) % P == 0, so a thread's four
 // columns are the same for all of its NV vectors.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int NV>
-__global__ __launch_bounds__(NT) void decode_fwd_cached(const float* __restrict__ z, const float* __restrict__ D,
+template <int NT, int NV, int MINW = 1>
+__global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __restrict__ z, const float* __restrict__ D,
                                                         const float* __restrict__ L, const float* __restrict__ m,
                                                         const float* __restrict__ w, float* __restrict__ p_out,
                                                         float* __restrict__ uvd, int J, int P, int method) {
+  // ONE dependent memory phase: every thread exponentiates against its OWN maximum (all its logits are in registers), so the
+  // loads of D, L and m are not held back behind a workgroup-wide max reduction; the two block reductions (max of the thread
+  // maxima, then the sums rescaled by exp(m_thread - M)) sit back to back at the end with no memory access between them.
+  //   p = exp(e - m_t) * exp(m_t - M) / S      (one extra rounding vs exp(e - M) / S: ~1e-7 relative)
   constexpr int NW = NT / 64;
   __shared__ float red[8 * NW];
   const int map = blockIdx.x, b = map / J, j = map - b * J;
@@ -46,17 +50,17 @@ __global__ __launch_bounds__(NT) void decode_fwd_cached(const float* __restrict_
   const int row0 = (tid * 4) / P;
 
   f32x4 e[NV];
-  float mx = -INFINITY;
+  float mt = -INFINITY;
   const float wj = (method == 0) ? w[j] : 1.f;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    e[k] = *reinterpret_cast<const f32x4*>(z + mo + (size_t)(k * NT + tid) * 4);
-    if (method == 0) {
+  for (int k = 0; k < NV; ++k) e[k] = *reinterpret_cast<const f32x4*>(z + mo + (size_t)(k * NT + tid) * 4);
+  if (method == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
       e[k] *= wj;
-      mx = fmaxf(mx, fmaxf(fmaxf(e[k].x, e[k].y), fmaxf(e[k].z, e[k].w)));
+      mt = fmaxf(mt, fmaxf(fmaxf(e[k].x, e[k].y), fmaxf(e[k].z, e[k].w)));
     }
   }
-  if (method == 0) mx = block_max<NW>(mx, red);
 
   float cs[4] = {0.f, 0.f, 0.f, 0.f};  // per-column sums of e
   float sv = 0.f, sm = 0.f, sd = 0.f;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(NT) void decode_fwd_cached(const float* __restrict_
     f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
     f32x4 ev;
     if (method == 0) {
-      ev.x = expf(e[k].x - mx); ev.y = expf(e[k].y - mx); ev.z = expf(e[k].z - mx); ev.w = expf(e[k].w - mx);
+      ev.x = expf(e[k].x - mt); ev.y = expf(e[k].y - mt); ev.z = expf(e[k].z - mt); ev.w = expf(e[k].w - mt);
     } else {
       ev.x = fmaxf(e[k].x, 0.f) + PWR_DEC_EPS; ev.y = fmaxf(e[k].y, 0.f) + PWR_DEC_EPS;
       ev.z = fmaxf(e[k].z, 0.f) + PWR_DEC_EPS; ev.w = fmaxf(e[k].w, 0.f) + PWR_DEC_EPS;
@@ -81,19 +85,29 @@ __global__ __launch_bounds__(NT) void decode_fwd_cached(const float* __restrict_
     f32x4 mr = mv * (dv + lv);       // m*(D+L)
     sm += (em.x + em.y) + (em.z + em.w);
     sd += (em.x * mr.x + em.y * mr.y) + (em.z * mr.z + em.w * mr.w);
+    // 128x128 maps (NV = 8): keep at most two iterations' loads in flight per thread, otherwise the scheduler hoists all 24 and
+    // the kernel needs 144 VGPRs = one workgroup per CU; with <= 128 two workgroups overlap their phases
+    if (MINW > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);
   }
   float r[5];
   r[0] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
   r[1] = (cs[0] * grid_coord(col0, P) + cs[1] * grid_coord(col0 + 1, P)) +
          (cs[2] * grid_coord(col0 + 2, P) + cs[3] * grid_coord(col0 + 3, P));
   r[2] = sv; r[3] = sm; r[4] = sd;
+  float f = 1.f;
+  if (method == 0) {
+    const float M = block_max<NW>(mt, red);
+    f = expf(mt - M);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r[i] *= f;
+  }
   block_sum<5, NW>(r, red);
   const float inv = __fdiv_rn(1.f, r[0]);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     f32x4 pv;
-    pv.x = __fdiv_rn(e[k].x, r[0]); pv.y = __fdiv_rn(e[k].y, r[0]);
-    pv.z = __fdiv_rn(e[k].z, r[0]); pv.w = __fdiv_rn(e[k].w, r[0]);
+    pv.x = __fdiv_rn(e[k].x * f, r[0]); pv.y = __fdiv_rn(e[k].y * f, r[0]);
+    pv.z = __fdiv_rn(e[k].z * f, r[0]); pv.w = __fdiv_rn(e[k].w * f, r[0]);
     *reinterpret_cast<f32x4*>(p_out + mo + (size_t)(k * NT + tid) * 4) = pv;
   }
   if (tid == 0) {
@@ -165,8 +179,15 @@ __device__ __forceinline__ float uniform_load(const float* p) {
   else return *p;
 }
 
-template <int NT, int NV, bool SC1 = false>
-__global__ __launch_bounds__(NT) void decode_bwd_cached(const float* __restrict__ p, const float* __restrict__ z,
+// Single pass: with A = gH + gu*gx + gv*gy and Bm = m*(m*(D+L) - d) the incoming gradient is g_p = A + (gd/S)*Bm, so every sum
+// the backward needs splits into sums that do NOT depend on S:
+//   S = sum p*m, T1 = sum p*A, T2 = sum p*Bm, T3 = sum p*A*z, T4 = sum p*Bm*z, T5 = sum p*z   ->   ONE block reduction
+//   A1 = T1 + gdS*T2,  g_w = (T3 + gdS*T4) - A1*T5,  g_z = w*p*(A + gdS*Bm - A1),  g_D = gD + gdS*p*m^2
+// and all operands of a map are loaded in one dependent phase (the two-reduction form read m, D, L, z behind the first barrier).
+// RELOAD (softmax only; used for the 128x128 maps where NV = 8): only p and Bm stay in registers, gH and m are fetched again
+// (L2) in the tail -- 100 instead of 256 VGPRs, so that two 512-thread workgroups share a CU and overlap their phases.
+template <int NT, int NV, bool RELOAD = false, bool SC1 = false>
+__global__ __launch_bounds__(NT, RELOAD ? (2 * NT) / 256 : 1) void decode_bwd_cached(const float* __restrict__ p, const float* __restrict__ z,
                                                         const float* __restrict__ D, const float* __restrict__ L,
                                                         const float* __restrict__ m, const float* __restrict__ w,
                                                         const float* __restrict__ uvd, const float* __restrict__ gH,
@@ -174,6 +195,7 @@ __global__ __launch_bounds__(NT) void decode_bwd_cached(const float* __restrict_
                                                         float* __restrict__ gz, float* __restrict__ gDout,
                                                         float* __restrict__ gw_part, int J, int P, int method) {
   constexpr int NW = NT / 64;
+  constexpr int NK = RELOAD ? 1 : NV;      // vectors of A / p*m^2 kept in registers
   __shared__ float red[8 * NW];
   const int map = blockIdx.x, b = map / J, j = map - b * J;
   const int N = P * P;
@@ -186,75 +208,77 @@ __global__ __launch_bounds__(NT) void decode_bwd_cached(const float* __restrict_
               gd = uniform_load<SC1>(gU + (size_t)map * 3 + 2);
   const float d = uniform_load<SC1>(uvd + (size_t)map * 3 + 2);
   const float wj = (method == 0) ? uniform_load<SC1>(w + j) : 1.f;
-
-  f32x4 pv[NV], gp[NV], pm2[NV];
-  float r1[2] = {0.f, 0.f};  // S (without eps), T (sum method)
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const size_t off = (size_t)(k * NT + tid) * 4;
-    pv[k] = *reinterpret_cast<const f32x4*>(p + mo + off);
-    f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
-    f32x4 pmv = pv[k] * mv;
-    pm2[k] = pmv * mv;
-    r1[0] += (pmv.x + pmv.y) + (pmv.z + pmv.w);
-  }
-  if (method != 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      f32x4 zv = *reinterpret_cast<const f32x4*>(z + mo + (size_t)(k * NT + tid) * 4);
-      r1[1] += (fmaxf(zv.x, 0.f) + PWR_DEC_EPS) + (fmaxf(zv.y, 0.f) + PWR_DEC_EPS) +
-               (fmaxf(zv.z, 0.f) + PWR_DEC_EPS) + (fmaxf(zv.w, 0.f) + PWR_DEC_EPS);
-    }
-  }
-  block_sum<2, NW>(r1, red);
-  const float S = r1[0] + PWR_DEC_EPS;
-  const float gdS = __fdiv_rn(gd, S);
   const float gxc[4] = {gu * grid_coord(col0, P), gu * grid_coord(col0 + 1, P), gu * grid_coord(col0 + 2, P),
                         gu * grid_coord(col0 + 3, P)};
-  float r2[3] = {0.f, 0.f, 0.f};
+
+  f32x4 pv[NV], Bv[NV], Av[NK], pm2[NK];
+  float r[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // S (without eps), T1..T5, T (sum method)
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const size_t off = (size_t)(k * NT + tid) * 4;
-    f32x4 dv = *reinterpret_cast<const f32x4*>(D + mo + off);
-    f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
-    f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
-    f32x4 zv = *reinterpret_cast<const f32x4*>(z + mo + off);
-    f32x4 g;
+    const f32x4 pk = *reinterpret_cast<const f32x4*>(p + mo + off);
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(D + mo + off);
+    const f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + mo + off);
     const float gyv = gv * grid_coord(row0 + k * rows_per_step, P);
-    g.x = gxc[0] + gyv + gdS * mv.x * (mv.x * (dv.x + lv.x) - d);
-    g.y = gxc[1] + gyv + gdS * mv.y * (mv.y * (dv.y + lv.y) - d);
-    g.z = gxc[2] + gyv + gdS * mv.z * (mv.z * (dv.z + lv.z) - d);
-    g.w = gxc[3] + gyv + gdS * mv.w * (mv.w * (dv.w + lv.w) - d);
-    if (gH) g += *reinterpret_cast<const f32x4*>(gH + mo + off);
-    gp[k] = g;
-    f32x4 pg = pv[k] * g;
-    r2[0] += (pg.x + pg.y) + (pg.z + pg.w);
-    r2[1] += (pg.x * zv.x + pg.y * zv.y) + (pg.z * zv.z + pg.w * zv.w);
-    r2[2] += (pv[k].x * zv.x + pv[k].y * zv.y) + (pv[k].z * zv.z + pv[k].w * zv.w);
-    if (method != 0) {  // keep the relu mask in pm-free form: store sign in gp via separate pass below
-      // sum-normalisation: g_z = (g_p - A1)/T * [z>0]; remember [z>0] by zeroing p where z<=0 later
-      f32x4 msk;
-      msk.x = zv.x > 0.f ? 1.f : 0.f; msk.y = zv.y > 0.f ? 1.f : 0.f;
-      msk.z = zv.z > 0.f ? 1.f : 0.f; msk.w = zv.w > 0.f ? 1.f : 0.f;
-      // A1 must use the true p, so the mask is folded into pv only after the products above
-      pv[k] = msk;  // pv now carries the relu mask (p itself no longer needed except via pm2)
+    f32x4 A;
+    A.x = gxc[0] + gyv; A.y = gxc[1] + gyv; A.z = gxc[2] + gyv; A.w = gxc[3] + gyv;
+    if (gH) A += *reinterpret_cast<const f32x4*>(gH + mo + off);
+    f32x4 Bm;
+    Bm.x = mv.x * (mv.x * (dv.x + lv.x) - d); Bm.y = mv.y * (mv.y * (dv.y + lv.y) - d);
+    Bm.z = mv.z * (mv.z * (dv.z + lv.z) - d); Bm.w = mv.w * (mv.w * (dv.w + lv.w) - d);
+    const f32x4 pmv = pk * mv, pA = pk * A, pB = pk * Bm;
+    r[0] += (pmv.x + pmv.y) + (pmv.z + pmv.w);
+    r[1] += (pA.x + pA.y) + (pA.z + pA.w);
+    r[2] += (pB.x + pB.y) + (pB.z + pB.w);
+    r[3] += (pA.x * zv.x + pA.y * zv.y) + (pA.z * zv.z + pA.w * zv.w);
+    r[4] += (pB.x * zv.x + pB.y * zv.y) + (pB.z * zv.z + pB.w * zv.w);
+    r[5] += (pk.x * zv.x + pk.y * zv.y) + (pk.z * zv.z + pk.w * zv.w);
+    pv[k] = pk; Bv[k] = Bm;
+    if (RELOAD) __builtin_amdgcn_sched_barrier(0);     // one iteration's six loads in flight (see the forward kernel)
+    if constexpr (!RELOAD) {
+      Av[k] = A; pm2[k] = pmv * mv;
+      if (method != 0) {
+        // sum-normalisation: g_z = (g_p - A1)/T * [z>0]; p itself is not needed in the tail (p*m^2 is kept), so pv carries the mask
+        r[6] += (fmaxf(zv.x, 0.f) + PWR_DEC_EPS) + (fmaxf(zv.y, 0.f) + PWR_DEC_EPS) + (fmaxf(zv.z, 0.f) + PWR_DEC_EPS) +
+                (fmaxf(zv.w, 0.f) + PWR_DEC_EPS);
+        f32x4 msk;
+        msk.x = zv.x > 0.f ? 1.f : 0.f; msk.y = zv.y > 0.f ? 1.f : 0.f;
+        msk.z = zv.z > 0.f ? 1.f : 0.f; msk.w = zv.w > 0.f ? 1.f : 0.f;
+        pv[k] = msk;
+      }
     }
   }
-  block_sum<3, NW>(r2, red);
-  const float A1 = r2[0];
-  const float invT = (method != 0) ? __fdiv_rn(1.f, r1[1]) : 0.f;
+  block_sum<7, NW>(r, red);
+  const float S = r[0] + PWR_DEC_EPS;
+  const float gdS = __fdiv_rn(gd, S);
+  const float A1 = r[1] + gdS * r[2];
+  const float invT = (method != 0) ? __fdiv_rn(1.f, r[6]) : 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const size_t off = (size_t)(k * NT + tid) * 4;
+    f32x4 A, q2;
+    if constexpr (RELOAD) {
+      const float gyv = gv * grid_coord(row0 + k * rows_per_step, P);
+      A.x = gxc[0] + gyv; A.y = gxc[1] + gyv; A.z = gxc[2] + gyv; A.w = gxc[3] + gyv;
+      if (gH) A += *reinterpret_cast<const f32x4*>(gH + mo + off);
+      const f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
+      q2 = (pv[k] * mv) * mv;
+    } else {
+      A = Av[k]; q2 = pm2[k];
+    }
+    const f32x4 g = A + gdS * Bv[k];
+    if (RELOAD && (k & 1)) __builtin_amdgcn_sched_barrier(0);
     f32x4 gzv;
-    if (method == 0) gzv = wj * (pv[k] * (gp[k] - A1));
-    else gzv = pv[k] * ((gp[k] - A1) * invT);
+    if (method == 0) gzv = wj * (pv[k] * (g - A1));
+    else gzv = pv[k] * ((g - A1) * invT);
     *reinterpret_cast<f32x4*>(gz + mo + off) = gzv;
-    f32x4 gdv = gdS * pm2[k];
+    f32x4 gdv = gdS * q2;
     if (gDin) gdv += *reinterpret_cast<const f32x4*>(gDin + mo + off);
     *reinterpret_cast<f32x4*>(gDout + mo + off) = gdv;
   }
-  if (tid == 0 && gw_part) gw_part[map] = (method == 0) ? (r2[1] - A1 * r2[2]) : 0.f;
+  if (tid == 0 && gw_part) gw_part[map] = (method == 0) ? ((r[3] + gdS * r[4]) - A1 * r[5]) : 0.f;
 }
 
 template <int NT>
@@ -330,8 +354,17 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
     hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
   else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
-  else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
+    // 128x128 maps.  A/B switch (tools/bench_decoder.py): 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU;
+    // 1 = 1024 threads x 4 vectors; 2 = 512 x 8 held to 128 VGPRs (two workgroups per CU, a few spilled registers)
+    static const int v = [] { const char* e = getenv("PWR_DEC_FWD128"); return e ? atoi(e) : 1; }();
+    if (v == 1 && 4096 % P == 0)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+    else if (v == 2)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4>), dim3(maps), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+    else
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  }
   else
     hipLaunchKernelGGL((pwr::decode_fwd_generic<256>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
   return (int)hipGetLastError();
@@ -346,13 +379,22 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
   const int N = P * P, maps = B * J;
   static const int sc1 = [] { const char* e = getenv("PWR_DEC_SCALAR_SC1"); return e ? atoi(e) : 0; }();   // experiment switch (tools/race_hunt.py)
   if (sc1 && P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, true>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, false, true>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
   else if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
   else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
-  else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
+    // 128x128 maps.  A/B switch: 0 = 512 x 8 with everything in registers (204 VGPRs, one workgroup per CU); 1 = 1024 x 4 (108 VGPRs,
+    // one 16-wave workgroup per CU); 2 = 512 x 8 RELOAD (softmax only; 128 VGPRs with spills, two workgroups per CU)
+    static const int v = [] { const char* e = getenv("PWR_DEC_BWD128"); return e ? atoi(e) : 1; }();
+    if (v == 1 && 4096 % P == 0)
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+    else if (v == 2 && method == 0)
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8, true>), dim3(maps), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+    else
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+  }
   else
     hipLaunchKernelGGL((pwr::decode_bwd_generic<256>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
   return (int)hipGetLastError();

@@ -57,3 +57,47 @@ def test_ddp_two_ranks_one_gpu(tmp_path):
         _, rank, err, same = l.split()
         assert float(err) < 1e-5, l
         assert same == "True", l
+
+
+WORKER_RCCL = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pixelwiseregression_amd import PixelwiseRegression
+from pixelwiseregression_amd.ddp import DataParallel
+from pixelwiseregression_amd.synthetic import make_pose_batch
+from pixelwiseregression_amd.train import TrainStep
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # "nccl" IS RCCL on ROCm
+def run(ddp):
+    torch.manual_seed(11)
+    m = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, norm_method="instance").to(dev).set_precision("bf16").train()
+    if ddp:
+        DataParallel(m)
+    ts = TrainStep(m, opt="adam", lr=1e-3)
+    losses = []
+    for it in range(4):
+        b = make_pose_batch(8, 14, 128, seed=100 + it, device=dev)
+        losses.append(ts(b["img"], b["label_img"], b["mask"], b["uvd"]))
+    torch.cuda.synchronize()
+    return m.flat_parameters().clone(), m.flat_grad().clone(), torch.stack(losses).flatten().clone()
+p1, g1, l1 = run(False)
+p2, g2, l2 = run(True)
+print("RESULT", torch.equal(p1, p2), torch.equal(g1, g2), torch.equal(l1, l2), float((p1 - p2).abs().max()), flush=True)
+dist.destroy_process_group()
+""" % ROOT
+
+
+def test_rccl_path_single_rank_is_bit_identical_to_single_gpu(tmp_path):
+    """The data-parallel path over the real RCCL backend (process group "nccl", per-segment async all-reduce on the flat
+    gradient slices, 1/world folded into the optimizer kernel) with ONE rank -- all a 1-GPU box can run -- must leave the
+    parameters, the gradients and the losses of four AdamW steps at BASELINE C2's architecture bit-identical to the plain
+    single-GPU path: the all-reduce of one rank is the identity and the segment joins are the same."""
+    script = tmp_path / "worker_rccl.py"
+    script.write_text(WORKER_RCCL)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    _, same_p, same_g, same_l, maxdiff = lines[0].split()
+    assert same_p == "True" and same_g == "True" and same_l == "True", lines[0]

@@ -1,0 +1,76 @@
+"""GPU: the device input pipeline (pixelwiseregression_amd.preprocess_batch -> pwr_crop_resize / pwr_warp_affine /
+pwr_label_mask_normalize / pwr_make_targets) against the outputs of the reference's own HandDataset.process_single_data on the
+same raw frames and the same random draws (tests/golden/preprocess.npz; see oracle/gen_golden.py::gen_preprocess for how the
+cv2 calls are handled), for the un-augmented and the augmented path, and the per-sample fallback."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+INTR = (588.037, 587.075, 320.0, 240.0)
+
+
+def _load(golden_dir):
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    depth = torch.from_numpy(np.stack([g["raw%d_depth" % i] for i in range(6)])).to(DEV)
+    joints = np.stack([g["raw%d_joints" % i] for i in range(6)])
+    com = np.stack([g["raw%d_com" % i] for i in range(6)])
+    return g, depth, joints, com
+
+
+@pytest.mark.parametrize("kind", ["plain", "aug"])
+def test_device_pipeline_matches_reference(golden_dir, kind):
+    from pixelwiseregression_amd import preprocess_batch, draw_augmentation
+    g, depth, joints, com = _load(golden_dir)
+    aug = None
+    if kind == "aug":
+        parts = []
+        for i in range(6):
+            random.seed(1000 + i)
+            parts.append(draw_augmentation(1, rng=random))
+        aug = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    out = preprocess_batch(depth, joints, com, 150, INTR, 128, 64, augmentation=aug)
+    assert not out["fallback"].any()
+    ref = lambda nm: np.stack([g["%s%d_%s" % (kind, i, nm)] for i in range(6)])
+    assert np.array_equal(out["box_size"].numpy(), ref("box_size"))
+    np.testing.assert_allclose(out["com"].numpy(), ref("com"), atol=1e-4)
+    np.testing.assert_allclose(out["uvd"].cpu().numpy(), ref("uvd"), atol=1e-7)
+    np.testing.assert_allclose(out["img"].cpu().numpy(), ref("img"), atol=5e-7)
+    np.testing.assert_allclose(out["label_img"].cpu().numpy(), ref("label_img"), atol=5e-7)
+    assert np.array_equal(out["mask"].cpu().numpy(), ref("mask"))
+    np.testing.assert_allclose(out["heatmaps"].cpu().numpy(), ref("heatmaps"), atol=2e-7)
+    # the depth-offset maps switch on at `heatmap > 0`: compare where the reference's heat map is clearly positive or exactly zero
+    h = ref("heatmaps")
+    sure = (h > 1e-12) | (h == 0)
+    np.testing.assert_allclose(out["depthmaps"].cpu().numpy()[sure], ref("depthmaps")[sure], atol=5e-7)
+
+
+def test_device_pipeline_falls_back_per_sample_like_the_reference(golden_dir):
+    """A joint that leaves the label map after the augmentation makes the reference return the UN-augmented sample
+    (datasets.py:300): same here, for that sample only."""
+    from pixelwiseregression_amd import preprocess_batch
+    g, depth, joints, com = _load(golden_dir)
+    aug = {"angle": np.array([10.0] * 6), "scale": np.array([1.0, 1.0, 1.2, 1.0, 1.0, 1.0]), "shift_x": np.zeros(6), "shift_y": np.zeros(6)}
+    joints = joints.copy()
+    joints[2, 0, :2] = com[2, :2] + np.array([105.0, 0.0])           # far from the COM: out of the map once scaled by 1.2
+    out = preprocess_batch(depth, joints, com, 150, INTR, 128, 64, augmentation=aug)
+    plain = preprocess_batch(depth, joints, com, 150, INTR, 128, 64, augmentation=None, dense_targets=False)
+    fb = out["fallback"].numpy()
+    assert fb[2] and fb.sum() == 1, fb
+    assert torch.equal(out["img"][2], plain["img"][2]) and torch.equal(out["uvd"][2], plain["uvd"][2])
+    assert not torch.equal(out["img"][0], plain["img"][0])
+
+
+def test_preprocessed_batch_feeds_the_model(golden_dir):
+    from pixelwiseregression_amd import preprocess_batch, PixelwiseRegression
+    g, depth, joints, com = _load(golden_dir)
+    out = preprocess_batch(depth, joints, com, 150, INTR, 128, 64)
+    torch.manual_seed(0)
+    m = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, norm_method="instance").to(DEV).eval()
+    with torch.no_grad():
+        res = m(out["img"], out["label_img"], out["mask"])
+    assert res[-1][2].shape == (6, 14, 3) and torch.isfinite(res[-1][2]).all()
