@@ -355,9 +355,10 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
   else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
   else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
-    // 128x128 maps.  A/B switch (tools/bench_decoder.py): 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU;
-    // 1 = 1024 threads x 4 vectors; 2 = 512 x 8 held to 128 VGPRs (two workgroups per CU, a few spilled registers)
-    static const int v = [] { const char* e = getenv("PWR_DEC_FWD128"); return e ? atoi(e) : 1; }();
+    // 128x128 maps.  A/B switch (tools/bench_decoder.py), measured at B=128, J=42 on MI355X (profiles/r2_decoder_bench.jsonl):
+    // 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU: 4.28 TB/s (default); 1 = 1024 threads x 4 vectors: 4.24 TB/s;
+    // 2 = 512 x 8 held to 128 VGPRs (two workgroups per CU, a few spilled registers): 3.87 TB/s
+    static const int v = [] { const char* e = getenv("PWR_DEC_FWD128"); return e ? atoi(e) : 0; }();
     if (v == 1 && 4096 % P == 0)
       hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
     else if (v == 2)
@@ -385,9 +386,10 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
   else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
   else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
-    // 128x128 maps.  A/B switch: 0 = 512 x 8 with everything in registers (204 VGPRs, one workgroup per CU); 1 = 1024 x 4 (108 VGPRs,
-    // one 16-wave workgroup per CU); 2 = 512 x 8 RELOAD (softmax only; 128 VGPRs with spills, two workgroups per CU)
-    static const int v = [] { const char* e = getenv("PWR_DEC_BWD128"); return e ? atoi(e) : 1; }();
+    // 128x128 maps.  A/B switch, measured like the forward: 0 = 512 x 8 with everything in registers (204 VGPRs, one workgroup per
+    // CU): 4.74 TB/s (default; the two-reduction form of round 1: 3.04); 1 = 1024 x 4 (108 VGPRs, one 16-wave workgroup per CU): 4.38;
+    // 2 = 512 x 8 RELOAD (softmax only; 128 VGPRs with spills, two workgroups per CU): 2.51
+    static const int v = [] { const char* e = getenv("PWR_DEC_BWD128"); return e ? atoi(e) : 0; }();
     if (v == 1 && 4096 % P == 0)
       hipLaunchKernelGGL((pwr::decode_bwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
     else if (v == 2 && method == 0)

@@ -280,7 +280,8 @@ struct Engine {
     // w3: one wave of workgroups, whole XCD groups (no tail).  The <= 64-channel kernels fit two workgroups per CU; on the big
     // stem maps (>= 2^18 pixels: 205 K steps per workgroup otherwise, at the tail of the step) they get two waves of them.
     const int target = (w3 && cout <= 64 && M >= (1 << 18)) ? 2 * w3_target : w3_target;
-    int s = w3 ? (target / tiles) / 8 * 8 : (512 + tiles - 1) / tiles;
+    static const int tr_target = [] { const char* e = getenv("PWR_WGRAD_TR_SLOTS"); return e ? atoi(e) : 512; }();
+    int s = w3 ? (target / tiles) / 8 * 8 : (tr_target + tiles - 1) / tiles;
     if (w3 && s < 8) s = 8;
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
     if (s > maxs) s = maxs;

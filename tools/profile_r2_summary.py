@@ -1,0 +1,110 @@
+"""Summaries of tools/profile_r2.sh's rocprofv3 output -> small csv / json files for profiles/ (run on the GPU box, right after)."""
+import collections, csv, glob, json, os, sys
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+
+def find(d, suffix):
+    fs = glob.glob(os.path.join(src, d, "**", "*" + suffix), recursive=True)
+    return fs[0] if fs else None
+
+
+def short(n):
+    return n.replace("void pwr::", "").replace("_ZN3pwr", "pwr::")[:150]
+
+
+# 1. kernel statistics (step, isolated kernels, decoder, dist)
+for d in ("step", "iso", "dec", "dist"):
+    f = find(d, "kernel_stats.csv")
+    if f:
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(dst, "r2_rocprofv3_%s_kernel_stats.csv" % d), "w") as o:
+            w = csv.writer(o)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+        print(d, "stats:", len(rows), "kernels; top:", [(short(r["Name"])[:50], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in rows[:4]])
+
+
+# 2. PMC passes -> bytes per launch
+def mean_by_kernel(d, counter):
+    f = find(d, "counter_collection.csv")
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[(r["Kernel_Name"], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+B, P, F_ = 32, 64, 128
+act = B * P * P * F_ * 2
+out = {"source": "tools/profile_r2.sh on MI355X: rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; both counters are KB; "
+                 "FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide streaming reads at 64 B, MI355X_MICROARCH.md section HBM)"}
+fe, wr = mean_by_kernel("pmc_fetch", "FETCH_SIZE"), mean_by_kernel("pmc_write", "WRITE_SIZE")
+
+
+def entry(table_f, table_w, match, grid, alg, label):
+    ks = [k for k in table_f if match in k[0] and (grid is None or k[1] == str(grid))]
+    if not ks:
+        return
+    k = ks[0]
+    w = table_w.get(k, 0.0)
+    out[label] = {"FETCH_SIZE_KB": table_f[k], "WRITE_SIZE_KB": w, "hbm_bytes_corrected": int(2 * table_f[k] * 1024 + w * 1024)}
+    if alg:
+        out[label]["algorithmic_bytes"] = alg
+        out[label]["ratio"] = out[label]["hbm_bytes_corrected"] / alg
+
+
+entry(fe, wr, "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128")
+entry(fe, wr, "conv_wgrad3_kernel<2, 2, 1, 2>", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3_kernel<2,2,1,2> same shape")
+entry(fe, wr, "wgrad_reduce_kernel", None, None, "wgrad_reduce_kernel same shape")
+fd, wd = mean_by_kernel("pmc_fetch_dec", "FETCH_SIZE"), mean_by_kernel("pmc_write_dec", "WRITE_SIZE")
+for (Bd, Jd, Pd, nt) in ((32, 14, 64, 256), (64, 21, 64, 256), (128, 42, 128, 512)):
+    grid = Bd * Jd * nt
+    entry(fd, wd, "decode_fwd_cached", grid, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+    entry(fd, wd, "decode_bwd_cached", grid, 28 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd, "decode_bwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+json.dump(out, open(os.path.join(dst, "r2_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+
+# 3. MFMA busy fraction of the dominant kernels
+f = find("pmc_mfma", "counter_collection.csv")
+if f:
+    acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    mm = {}
+    for k, c in acc.items():
+        if "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1" in k or "conv_wgrad3_kernel<2, 2, 1, 2>" in k:
+            m = {n: sum(v) / len(v) for n, v in c.items()}
+            e = {"mean_ns_under_pmc": sum(dur[k]) / len(dur[k]), **m}
+            if m.get("GRBM_GUI_ACTIVE", 0) > 0:
+                cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                e["cycles_per_launch"] = cyc
+                e["mfma_busy_fraction"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / cyc
+            mm[short(k)] = e
+    json.dump(mm, open(os.path.join(dst, "r2_mfma_util.json"), "w"), indent=1)
+    print(json.dumps(mm, indent=1))
+
+# 4. data-parallel path: do the RCCL kernels overlap the next segment's backward?
+f = find("dist", "kernel_trace.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rc = [r for r in rows if "ccl" in r["Kernel_Name"].lower() or "allreduce" in r["Kernel_Name"].lower()]
+    lines = ["kernels in the trace: %d; RCCL kernels: %d (names: %s)" % (len(rows), len(rc), sorted({r["Kernel_Name"][:60] for r in rc}))]
+    ov = 0
+    for r in rc[-9:]:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        co = [q for q in rows if q is not r and int(q["Start_Timestamp"]) < e and int(q["End_Timestamp"]) > s and q["Stream_Id"] != r["Stream_Id"]]
+        ov += bool(co)
+        lines.append("RCCL kernel on stream %s: %.1f us, overlapped by %d engine kernels on other streams (e.g. %s)" % (
+            r["Stream_Id"], (e - s) / 1e3, len(co), short(co[0]["Kernel_Name"])[:50] if co else "-"))
+    lines.append("of the last %d RCCL kernels, %d overlap engine kernels of other streams" % (len(rc[-9:]), ov))
+    open(os.path.join(dst, "r2_dist_overlap.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+for nm in ("step_bench.json", "iso_bench.jsonl", "dec_bench.jsonl", "dist_bench.json"):
+    p = os.path.join(src, nm)
+    if os.path.exists(p):
+        open(os.path.join(dst, "r2_" + nm), "w").write(open(p).read())
