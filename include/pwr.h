@@ -168,6 +168,11 @@ int pwr_norm_bwd_params(const float* partial, float* dgamma, float* dbeta, int a
 int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* sums, const void* addend, void* dy, int relu, int B,
                        int HW, int C, int dtype, void* stream);
 int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream);
+/* InstanceNorm (+ReLU) backward with the parameter gradients deferred (round 2): reductions from `partial` (`chunks` rows per sample
+ * written by a data-gradient conv's epilogue, or chunks = 0: computed here first; partial then needs pwr_norm_partial_bytes), S1 / S2 and
+ * the apply on `stream`; the raw per-sample sums go to `sums` [B][2][C] for pwr_norm_param_grad, which may run later on any stream. */
+int pwr_norm_bwd_deferred(const void* g, const void* y, const float* state, float* partial, int chunks, float* S1, float* S2, float* sums,
+                          const void* addend, void* dy, int relu, int B, int HW, int C, int dtype, void* stream);
 
 /* Dense training targets on the device (datasets.py:285-294 heat maps = Gaussian blur, default border, of the bilinear 2x2
  * splat utils.py:37-64; datasets.py:365-383 depth-offset maps) from the normalised joints uvd [B,J,3], label_img and mask

@@ -294,6 +294,14 @@ struct Engine {
     static const int m = [] { const char* e = getenv("PWR_CONV_STATS_MASK"); return e ? atoi(e) : 3; }();
     return m;
   }
+  // A/B switch: InstanceNorm backward with the chunk reduction spread over 8 threads per (sample, channel) and dgamma / dbeta on a side
+  // stream (pwr_norm_bwd_deferred + pwr_norm_param_grad) instead of the one-thread-per-(b, c) reduction that also does dgamma / dbeta
+  // 0 = off (measured default: 6.94 ms/step), 1 = dgamma / dbeta on a side stream (7.31 ms: 34 more forked launches per step cost more
+  // than the shorter reduction saves), 2 = dgamma / dbeta right behind on the chain
+  static int deferred_norm_grads() {
+    static const int v = [] { const char* e = getenv("PWR_NORM_BWD_PAR"); return e ? atoi(e) : 0; }();
+    return v;
+  }
   // ---- norm statistics of tensor t (forward) and its backward (g -> dy, in place in t.goff, + addend)
   void norm_fwd_sizes(const Tn& t) {
     const size_t pb = pwr_norm_partial_bytes(B, t.H * t.W, t.C);
@@ -345,6 +353,18 @@ struct Engine {
           return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                               (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), has_addend ? c.arena + addend_goff : nullptr,
                               c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
+        if (mode == 0 && deferred_norm_grads()) {
+          // S1 / S2 + apply on the chain; dgamma / dbeta (a reduction over the batch of the per-sample sums) beside it
+          int rc = pwr_norm_bwd_deferred(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart), chunks,
+                                         (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), (float*)(c.arena + n.sums),
+                                         has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
+          if (rc) return rc;
+          if (deferred_norm_grads() == 2)
+            return pwr_norm_param_grad((float*)(c.arena + n.sums), c.grads + n.gamma, c.grads + n.beta, Bc, C, 0, c.stream);
+          return run_on_side(c, [=](Ctx& c2) {
+            return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
+          });
+        }
         return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart),
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
@@ -373,6 +393,17 @@ struct Engine {
         if (rc) return rc;
         return run_on_side(c, [=](Ctx& c2) {
           return pwr_norm_bwd_params((float*)(c2.arena + bpart), c2.grads + n.gamma, c2.grads + n.beta, 0, Bc, HW, C, c2.stream);
+        });
+      }
+      if (mode == 0 && deferred_norm_grads()) {
+        int rc = pwr_norm_bwd_deferred(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial), 0,
+                                       (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), (float*)(c.arena + n.sums),
+                                       has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
+        if (rc) return rc;
+        if (deferred_norm_grads() == 2)
+          return pwr_norm_param_grad((float*)(c.arena + n.sums), c.grads + n.gamma, c.grads + n.beta, Bc, C, 0, c.stream);
+        return run_on_side(c, [=](Ctx& c2) {
+          return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
         });
       }
       return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),

@@ -629,6 +629,94 @@ __global__ void norm_finalize_chunks_kernel(const float* __restrict__ partial, c
   }
 }
 
+
+// InstanceNorm form of the above with the chunks of one (sample, channel) spread over 8 threads: block = 32 channels x 8 chunk groups,
+// grid = (C/32, B).  Each thread merges its contiguous share of the chunks (equal sizes), the 8 group results are combined through LDS
+// in group order with the general pairwise formula.  One thread per (b, c) walking 128 chunks through two dependent divisions each
+// took 6.2 us on the critical chain 52 times per step.
+__global__ __launch_bounds__(256) void norm_finalize_chunks_par_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float* __restrict__ state, int B, int HW,
+                                                                       int C, int chunks, float eps) {
+  __shared__ float smean[8][33], sm2[8][33];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int b = blockIdx.y, c = blockIdx.x * 32 + cl;
+  const int per = chunks / 8;
+  const float nper = (float)(HW / chunks), inv = 1.f / nper;
+  float mean = 0.f, m2 = 0.f, cnt = 0.f;
+  if (c < C) {
+    const float* base = partial + (((size_t)b * chunks + (size_t)grp * per) * 3) * C + c;
+    for (int j0 = 0; j0 < per; j0 += 8) {
+      float a[8], q[8], k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(j0 + u, per - 1);
+        a[u] = base[((size_t)j * 3 + 0) * C]; q[u] = base[((size_t)j * 3 + 1) * C]; k[u] = base[((size_t)j * 3 + 2) * C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (j0 + u < per) {
+          const float mj = k[u] + a[u] * inv, d = mj - mean, c1 = cnt + 1.f;
+          mean += d / c1;
+          m2 += fmaxf(q[u] - a[u] * a[u] * inv, 0.f) + nper * d * d * (cnt / c1);
+          cnt = c1;
+        }
+      }
+    }
+  }
+  smean[grp][cl] = mean; sm2[grp][cl] = m2;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    // groups hold equal counts n_g = per * nper: after merging t groups the running count is t * n_g
+    float M = smean[0][cl], Q = sm2[0][cl];
+    const float ng = (float)per * nper;
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+      const float d = smean[t][cl] - M, tf = (float)t;
+      M += d / (tf + 1.f);
+      Q += sm2[t][cl] + ng * d * d * (tf / (tf + 1.f));
+    }
+    const float n = (float)HW;
+    const float var = fmaxf(Q / n, 0.f), rstd = 1.f / sqrtf(var + eps);
+    const size_t plane = (size_t)B * C, idx = (size_t)b * C + c;
+    state[idx] = M; state[plane + idx] = rstd; state[2 * plane + idx] = gamma[c] * rstd; state[3 * plane + idx] = beta[c];
+  }
+}
+
+// InstanceNorm backward reductions with the pixel chunks of one (sample, channel) spread over 8 threads (block = 32 channels x 8 chunk
+// groups, grid = (C/32, B): 128 blocks at C2 instead of the 16 of norm_bwd_sum_kernel, whose threads each walked all chunks of one
+// (b, c) -- 7.4 us on the critical chain 34 times per step).  Writes S1, S2 = sums / HW for the apply kernel and the raw per-sample
+// sums to `sums` [B][2][C]; dgamma / dbeta are reduced over the batch from `sums` by pwr_norm_param_grad, off the critical path.
+__global__ __launch_bounds__(256) void norm_bwd_sum_par_kernel(const float* __restrict__ partial, float* __restrict__ S1, float* __restrict__ S2,
+                                                               float* __restrict__ sums, int HW, int C, int nchunks) {
+  __shared__ float r1[8][33], r2[8][33];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int b = blockIdx.y, c = blockIdx.x * 32 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float* pp = partial + ((size_t)b * nchunks * 2) * C + c;
+    for (int k0 = grp; k0 < nchunks; k0 += 64) {       // this thread's chunks: grp, grp + 8, ...; 8 of them in flight
+      float a[8], q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 8 * u;
+        const bool ok = k < nchunks;
+        a[u] = ok ? pp[((size_t)k * 2 + 0) * C] : 0.f; q[u] = ok ? pp[((size_t)k * 2 + 1) * C] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += q[u]; }
+    }
+  }
+  r1[grp][cl] = s1; r2[grp][cl] = s2;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { a1 += r1[t][cl]; a2 += r2[t][cl]; }
+    S1[(size_t)b * C + c] = a1 / (float)HW; S2[(size_t)b * C + c] = a2 / (float)HW;
+    sums[((size_t)b * 2 + 0) * C + c] = a1; sums[((size_t)b * 2 + 1) * C + c] = a2;
+  }
+}
+
 }  // namespace pwr
 
 extern "C" int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
@@ -636,8 +724,13 @@ extern "C" int pwr_norm_finalize_partial(const float* partial, int chunks, const
                                          float eps, float momentum, void* stream) {
   if ((mode != 0 && mode != 1) || chunks < 1 || HW % chunks) return PWR_EINVAL;
   const int n = mode == 1 ? C : B * C;
-  hipLaunchKernelGGL(norm_finalize_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, state,
-                     running_mean, running_var, B, HW, C, chunks, mode, eps, momentum);
+  static const bool par = [] { const char* e = getenv("PWR_NORM_PAR"); return e ? atoi(e) != 0 : true; }();
+  if (mode == 0 && par && chunks % 8 == 0 && chunks >= 16)
+    hipLaunchKernelGGL(norm_finalize_chunks_par_kernel, dim3((C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, state, B,
+                       HW, C, chunks, eps);
+  else
+    hipLaunchKernelGGL(norm_finalize_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, state,
+                       running_mean, running_var, B, HW, C, chunks, mode, eps, momentum);
   return (int)hipGetLastError();
 }
 
@@ -695,6 +788,36 @@ extern "C" int pwr_norm_bwd_from_partial(const void* g, const void* y, const flo
     hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
                        S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
   }
+  return (int)hipGetLastError();
+}
+
+// InstanceNorm (+ReLU) backward with the parameter gradients DEFERRED: the two reductions come from `partial` (rows per sample:
+// `chunks` when a data-gradient conv's epilogue wrote them, pwr_conv_fwd_stats; 0 = compute them here from (g, y) first), S1 / S2 and
+// the apply run on `stream`, and the per-sample sums go to `sums` [B][2][C] for pwr_norm_param_grad (any stream, any time later).
+extern "C" int pwr_norm_bwd_deferred(const void* g, const void* y, const float* state, float* partial, int chunks, float* S1, float* S2,
+                                     float* sums, const void* addend, void* dy, int relu, int B, int HW, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256 || chunks < 0) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = norm_chunks(B, HW);
+  int rows = chunks;
+  if (chunks == 0) {
+    const int pl = 256 / (C / EP);
+    const size_t sh = (size_t)pl * 2 * C * 4;
+    partial = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + norm_counter_bytes(B));
+    if (dtype == PWR_BF16)
+      hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y, state, B, partial, HW, C, nch, relu);
+    else
+      hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state, B, partial, HW, C, nch, relu);
+    rows = nch;
+  }
+  hipLaunchKernelGGL(norm_bwd_sum_par_kernel, dim3((C + 31) / 32, B), dim3(256), 0, s, partial, S1, S2, sums, HW, C, rows);
+  if (dtype == PWR_BF16)
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, false>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B, S1, S2,
+                       (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
+  else
+    hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B, S1, S2,
+                       (const float*)addend, (float*)dy, HW, C, nch, relu);
   return (int)hipGetLastError();
 }
 

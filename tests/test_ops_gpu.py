@@ -539,6 +539,13 @@ def test_conv_epilogue_norm_backward_sums(case, dtype):
         assert_close(dy1.double().cpu(), dy0.double().cpu(), t, "dy (mode %d)" % mode)
         assert_close(dg1.double().cpu(), dg0.double().cpu(), 1e-4, "dgamma")
         assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
+        if mode == 0:
+            # round 2: the chunk reduction spread over 8 threads per (sample, channel), dgamma / dbeta deferred to pwr_norm_param_grad --
+            # from the conv epilogue's partials and from its own partial pass
+            for dy2, dg2, db2 in (K.norm_bwd_deferred(g1, y, state, partial, chunks, addend=add), K.norm_bwd_deferred(g1, y, state, addend=add)):
+                assert_close(dy2.double().cpu(), dy0.double().cpu(), t, "dy (deferred)")
+                assert_close(dg2.double().cpu(), dg0.double().cpu(), 1e-4, "dgamma (deferred)")
+                assert_close(db2.double().cpu(), db0.double().cpu(), 1e-4, "dbeta (deferred)")
 
 
 @pytest.mark.parametrize("B,H,W", [(32, 64, 64), (33, 64, 64), (5, 128, 160)])
