@@ -54,7 +54,54 @@ struct Ctx {
   int n_side = 0, side_rr = 0;
   size_t slab_off = 0, slab_stride = 0;   // byte offset of the current stream's slab inside the slab scratch
   bool use_side = true;
+  bool attached = false;    // side streams / events taken from the process-wide pool
 };
+
+// The side streams, their join events and the pool of fork events are PROCESS-wide (one set per device), shared by every engine:
+// HIP streams map onto a limited number of hardware queues, and every further pair of side streams kept alive by another plan (a
+// second batch size, the previous model of a sweep not yet garbage-collected) made ALL of them slower -- C3's train step took
+// 20.2 ms instead of 11.5 ms when it ran after C2's plan in the same process.  Engines run one at a time on the caller's stream, so
+// sharing is safe; the streams live as long as the process.
+struct SidePool {
+  hipStream_t side[Ctx::kMaxSide] = {};
+  hipEvent_t ev_fork[Ctx::kForkPool] = {}, ev_join[Ctx::kMaxSide] = {};
+  int n_side = -1, n_fork = 0;     // -1: not created yet
+};
+static SidePool& side_pool() {
+  static SidePool pools[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return pools[dev & 15];
+}
+static void side_pool_attach(Ctx& c) {
+  SidePool& sp = side_pool();
+  if (sp.n_side < 0) {
+    const char* env = getenv("PWR_SIDE_STREAM");   // number of side streams, 0 = everything on the caller's stream
+    int want = env ? atoi(env) : 2;
+    if (want > Ctx::kMaxSide) want = Ctx::kMaxSide;
+    sp.n_side = 0;
+    for (int k = 0; want > 0 && k < Ctx::kForkPool; ++k) {
+      if (hipEventCreateWithFlags(&sp.ev_fork[k], hipEventDisableTiming) != hipSuccess) break;
+      sp.n_fork = k + 1;
+    }
+    // side streams at the LOWEST priority: when a weight-gradient kernel and a kernel of the critical chain both have
+    // workgroups to place, the chain goes first and the weight gradients fill what is left
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char* pe = getenv("PWR_SIDE_PRIORITY");
+    const bool low = pe ? atoi(pe) != 0 : true;
+    for (int k = 0; sp.n_fork > 0 && k < want; ++k) {
+      if (hipStreamCreateWithPriority(&sp.side[k], hipStreamNonBlocking, low ? prio_lo : 0) != hipSuccess ||
+          hipEventCreateWithFlags(&sp.ev_join[k], hipEventDisableTiming) != hipSuccess) break;
+      sp.n_side = k + 1;
+    }
+  }
+  for (int k = 0; k < sp.n_side; ++k) { c.side[k] = sp.side[k]; c.ev_join[k] = sp.ev_join[k]; }
+  for (int k = 0; k < sp.n_fork; ++k) c.ev_fork[k] = sp.ev_fork[k];
+  c.n_side = sp.n_side; c.n_fork = sp.n_fork;
+  c.use_side = sp.n_side > 0;
+  c.attached = true;
+}
 
 // run `op` on the side stream, ordered after everything enqueued so far on the main stream
 static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
@@ -904,11 +951,7 @@ extern "C" void* pwr_engine_create(const int* cfg, int B, int dtype, int trainin
 
 extern "C" void pwr_engine_destroy(void* h) {
   Engine* e = (Engine*)h;
-  for (int k = 0; k < e->ctx.n_side; ++k) {
-    hipStreamSynchronize(e->ctx.side[k]);
-    hipEventDestroy(e->ctx.ev_join[k]); hipStreamDestroy(e->ctx.side[k]);
-  }
-  for (int k = 0; k < e->ctx.n_fork; ++k) hipEventDestroy(e->ctx.ev_fork[k]);
+  for (int k = 0; k < e->ctx.n_side; ++k) hipStreamSynchronize(e->ctx.side[k]);    // (shared streams: drained, not destroyed)
   e->destroy_graphs();
   delete e;
 }
@@ -997,29 +1040,7 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
   for (int s = 0; s < e->stages; ++s) {
     c.g_p[s] = (const float*)gouts[3 * s]; c.g_D[s] = (const float*)gouts[3 * s + 1]; c.g_uvd[s] = (const float*)gouts[3 * s + 2];
   }
-  if (c.use_side && c.n_side == 0) {
-    const char* env = getenv("PWR_SIDE_STREAM");   // number of side streams, 0 = everything on the caller's stream
-    int want = env ? atoi(env) : 2;
-    if (want > Ctx::kMaxSide) want = Ctx::kMaxSide;
-    c.use_side = want > 0;
-    for (int k = 0; c.use_side && k < Ctx::kForkPool; ++k) {
-      if (hipEventCreateWithFlags(&c.ev_fork[k], hipEventDisableTiming) != hipSuccess) break;
-      c.n_fork = k + 1;
-    }
-    if (c.n_fork == 0) c.use_side = false;
-    // side streams at the LOWEST priority: when a weight-gradient kernel and a kernel of the critical chain both have
-    // workgroups to place, the chain goes first and the weight gradients fill what is left
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const char* pe = getenv("PWR_SIDE_PRIORITY");
-    const bool low = pe ? atoi(pe) != 0 : true;
-    for (int k = 0; c.use_side && k < want; ++k) {
-      if (hipStreamCreateWithPriority(&c.side[k], hipStreamNonBlocking, low ? prio_lo : 0) != hipSuccess ||
-          hipEventCreateWithFlags(&c.ev_join[k], hipEventDisableTiming) != hipSuccess) break;
-      c.n_side = k + 1;
-    }
-    if (c.n_side == 0) c.use_side = false;
-  }
+  if (!c.attached) side_pool_attach(c);
   auto run = [&](void* st) -> int {
     c.stream = st;
     c.side_rr = 0;

@@ -21,7 +21,6 @@ JOIN_ONCE = _os.environ.get("PWR_JOIN_ONCE", "0") not in ("", "0")
 class _Plan:
     def __init__(self, model, B, dtype, need_grad):
         l = _lib.lib()
-        self.model_ref = model
         self.B, self.dtype, self.need_grad = B, dtype, need_grad
         dev = model._flat.device
         cfg = (ctypes.c_int * 8)(model.joints, model.stage, model.label_size, model.features, model.level, model.kernel_size,

@@ -1,0 +1,65 @@
+"""Build container only (needs /root/reference): is the CPU oracle (oracle/model_ref.py, what bench.py times as `cpu_baseline` on the
+GPU box, where the reference's files are absent) as fast as the reference itself?  Same architecture (BASELINE C2), same batch,
+same threads, BASELINE.md section 3 protocol (3 warm-up + 10 timed, median), inference and train step (fwd + loss + bwd + AdamW).
+
+    python tools/ref_vs_oracle_cpu.py [batch] > profiles/r2_ref_vs_oracle_cpu.json
+"""
+import json, os, statistics, sys, time, types
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import gen_golden as G
+from oracle import model_ref
+from pixelwiseregression_amd.synthetic import make_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+threads = os.cpu_count()
+torch.set_num_threads(threads)
+ref_model, _, _ = G.import_reference()
+torch.manual_seed(0)
+kw = dict(stage=2, label_size=64, features=128, level=4, kernel_size=3, norm_method="instance", heatmap_method="softmax")
+m = ref_model.PixelwiseRegression(14, **kw)
+sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+batch = make_batch(B, 14, S=128, seed=1234)
+rc = model_ref.RefConfig(14, 2, 64, 128, 4, 3, "instance", "softmax")
+
+
+def timed(fn, warm=3, n=10):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+    return statistics.median(ts)
+
+
+def ref_infer():
+    with torch.no_grad():
+        m(batch["img"], batch["label_img"], batch["mask"])
+
+
+opt_r = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0)
+def ref_train():
+    opt_r.zero_grad()
+    res = m(batch["img"], batch["label_img"], batch["mask"])
+    sum(torch.mean(torch.sum((u - batch["uvd"]) ** 2, dim=2)) for (_, _, u) in res).backward()
+    opt_r.step()
+
+
+params = {k: v.clone().requires_grad_(v.is_floating_point() and "filter" not in k) for k, v in sd.items()}
+opt_o = torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=1e-4, weight_decay=0)
+def ora_infer():
+    with torch.no_grad():
+        model_ref.forward(params, rc, batch["img"], batch["label_img"], batch["mask"], training=False)
+def ora_train():
+    opt_o.zero_grad()
+    res = model_ref.forward(params, rc, batch["img"], batch["label_img"], batch["mask"], training=True)
+    model_ref.train_loss(res, batch["uvd"]).backward()
+    opt_o.step()
+
+
+m.eval(); ri = timed(ref_infer); oi = timed(ora_infer)
+m.train(); rt = timed(ref_train, 2, 6); ot = timed(ora_train, 2, 6)
+print(json.dumps({"where": "build container (no GPU)", "threads": threads, "batch": B, "protocol": "median; inference 3 warm-up + 10 timed, train 2 + 6",
+                  "reference_infer_frames_per_s": B / ri, "oracle_infer_frames_per_s": B / oi, "oracle_over_reference_infer": ri / oi,
+                  "reference_train_frames_per_s": B / rt, "oracle_train_frames_per_s": B / ot, "oracle_over_reference_train": rt / ot}, indent=1))
