@@ -54,21 +54,24 @@ struct RbGeom {
   static constexpr int TOTAL = R_BYTES + W_BYTES + RED_BYTES;
 };
 
-// waves of the 256-thread workgroup over an MF x NF grid of 32x32 MFMA tiles
-template <int MF, int NF>
+// The workgroup has NW waves: 8 for the 16x16 and 8x8 maps, 4 below (round 2: with 4 waves = one per SIMD nothing hid the LDS /
+// global round trips of the twelve dependent phases and the element-wise passes ran on a quarter of the CU's lanes; 16 waves cap the
+// kernel at 128 VGPRs and it spills ~200 of them -- measured 8: train step 6.88 -> 6.77 ms, inference 15.9k -> 16.15k frames/s).
+// waves of the workgroup over an MF x NF grid of 32x32 MFMA tiles
+template <int MF, int NF, int NW>
 struct RbWaves {
-  static constexpr int WMv = MF >= 4 ? 4 : MF, WNv = 4 / WMv;
+  static constexpr int WMv = MF >= NW ? NW : MF, WNv = NW / WMv;
   static constexpr int MR = MF / WMv, NR = NF >= WNv ? NF / WNv : 1;
 };
 
 // whole weight pack -> LDS by LDS-DMA: `ntiles` tiles of [NROWS][64 B]; 1 KiB (16 rows) per wave instruction, XOR swizzle
 // applied to the source address (cdna_hip_programming.md rule 21).  Completion: s_waitcnt vmcnt(0) + barrier.
-template <int NROWS>
+template <int NROWS, int NW>
 __device__ __forceinline__ void rb_dma_weights(const char* __restrict__ pack, int ntiles, char* Wl) {
   constexpr int CPT = NROWS / 16;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nch = ntiles * CPT;
-  for (int c = wid; c < nch; c += 4) {
+  for (int c = wid; c < nch; c += NW) {
     const int tile = c / CPT, row = 16 * (c % CPT) + (lane >> 2);
     const int slot = (lane & 3) ^ ((row >> 2) & 3);
     const char* src = pack + ((size_t)tile * NROWS + row) * 64 + slot * 16;
@@ -83,9 +86,9 @@ __device__ __forceinline__ void rb_wait_sync() {
 }
 
 // acc[MR][NR] = A (LDS: [pixel][K] tile of pitch AP, or the 3x3 patch) x weights (LDS tiles)
-template <int LOGW, int MF, int NF, int TAPS, int KCH, bool PATCH, int AP>
-__device__ __forceinline__ void rb_gemm(const char* A, const char* Wl, f32x16 (&acc)[RbWaves<MF, NF>::MR][RbWaves<MF, NF>::NR]) {
-  typedef RbWaves<MF, NF> WT;
+template <int LOGW, int MF, int NF, int TAPS, int KCH, bool PATCH, int AP, int NW>
+__device__ __forceinline__ void rb_gemm(const char* A, const char* Wl, f32x16 (&acc)[RbWaves<MF, NF, NW>::MR][RbWaves<MF, NF, NW>::NR]) {
+  typedef RbWaves<MF, NF, NW> WT;
   constexpr int MR = WT::MR, NR = WT::NR, Wd = 1 << LOGW, PWp = Wd + 2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int wm = wid / WT::WNv, wn = wid % WT::WNv;
@@ -130,10 +133,10 @@ __device__ __forceinline__ void rb_gemm(const char* A, const char* Wl, f32x16 (&
 }
 
 // accumulators (+ bias) -> bf16 -> LDS [pixel][channel] of pitch TP (the rounding point of the unfused conv epilogue)
-template <int MF, int NF>
-__device__ __forceinline__ void rb_acc_to_lds(const f32x16 (&acc)[RbWaves<MF, NF>::MR][RbWaves<MF, NF>::NR], const float* __restrict__ bias,
+template <int MF, int NF, int NW>
+__device__ __forceinline__ void rb_acc_to_lds(const f32x16 (&acc)[RbWaves<MF, NF, NW>::MR][RbWaves<MF, NF, NW>::NR], const float* __restrict__ bias,
                                               char* T, int TP) {
-  typedef RbWaves<MF, NF> WT;
+  typedef RbWaves<MF, NF, NW> WT;
   constexpr int MR = WT::MR, NR = WT::NR;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int wm = wid / WT::WNv, wn = wid % WT::WNv;
@@ -152,24 +155,38 @@ __device__ __forceinline__ void rb_acc_to_lds(const f32x16 (&acc)[RbWaves<MF, NF
   }
 }
 
-// sum of s[0..15] over the pixel lanes of the workgroup (threads with the same channel slot); result in all threads
-template <int NSLOT>
+// sum of s[0..15] over the pixel lanes of the workgroup (threads with the same channel slot); result in all threads.
+// `red` holds 1024 floats: with more than four waves the 16 values go through it in rounds of 1024 / (NW * NSLOT).
+template <int NSLOT, int NW>
 __device__ __forceinline__ void rb_reduce16(float (&s)[16], float* red, int slot) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int o = NSLOT; o < 64; o <<= 1)
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] += __shfl_xor(s[e], o, 64);
-  __syncthreads();   // `red` may still be read from a previous use
-  if (lane < NSLOT) {
+  constexpr int CAP = 1024 / (NW * NSLOT), VPR = CAP >= 16 ? 16 : CAP;
+  static_assert(VPR >= 1 && 16 % VPR == 0, "rounds of whole values");
 #pragma unroll
-    for (int e = 0; e < 16; ++e) red[(wid * NSLOT + slot) * 16 + e] = s[e];
+  for (int r0 = 0; r0 < 16; r0 += VPR) {
+    __syncthreads();   // `red` may still be read from a previous use / round
+    if (lane < NSLOT) {
+#pragma unroll
+      for (int e = 0; e < VPR; ++e) red[(wid * NSLOT + slot) * VPR + e] = s[r0 + e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VPR; ++e) {
+      if constexpr (NW == 4) {
+        s[r0 + e] = (red[(0 * NSLOT + slot) * VPR + e] + red[(1 * NSLOT + slot) * VPR + e]) +
+                    (red[(2 * NSLOT + slot) * VPR + e] + red[(3 * NSLOT + slot) * VPR + e]);
+      } else {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(w * NSLOT + slot) * VPR + e];
+        s[r0 + e] = t;
+      }
+    }
   }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 16; ++e)
-    s[e] = (red[(0 * NSLOT + slot) * 16 + e] + red[(1 * NSLOT + slot) * 16 + e]) +
-           (red[(2 * NSLOT + slot) * 16 + e] + red[(3 * NSLOT + slot) * 16 + e]);
 }
 
 template <int LOGW, int DST>
@@ -180,10 +197,10 @@ __device__ __forceinline__ int rb_dst_off(int px, int slot, int DP) {
 }
 
 // zero the halo of the 3x3 patch (W+2)^2 x 64 channels
-template <int LOGW>
+template <int LOGW, int NW>
 __device__ __forceinline__ void rb_zero_halo(char* R) {
   constexpr int PWp = (1 << LOGW) + 2;
-  for (int idx = threadIdx.x; idx < PWp * PWp * 8; idx += 256) {
+  for (int idx = threadIdx.x; idx < PWp * PWp * 8; idx += 64 * NW) {
     const int pix = idx >> 3, s = idx & 7;
     const int py = pix / PWp, px = pix - py * PWp;
     if (py == 0 || py == PWp - 1 || px == 0 || px == PWp - 1) *reinterpret_cast<bf16x8*>(R + pix * 144 + s * 16) = bf16x8{};
@@ -192,11 +209,11 @@ __device__ __forceinline__ void rb_zero_halo(char* R) {
 
 // InstanceNorm statistics of one sample's [HW][CH] map + normalise + ReLU into the next GEMM's A operand.
 // Source: global (the block input) or LDS (raw conv output, also stored to global for the backward pass).
-template <int CH, int LOGW, bool SRC_GLOBAL, int DST>
+template <int CH, int LOGW, bool SRC_GLOBAL, int DST, int NW>
 __device__ __forceinline__ void rb_norm_fwd(const bf16_t* __restrict__ gsrc, const char* T, int TP, bf16_t* __restrict__ raw_dst,
                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ state,
                                             int b, int B, char* dst, int DP, float eps, float* red) {
-  constexpr int HW = 1 << (2 * LOGW), NSLOT = CH / 8, PL = 256 / NSLOT, NPX = (HW + PL - 1) / PL;
+  constexpr int HW = 1 << (2 * LOGW), NSLOT = CH / 8, PL = 64 * NW / NSLOT, NPX = (HW + PL - 1) / PL;
   const int slot = threadIdx.x % NSLOT, pl = threadIdx.x / NSLOT;
   float ga[8], be[8];
 #pragma unroll
@@ -235,7 +252,7 @@ __device__ __forceinline__ void rb_norm_fwd(const bf16_t* __restrict__ gsrc, con
       }
     }
   }
-  rb_reduce16<NSLOT>(s, red, slot);
+  rb_reduce16<NSLOT, NW>(s, red, slot);
   float mean[8], scale[8];
   const float inv = 1.f / (float)HW;
 #pragma unroll
@@ -265,11 +282,11 @@ __device__ __forceinline__ void rb_norm_fwd(const bf16_t* __restrict__ gsrc, con
 
 // backward of relu(IN(y)) for one sample: g (raw data gradient, LDS) -> dy = scale * (gm - mean(gm) - xhat * mean(gm * xhat))
 // (+ addend), written to global (for the weight gradient) and, DST 0/1, into the next GEMM's A operand.
-template <int CH, int LOGW, int DST>
+template <int CH, int LOGW, int DST, int NW>
 __device__ __forceinline__ void rb_norm_bwd(const char* T, int TP, const bf16_t* __restrict__ ysrc, const float* __restrict__ state, int b, int B,
                                             const bf16_t* __restrict__ addend, bf16_t* __restrict__ dy_dst, float* __restrict__ sums,
                                             char* dst, int DP, float* red) {
-  constexpr int HW = 1 << (2 * LOGW), NSLOT = CH / 8, PL = 256 / NSLOT, NPX = (HW + PL - 1) / PL;
+  constexpr int HW = 1 << (2 * LOGW), NSLOT = CH / 8, PL = 64 * NW / NSLOT, NPX = (HW + PL - 1) / PL;
   const int slot = threadIdx.x % NSLOT, pl = threadIdx.x / NSLOT;
   float mu[8], rs[8], sc[8], sh[8];
   {
@@ -305,7 +322,7 @@ __device__ __forceinline__ void rb_norm_bwd(const char* T, int TP, const bf16_t*
       }
     }
   }
-  rb_reduce16<NSLOT>(s, red, slot);
+  rb_reduce16<NSLOT, NW>(s, red, slot);
   if (pl == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sums[slot * 8 + e] = s[e]; sums[CH + slot * 8 + e] = s[8 + e]; }
@@ -333,8 +350,8 @@ __device__ __forceinline__ void rb_norm_bwd(const char* T, int TP, const bf16_t*
   }
 }
 
-template <int LOGW>
-__global__ __launch_bounds__(256) void resblock_fwd_small_kernel(RbFwdParams p) {
+template <int LOGW, int NW>
+__global__ __launch_bounds__(64 * NW) void resblock_fwd_small_kernel(RbFwdParams p) {
   typedef RbGeom<LOGW> G;
   constexpr int HW = G::HW, MF = G::MF;
   __shared__ __attribute__((aligned(16))) char smem[G::TOTAL];
@@ -345,45 +362,45 @@ __global__ __launch_bounds__(256) void resblock_fwd_small_kernel(RbFwdParams p) 
   const int b = blockIdx.x;
 
   // ---- a0 = relu(IN_a(x)) -> R [HW][128]
-  rb_dma_weights<64>(p.wa, 4, Wl);
-  rb_norm_fwd<128, LOGW, true, 0>(p.x + (size_t)b * HW * 128, nullptr, 0, nullptr, p.ga, p.bta, p.sa, b, p.B, R, G::P128, p.eps, red);
+  rb_dma_weights<64, NW>(p.wa, 4, Wl);
+  rb_norm_fwd<128, LOGW, true, 0, NW>(p.x + (size_t)b * HW * 128, nullptr, 0, nullptr, p.ga, p.bta, p.sa, b, p.B, R, G::P128, p.eps, red);
   rb_wait_sync();
   // ---- t1 = conv1x1_a(a0) + bias
   {
-    f32x16 acc[RbWaves<MF, 2>::MR][RbWaves<MF, 2>::NR];
-    rb_gemm<LOGW, MF, 2, 1, 4, false, G::P128>(R, Wl, acc);
+    f32x16 acc[RbWaves<MF, 2, NW>::MR][RbWaves<MF, 2, NW>::NR];
+    rb_gemm<LOGW, MF, 2, 1, 4, false, G::P128, NW>(R, Wl, acc);
     __syncthreads();                       // R (a0) and the weights are dead
-    rb_dma_weights<64>(p.wb, 18, Wl);      // lands while the norm below runs
-    rb_acc_to_lds<MF, 2>(acc, p.ba, T, G::P64);
+    rb_dma_weights<64, NW>(p.wb, 18, Wl);      // lands while the norm below runs
+    rb_acc_to_lds<MF, 2, NW>(acc, p.ba, T, G::P64);
   }
-  rb_zero_halo<LOGW>(R);
+  rb_zero_halo<LOGW, NW>(R);
   __syncthreads();
-  rb_norm_fwd<64, LOGW, false, 1>(nullptr, T, G::P64, p.t1 ? p.t1 + (size_t)b * HW * 64 : nullptr, p.gb, p.btb, p.sb, b, p.B, R, G::P64, p.eps, red);
+  rb_norm_fwd<64, LOGW, false, 1, NW>(nullptr, T, G::P64, p.t1 ? p.t1 + (size_t)b * HW * 64 : nullptr, p.gb, p.btb, p.sb, b, p.B, R, G::P64, p.eps, red);
   rb_wait_sync();
   // ---- t2 = conv3x3_b(a1) + bias
   {
-    f32x16 acc[RbWaves<MF, 2>::MR][RbWaves<MF, 2>::NR];
-    rb_gemm<LOGW, MF, 2, 9, 2, true, G::P64>(R, Wl, acc);
+    f32x16 acc[RbWaves<MF, 2, NW>::MR][RbWaves<MF, 2, NW>::NR];
+    rb_gemm<LOGW, MF, 2, 9, 2, true, G::P64, NW>(R, Wl, acc);
     __syncthreads();
-    rb_dma_weights<128>(p.wc, 2, Wl);
-    rb_acc_to_lds<MF, 2>(acc, p.bb, T, G::P64);
+    rb_dma_weights<128, NW>(p.wc, 2, Wl);
+    rb_acc_to_lds<MF, 2, NW>(acc, p.bb, T, G::P64);
   }
   __syncthreads();
-  rb_norm_fwd<64, LOGW, false, 0>(nullptr, T, G::P64, p.t2 ? p.t2 + (size_t)b * HW * 64 : nullptr, p.gc, p.btc, p.sc, b, p.B, R, G::P64, p.eps, red);
+  rb_norm_fwd<64, LOGW, false, 0, NW>(nullptr, T, G::P64, p.t2 ? p.t2 + (size_t)b * HW * 64 : nullptr, p.gc, p.btc, p.sc, b, p.B, R, G::P64, p.eps, red);
   rb_wait_sync();
   // ---- out = conv1x1_c(a2) + bias + x
   {
-    f32x16 acc[RbWaves<MF, 4>::MR][RbWaves<MF, 4>::NR];
-    rb_gemm<LOGW, MF, 4, 1, 2, false, G::P64>(R, Wl, acc);
+    f32x16 acc[RbWaves<MF, 4, NW>::MR][RbWaves<MF, 4, NW>::NR];
+    rb_gemm<LOGW, MF, 4, 1, 2, false, G::P64, NW>(R, Wl, acc);
     __syncthreads();
-    rb_acc_to_lds<MF, 4>(acc, p.bc, Wl, G::P128);
+    rb_acc_to_lds<MF, 4, NW>(acc, p.bc, Wl, G::P128);
   }
   __syncthreads();
   {
     const int slot = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const bf16_t* xs = p.x + (size_t)b * HW * 128;
     bf16_t* os = p.out + (size_t)b * HW * 128;
-    for (int px = pl; px < HW; px += 16) {
+    for (int px = pl; px < HW; px += 4 * NW) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(Wl + px * G::P128 + slot * 16);
       const bf16x8 xr = *reinterpret_cast<const bf16x8*>(xs + (size_t)px * 128 + slot * 8);
       bf16x8 o;
@@ -394,8 +411,8 @@ __global__ __launch_bounds__(256) void resblock_fwd_small_kernel(RbFwdParams p) 
   }
 }
 
-template <int LOGW>
-__global__ __launch_bounds__(256) void resblock_bwd_small_kernel(RbBwdParams p) {
+template <int LOGW, int NW>
+__global__ __launch_bounds__(64 * NW) void resblock_bwd_small_kernel(RbBwdParams p) {
   typedef RbGeom<LOGW> G;
   constexpr int HW = G::HW, MF = G::MF;
   __shared__ __attribute__((aligned(16))) char smem[G::TOTAL];
@@ -407,19 +424,20 @@ __global__ __launch_bounds__(256) void resblock_bwd_small_kernel(RbBwdParams p) 
   const bf16_t* go = p.gout + (size_t)b * HW * 128;
 
   // ---- g_out -> R [HW][128]
-  rb_dma_weights<64>(p.wcd, 4, Wl);
+  rb_dma_weights<64, NW>(p.wcd, 4, Wl);
   {
     const int slot = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    constexpr int NPX = (HW + 15) / 16;
+    constexpr int PLG = 4 * NW, NPX = (HW + PLG - 1) / PLG;
     bf16x8 v[NPX];
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
-      const int px = pl + 16 * k;
+      const int px = pl + PLG * k;
+      v[k] = bf16x8{};
       if (px < HW) v[k] = *reinterpret_cast<const bf16x8*>(go + (size_t)px * 128 + slot * 8);
     }
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
-      const int px = pl + 16 * k;
+      const int px = pl + PLG * k;
       if (px < HW) *reinterpret_cast<bf16x8*>(R + px * G::P128 + slot * 16) = v[k];
     }
     if (p.bias_sums) {   // db_c[b][c] = sum over pixels of g_out (conv c's bias gradient, summed over b by rb_param_grad_kernel)
@@ -428,13 +446,13 @@ __global__ __launch_bounds__(256) void resblock_bwd_small_kernel(RbBwdParams p) 
       for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
       for (int k = 0; k < NPX; ++k) {
-        const int px = pl + 16 * k;
+        const int px = pl + PLG * k;
         if (px < HW) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) s[e] += (float)v[k][e];
         }
       }
-      rb_reduce16<16>(s, red, slot);
+      rb_reduce16<16, NW>(s, red, slot);
       if (pl == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) p.bias_sums[(size_t)b * 128 + slot * 8 + e] = s[e];
@@ -444,38 +462,38 @@ __global__ __launch_bounds__(256) void resblock_bwd_small_kernel(RbBwdParams p) 
   rb_wait_sync();
   // ---- g wrt a2 = g_out x Wc^T ; norm-backward c -> dt2
   {
-    f32x16 acc[RbWaves<MF, 2>::MR][RbWaves<MF, 2>::NR];
-    rb_gemm<LOGW, MF, 2, 1, 4, false, G::P128>(R, Wl, acc);
+    f32x16 acc[RbWaves<MF, 2, NW>::MR][RbWaves<MF, 2, NW>::NR];
+    rb_gemm<LOGW, MF, 2, 1, 4, false, G::P128, NW>(R, Wl, acc);
     __syncthreads();
-    rb_dma_weights<64>(p.wbd, 18, Wl);
-    rb_acc_to_lds<MF, 2>(acc, nullptr, T, G::P64);
+    rb_dma_weights<64, NW>(p.wbd, 18, Wl);
+    rb_acc_to_lds<MF, 2, NW>(acc, nullptr, T, G::P64);
   }
-  rb_zero_halo<LOGW>(R);
+  rb_zero_halo<LOGW, NW>(R);
   __syncthreads();
-  rb_norm_bwd<64, LOGW, 1>(T, G::P64, p.t2 + (size_t)b * HW * 64, p.sc, b, p.B, nullptr, p.dt2 + (size_t)b * HW * 64,
+  rb_norm_bwd<64, LOGW, 1, NW>(T, G::P64, p.t2 + (size_t)b * HW * 64, p.sc, b, p.B, nullptr, p.dt2 + (size_t)b * HW * 64,
                            p.sums_c + (size_t)b * 2 * 64, R, G::P64, red);
   rb_wait_sync();
   // ---- g wrt a1 = conv3x3(dt2, flipped Wb) ; norm-backward b -> dt1
   {
-    f32x16 acc[RbWaves<MF, 2>::MR][RbWaves<MF, 2>::NR];
-    rb_gemm<LOGW, MF, 2, 9, 2, true, G::P64>(R, Wl, acc);
+    f32x16 acc[RbWaves<MF, 2, NW>::MR][RbWaves<MF, 2, NW>::NR];
+    rb_gemm<LOGW, MF, 2, 9, 2, true, G::P64, NW>(R, Wl, acc);
     __syncthreads();
-    rb_dma_weights<128>(p.wad, 2, Wl);
-    rb_acc_to_lds<MF, 2>(acc, nullptr, T, G::P64);
+    rb_dma_weights<128, NW>(p.wad, 2, Wl);
+    rb_acc_to_lds<MF, 2, NW>(acc, nullptr, T, G::P64);
   }
   __syncthreads();
-  rb_norm_bwd<64, LOGW, 0>(T, G::P64, p.t1 + (size_t)b * HW * 64, p.sb, b, p.B, nullptr, p.dt1 + (size_t)b * HW * 64,
+  rb_norm_bwd<64, LOGW, 0, NW>(T, G::P64, p.t1 + (size_t)b * HW * 64, p.sb, b, p.B, nullptr, p.dt1 + (size_t)b * HW * 64,
                            p.sums_b + (size_t)b * 2 * 64, R, G::P64, red);
   rb_wait_sync();
   // ---- g wrt a0 = dt1 x Wa^T ; norm-backward a + skip -> dx
   {
-    f32x16 acc[RbWaves<MF, 4>::MR][RbWaves<MF, 4>::NR];
-    rb_gemm<LOGW, MF, 4, 1, 2, false, G::P64>(R, Wl, acc);
+    f32x16 acc[RbWaves<MF, 4, NW>::MR][RbWaves<MF, 4, NW>::NR];
+    rb_gemm<LOGW, MF, 4, 1, 2, false, G::P64, NW>(R, Wl, acc);
     __syncthreads();
-    rb_acc_to_lds<MF, 4>(acc, nullptr, Wl, G::P128);
+    rb_acc_to_lds<MF, 4, NW>(acc, nullptr, Wl, G::P128);
   }
   __syncthreads();
-  rb_norm_bwd<128, LOGW, 2>(Wl, G::P128, p.x + (size_t)b * HW * 128, p.sa, b, p.B, go, p.dx + (size_t)b * HW * 128,
+  rb_norm_bwd<128, LOGW, 2, NW>(Wl, G::P128, p.x + (size_t)b * HW * 128, p.sa, b, p.B, go, p.dx + (size_t)b * HW * 128,
                             p.sums_a + (size_t)b * 2 * 128, nullptr, 0, red);
 }
 
@@ -540,10 +558,13 @@ extern "C" int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* o
   p.sa = state_a; p.sb = state_b; p.sc = state_c;
   p.B = B; p.eps = eps;
   hipStream_t s = (hipStream_t)stream;
-  if (W == 16) hipLaunchKernelGGL((resblock_fwd_small_kernel<4>), dim3(B), dim3(256), 0, s, p);
-  else if (W == 8) hipLaunchKernelGGL((resblock_fwd_small_kernel<3>), dim3(B), dim3(256), 0, s, p);
-  else if (W == 4) hipLaunchKernelGGL((resblock_fwd_small_kernel<2>), dim3(B), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((resblock_fwd_small_kernel<1>), dim3(B), dim3(256), 0, s, p);
+  static const int wide = [] { const char* e = getenv("PWR_RESBLOCK_WAVES"); return e ? atoi(e) : 1; }();   // 0: four waves everywhere (round 1)
+  if (W == 16 && wide) hipLaunchKernelGGL((resblock_fwd_small_kernel<4, 8>), dim3(B), dim3(512), 0, s, p);
+  else if (W == 16) hipLaunchKernelGGL((resblock_fwd_small_kernel<4, 4>), dim3(B), dim3(256), 0, s, p);
+  else if (W == 8 && wide) hipLaunchKernelGGL((resblock_fwd_small_kernel<3, 8>), dim3(B), dim3(512), 0, s, p);
+  else if (W == 8) hipLaunchKernelGGL((resblock_fwd_small_kernel<3, 4>), dim3(B), dim3(256), 0, s, p);
+  else if (W == 4) hipLaunchKernelGGL((resblock_fwd_small_kernel<2, 4>), dim3(B), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((resblock_fwd_small_kernel<1, 4>), dim3(B), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
 
@@ -560,9 +581,12 @@ extern "C" int pwr_resblock_bwd_small(const void* gout, const void* x, const voi
   p.sums_a = sums_a; p.sums_b = sums_b; p.sums_c = sums_c; p.bias_sums = bias_sums;
   p.B = B;
   hipStream_t s = (hipStream_t)stream;
-  if (W == 16) hipLaunchKernelGGL((resblock_bwd_small_kernel<4>), dim3(B), dim3(256), 0, s, p);
-  else if (W == 8) hipLaunchKernelGGL((resblock_bwd_small_kernel<3>), dim3(B), dim3(256), 0, s, p);
-  else if (W == 4) hipLaunchKernelGGL((resblock_bwd_small_kernel<2>), dim3(B), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((resblock_bwd_small_kernel<1>), dim3(B), dim3(256), 0, s, p);
+  static const int wide = [] { const char* e = getenv("PWR_RESBLOCK_WAVES"); return e ? atoi(e) : 1; }();   // 0: four waves everywhere (round 1)
+  if (W == 16 && wide) hipLaunchKernelGGL((resblock_bwd_small_kernel<4, 8>), dim3(B), dim3(512), 0, s, p);
+  else if (W == 16) hipLaunchKernelGGL((resblock_bwd_small_kernel<4, 4>), dim3(B), dim3(256), 0, s, p);
+  else if (W == 8 && wide) hipLaunchKernelGGL((resblock_bwd_small_kernel<3, 8>), dim3(B), dim3(512), 0, s, p);
+  else if (W == 8) hipLaunchKernelGGL((resblock_bwd_small_kernel<3, 4>), dim3(B), dim3(256), 0, s, p);
+  else if (W == 4) hipLaunchKernelGGL((resblock_bwd_small_kernel<2, 4>), dim3(B), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((resblock_bwd_small_kernel<1, 4>), dim3(B), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
