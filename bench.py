@@ -74,20 +74,29 @@ def time_head_conv(dev, B, iters=20, precision="bf16"):
     return t, flops
 
 
-def time_decoder(dev, B, iters=20):
-    from pixelwiseregression_amd import ops
+def time_decoder(dev, B, iters=50):
+    """The decoder forward at the workload's shape, launched back to back through the C ABI on preallocated buffers (going through
+    ops.decode_forward -- two torch.empty per call -- made the measurement host-bound: 11.8 us per call for a 7.6 us kernel)."""
+    from pixelwiseregression_amd import _lib
+    l = _lib.lib()
     z = torch.randn(B, J, P, P, device=dev)
     D = torch.randn(B, J, P, P, device=dev)
     m = (torch.rand(B, 1, P, P, device=dev) < 0.4).float()
     L = torch.randn(B, 1, P, P, device=dev) * m
-    w = torch.ones(J, 1, device=dev)
+    w = torch.ones(J, device=dev)
+    p_out, uvd = torch.empty_like(z), torch.empty(B, J, 3, device=dev)
+    s = _lib.stream_ptr(dev)
+
+    def launch():
+        _lib.check(l.pwr_decode_fwd(z.data_ptr(), D.data_ptr(), L.data_ptr(), m.data_ptr(), w.data_ptr(), p_out.data_ptr(), uvd.data_ptr(),
+                                    B, J, P, 0, s), "pwr_decode_fwd")
     for _ in range(3):
-        ops.decode_forward(z, D, L, m, w, "softmax")
+        launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.decode_forward(z, D, L, m, w, "softmax")
+        launch()
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / iters * 1e-3
@@ -208,6 +217,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the two roofline probes (dominant conv, decoder) and print their JSON: the command profiles/ holds a "
+                         "rocprofv3 --kernel-trace --stats summary of, so that the live HIP-event time can be checked against rocprofv3's average")
     ap.add_argument("--accuracy-steps", type=int, default=300,
                     help="training steps of the accuracy block (mm error, bf16 and fp32 engines; rank 0 at N=1 only); 0 = skip")
     ap.add_argument("--harness", default="native", choices=["native", "torch"],
@@ -220,6 +232,17 @@ def main():
                     help="debug: all ranks share cuda:0 (with --dist-backend gloo) to exercise the data-parallel path on a 1-GPU box")
     args = ap.parse_args()
 
+    if args.roofline_only:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        t, flops = time_head_conv(dev, B_PER_GPU, precision=args.precision)
+        td, nb = time_decoder(dev, B_PER_GPU)
+        print(json.dumps({"roofline": {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak,
+                                       "us_per_launch": t * 1e6, "launches": 23},
+                          "roofline_decoder": {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                               "frac": nb / td / 1e9 / PEAK_HBM_GBS, "us_per_launch": td * 1e6, "launches": 53}}), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -336,8 +359,14 @@ def main():
                                "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": t * 1e6,
                                "flop_per_launch": flops}
             td, nb = time_decoder(dev, B_PER_GPU)
+            dtraffic = None
+            fp = os.path.join(ROOT, "profiles", "r2_traffic.json")
+            if os.path.exists(fp):
+                dtraffic = json.load(open(fp)).get("decode_fwd B=%d J=%d P=%d" % (B_PER_GPU, J, P), {}).get("hbm_bytes_corrected")
             out["roofline_decoder"] = {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": td * 1e6}
+                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": dtraffic, "traffic_source": "profiles/r2_traffic.json",
+                                       "us_per_launch": td * 1e6,
+                                       "note": "23 MB per launch: launch / latency bound at this shape; HBM bound at the C5 shape (profiles/r2_dec_bench.jsonl: 4.3 / 4.7 TB/s)"}
         if world == 1 and not use_dist and args.accuracy_steps > 0:
             out["accuracy"] = accuracy_block(args.accuracy_steps, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -5,6 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r2p; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python3 $R/bench.py --steps 25 --warmup 5 --no-cpu-baseline --accuracy-steps 0 > $O/step_bench.json 2> $O/step.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/roof -o roof -- python3 $R/bench.py --roofline-only > $O/roofline_only.json 2> $O/roof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso -o iso -- python3 $R/tools/bench_kernels.py all 20 > $O/iso_bench.jsonl 2> $O/iso.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec -o dec -- python3 $R/tools/bench_decoder.py > $O/dec_bench.jsonl 2> $O/dec.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/bench_kernels.py all 3 > /dev/null 2> $O/pmc_fetch.err
