@@ -88,6 +88,10 @@ def wellcond_report():
         for e, r, k in rows[:10]:
             print("   %.2e  %.2e  %s" % (e, r, k))
         print("   median engine %.2e, median reference %.2e" % (np.median([r[0] for r in rows]), np.median([r[1] for r in rows])))
+        if os.environ.get("GRAD_REPORT_ALL"):
+            byname = {k: (e, r) for e, r, k in rows}
+            for k, _ in m.named_parameters():
+                print("      %-70s %.2e  %.2e" % (k, byname[k][0], byname[k][1]))
 
 
 if __name__ == "__main__":
