@@ -207,6 +207,39 @@ int pwr_resblock_param_grads(const float* sums_a, const float* sums_b, const flo
                              int B, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The inner hourglass (model.py:25-47: the recursion below the 32x32 level, maps of 16x16 down to 2x2) as ONE launch per
+ * direction.  A workgroup owns a sample and runs a program of `nsteps` steps in order: PWR_SUBHG_BLOCK = the ResBlock
+ * blocks[step.block] (arguments as for pwr_resblock_fwd_small / pwr_resblock_bwd_small) on a map of width 2^logw;
+ * PWR_SUBHG_POOL = MaxPool2d(2,2) (forward: s0 [B,W,W,C] -> d [B,W/2,W/2,C], logw = log2 W; backward: d = dx [B,W,W,C] from
+ * s0 = x, s1 = dh [B,W/2,W/2,C], s2 = addend or NULL -- pwr_maxpool_bwd); PWR_SUBHG_UP = nearest up-sample by two + skip add
+ * (forward: d [B,W,W,C] = s1 (skip) + up(s0 [B,W/2,W/2,C]); backward: d = dh [B,W/2,W/2,C] from s0 = dout [B,W,W,C]; logw =
+ * log2 of the larger map).  Every tensor the per-block launches write is written, with the same values (bit-identical): the
+ * call replaces the launches, nothing else.  bf16, InstanceNorm, C == 128, maps of 2..16 pixels a side.
+ * ------------------------------------------------------------------------------------------- */
+#define PWR_SUBHG_MAX_BLOCKS 8
+#define PWR_SUBHG_MAX_STEPS 16
+enum { PWR_SUBHG_BLOCK = 0, PWR_SUBHG_POOL = 1, PWR_SUBHG_UP = 2 };
+typedef struct {
+  const void* x; void* t1; void* t2; void* out;
+  const void* wa; const void* wb; const void* wc;
+  const float* bias_a; const float* bias_b; const float* bias_c;
+  const float* gamma_a; const float* beta_a; const float* gamma_b; const float* beta_b; const float* gamma_c; const float* beta_c;
+  float* state_a; float* state_b; float* state_c;
+} pwr_resblock_fwd_args;
+typedef struct {
+  const void* gout; const void* x; const void* t1; const void* t2;
+  void* dx; void* dt1; void* dt2;
+  const void* wc_d; const void* wb_d; const void* wa_d;
+  const float* state_a; const float* state_b; const float* state_c;
+  float* sums_a; float* sums_b; float* sums_c; float* bias_sums;
+} pwr_resblock_bwd_args;
+typedef struct { int kind; int logw; int block; int reserved; const void* s0; const void* s1; const void* s2; void* d; } pwr_subhg_step;
+int pwr_subhourglass_fwd(const pwr_resblock_fwd_args* blocks, int nblocks, const pwr_subhg_step* steps, int nsteps, int B, int C,
+                         float eps, int dtype, void* stream);
+int pwr_subhourglass_bwd(const pwr_resblock_bwd_args* blocks, int nblocks, const pwr_subhg_step* steps, int nsteps, int B, int C,
+                         int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Hourglass plumbing (model.py:40, :45-47), NHWC.
  * ------------------------------------------------------------------------------------------- */
 int pwr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);

@@ -51,7 +51,7 @@ def build(force=False, verbose=True, extra_flags=(), lib=None, obj=None):
         finally:
             FLAGS, LIB, OBJ = saved
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "pwr.h"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs = []
