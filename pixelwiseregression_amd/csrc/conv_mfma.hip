@@ -625,8 +625,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
 // is incremental (no divisions in the loop).  192 accumulator registers per wave -> one workgroup per CU; global
 // loads are prefetched two tiles ahead in registers.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int MR, int NR>
+// DBG (only instantiated with -DPWR_WGRAD3_DBG_BUILD, tools/build_wgrad3_dbg.py): timing by elimination, results are WRONG --
+// 1 no MFMAs, 2 no fragment reads, 4 no norm / ReLU math in the staging, 16 no staging stores, 32 no global loads in the loop
+template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
+  static_assert(DEPTH >= 2 && DEPTH % 2 == 0, "register stages: even, so that the LDS buffer parity follows the step parity");
   typedef bf16_t T;
   typedef bf16x8 V;
   constexpr int KP = 32, EP = 8, AP = KP + 2;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
     b_lds[i] = (c < KP * BCH ? pix : 0) * PB + cq * 16;
   }
   struct Stage { V a[NA]; V b[NBL]; unsigned okmask; int bidx; bool rowok; };
-  Stage sg[2];
+  Stage sg[DEPTH];   // tiles st+1 .. st+DEPTH-1 in registers (global latency budget: DEPTH-1 steps), tile st in LDS
   auto load_global = [&](Stage& S) {
     const int iy = ty + ky - 1;
     S.rowok = iy >= 0 && iy < p.H;
@@ -735,11 +738,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
   auto store_lds = [&](Stage& S, int buf) {
     char* lA = smem + buf * (TILE_A + TILE_B);
     char* lB = lA + TILE_A;
+    if (DBG & 16) return;
     load_state(S.bidx);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       V v = S.a[i];
-      if (p.in_norm) {
+      if (p.in_norm && !(DBG & 4)) {
         V o;
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
@@ -771,10 +775,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
         for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
 
   // one pipeline step with a compile-time stage index (runtime-indexed register arrays would go to scratch)
-  auto body = [&](auto BUF, int st) {
-    constexpr int buf = decltype(BUF)::value;
-    const bool rowok_cur = sg[buf].rowok;
-    load_global(sg[buf]);                            // sg[buf] was already stored to LDS: refill with tile st+2 (or the last one again)
+  auto body = [&](auto KK, int st) {
+    constexpr int kk = decltype(KK)::value, buf = kk & 1;
+    const bool rowok_cur = sg[kk].rowok;
+    if (!(DBG & 32)) load_global(sg[kk]);            // sg[kk] was already stored to LDS: refill with tile st+DEPTH (or the last one again)
     if (rowok_cur) {
       const char* lA = smem + buf * (TILE_A + TILE_B);
       const char* lB = lA + TILE_A;
@@ -784,11 +788,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) bf[ss][j] = frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
+        for (int j = 0; j < NR; ++j) bf[ss][j] = (DBG & 2) ? V{(bf16_t)(float)lane} : frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int i = 0; i < MR; ++i) af[ss][t][i] = frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane);
+          for (int i = 0; i < MR; ++i) af[ss][t][i] = (DBG & 2) ? V{(bf16_t)(float)(lane + t)} : frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane);
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss)
@@ -797,20 +801,26 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
 #pragma unroll
           for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < NR; ++j)
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ss][t][i], bf[ss][j], acc[t][i][j], 0, 0, 0);
+            for (int j = 0; j < NR; ++j) {
+              if (DBG & 1) asm volatile("" ::"v"(af[ss][t][i]), "v"(bf[ss][j]));
+              else acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ss][t][i], bf[ss][j], acc[t][i][j], 0, 0, 0);
+            }
     }
-    store_lds(sg[buf ^ 1], buf ^ 1);                 // (after the last step: a tile nobody reads)
+    store_lds(sg[(kk + 1) % DEPTH], buf ^ 1);        // (after the last step: a tile nobody reads)
     __syncthreads();
   };
   if (nsteps > 0) {
-    load_global(sg[0]);
-    load_global(sg[1]);
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) load_global(sg[k]);
     store_lds(sg[0], 0);
     __syncthreads();
-    for (int st = 0; st < nsteps; st += 2) {
+    for (int st = 0; st < nsteps; st += DEPTH) {
       body(std::integral_constant<int, 0>{}, st);
       if (st + 1 < nsteps) body(std::integral_constant<int, 1>{}, st + 1);
+      if constexpr (DEPTH == 4) {
+        if (st + 2 < nsteps) body(std::integral_constant<int, 2>{}, st + 2);
+        if (st + 3 < nsteps) body(std::integral_constant<int, 3>{}, st + 3);
+      }
     }
   }
   const int r = lane & 31, h = lane >> 5;
@@ -922,6 +932,67 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction with ALL of a thread's slab loads of a round in flight before the first add: one block per (32 co, 1 ci) row,
+// thread = (float4 of co, slab group g of 32), slabs k = g, g + 32, ... ascending (the summation order of wgrad_reduce_kernel: the
+// results are bit-identical), SL slabs x TAPS items loaded back to back.  wgrad_reduce_kernel issued one slab's items, waited,
+// added, and went round again: 2.5 dependent rounds of DRAM latency on 256 blocks = 25 us for the 47 MB of a 128 -> 128 3x3 layer
+// (1.9 TB/s), more than a third of the weight gradient's own time.
+template <int TAPS, int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout,
+                                                                int CinPad, int CoutPad, int cin_real, int accumulate) {
+  __shared__ float tile[4 * 32 * (TAPS + 1)];
+  constexpr int pitch = TAPS + 1;
+  const int co0 = blockIdx.x * 32, ci = blockIdx.y;
+  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3, wave = threadIdx.x >> 6;
+  const int co = co0 + c4 * 4;
+  f32x4 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)TAPS * CinPad * CoutPad, tstride = (size_t)CinPad * CoutPad;
+  const float* base = slab + (size_t)ci * CoutPad + co;
+  for (int k0 = grp; k0 < S; k0 += 32 * SL) {
+    f32x4 v[SL][TAPS];
+#pragma unroll
+    for (int u = 0; u < SL; ++u) {
+      const int k = k0 + 32 * u;
+      const float* q = base + (size_t)(k < S ? k : grp) * stride;     // (unconditional loads; the add below is predicated)
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) v[u][t] = *reinterpret_cast<const f32x4*>(q + t * tstride);
+    }
+#pragma unroll
+    for (int u = 0; u < SL; ++u) {
+      if (k0 + 32 * u < S) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[t] += v[u][t];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      acc[t].x += __shfl_xor(acc[t].x, o, 64); acc[t].y += __shfl_xor(acc[t].y, o, 64);
+      acc[t].z += __shfl_xor(acc[t].z, o, 64); acc[t].w += __shfl_xor(acc[t].w, o, 64);
+    }
+    if ((threadIdx.x & 63) < 8) {
+      float* q = tile + (wave * 32 + c4 * 4) * pitch + t;
+      q[0] = acc[t].x; q[pitch] = acc[t].y; q[2 * pitch] = acc[t].z; q[3 * pitch] = acc[t].w;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * TAPS; i += 256) {
+    const int col2 = i / TAPS, rem = i - col2 * TAPS;
+    const int co2 = co0 + col2;
+    if (co2 < Cout) {
+      float r = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) r += tile[(g * 32 + col2) * pitch + rem];
+      const size_t o = ((size_t)co2 * cin_real + ci) * TAPS + rem;
+      dw[o] = accumulate ? dw[o] + r : r;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight packing: OIHW fp32 -> [tap][kch][RowsPad][KE] T
 //   kind 0 (forward): rows = cout, k = cin            value = W[row][k][ky][kx]
@@ -993,7 +1064,23 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       static const bool bm64 = [] { const char* e = getenv("PWR_WGRAD3_BM64"); return e ? atoi(e) != 0 : true; }();
       if (bn == 128 && bm64) {
         dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
-        hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2>), g64, block, 0, s, p);
+        static const int depth = [] { const char* e = getenv("PWR_WGRAD3_DEPTH"); return e ? atoi(e) : 2; }();
+#ifdef PWR_WGRAD3_DBG_BUILD
+        static const int dbg = [] { const char* e = getenv("PWR_WGRAD3_DBG"); return e ? atoi(e) : 0; }();
+        switch (dbg) {
+          case 1: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 1>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 2: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 2>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 3: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 3>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 4: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 4>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 16: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 16>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 19: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 19>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 48: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 48>), g64, block, 0, s, p); return (int)hipGetLastError();
+          case 51: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 51>), g64, block, 0, s, p); return (int)hipGetLastError();
+          default: break;
+        }
+#endif
+        if (depth == 4) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 4>), g64, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2>), g64, block, 0, s, p);
         return (int)hipGetLastError();
       }
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 2>), g3, block, 0, s, p);
@@ -1123,6 +1210,15 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   if (rc) return rc;
   if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin || ksize * ksize * PWR_RED_CI > PWR_RED_MAXITEMS) return PWR_EINVAL;
   const int taps = ksize * ksize;
+  const bool fast = [] { const char* e = getenv("PWR_WGRAD_REDUCE_FAST"); return e ? atoi(e) != 0 : true; }();   // (per call: the A/B test toggles it)
+  if (fast) {
+    const dim3 g((cout_real + 31) / 32, cin_real);
+    if (taps == 9)
+      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+    else
+      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + PWR_RED_CI - 1) / PWR_RED_CI), dim3(256),
                      (size_t)4 * 32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
                      accumulate);

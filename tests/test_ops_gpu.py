@@ -178,6 +178,24 @@ def test_conv_wgrad(case, dtype, prologue):
     assert_close(dw.double().cpu(), w.grad, tol(dtype), "wgrad %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 3, 80), (2, 64, 64, 128, 128, 3, 100), (4, 32, 32, 64, 64, 3, 40),
+                                  (8, 64, 64, 128, 64, 1, 512), (2, 16, 16, 64, 128, 1, 20), (2, 16, 16, 128, 16, 3, 7)])
+def test_wgrad_reduce_fast_is_bit_identical(case, monkeypatch):
+    """The split-K reduction with all of a round's slab loads in flight (wgrad_reduce_fast_kernel, the default) sums in the
+    order of the original wgrad_reduce_kernel (PWR_WGRAD_REDUCE_FAST=0): same bits, also with accumulate."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, k, splits = case
+    x, dy = nhwc(rnd(B, Cin, H, W, seed=1), torch.bfloat16), nhwc(rnd(B, Cout, H, W, seed=7), torch.bfloat16)
+    got = {}
+    for fast in ("0", "1"):
+        monkeypatch.setenv("PWR_WGRAD_REDUCE_FAST", fast)
+        dw = K.conv_wgrad(x, dy, Cout, k, 1, splits=splits)
+        got[fast] = (dw.clone(), K.conv_wgrad(x, dy, Cout, k, 1, splits=splits, dw=dw.clone()).clone())
+    assert float(got["0"][0].abs().max()) > 0
+    assert torch.equal(got["0"][0], got["1"][0]) and torch.equal(got["0"][1], got["1"][1])
+    assert torch.equal(got["1"][1], got["1"][0] + got["1"][0])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_wgrad_padded_dy(dtype):
     """head's last conv: dy arrives as [B,P,P,Jp] with Jp > J zero-padded channels"""
