@@ -85,7 +85,7 @@ int pwr_pack_weights(const float* flat_params, void* packs, const void* descs_de
 /* y = conv(NR(x)) + bias (+ residual).  NR(x) = (x - mean[b,c]) * scale[b,c] + beta[b,c], then ReLU if relu_in;
  * skipped when in_norm == NULL: the InstanceNorm/BatchNorm + ReLU that precedes the conv in model.py, fused
  * into the operand load.  in_norm is the [4][B][Cin] state written by pwr_norm_stats.  x: [B,H,W,Cin]; y: [B,Ho,Wo,Cout] (NULL to skip); y_nchw: fp32 [B,Cout,Ho,Wo] (NULL to
- * skip; used by the heads' last conv, model.py:64/:113).  ksize in {1,3}, pad = ksize/2, stride in {1,2}.
+ * skip; used by the heads' last conv, model.py:64/:113).  ksize in {1,3,5,7} (the scripts' --filter_size, train.py:47), pad = ksize/2, stride in {1,2}.
  * mode 0: convolution.  mode 1: data-gradient of a stride-2 conv: x is dy [B,H,W,Cin], y is [B,2H,2W,Cout],
  * wpack of kind 2.  The data-gradient of a stride-1 conv is mode 0 with a kind-1 pack. */
 int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,

@@ -132,11 +132,11 @@ def _run_model(ref_model, cfg, sd, batch, alpha, train=True, double=False):
 def gen_tiny(ref_model):
     from weights_util import fill_state_dict
     from pixelwiseregression_amd.synthetic import make_batch
-    for norm in ("instance", "batch"):
-        for method in ("softmax", "sum"):
-            if norm == "batch" and method == "sum":
-                continue
-            cfg = dict(joints=4, stage=2, label_size=16, features=32, level=2, kernel_size=3,
+    # kernel_size 5 / 7: the scripts' --filter_size (train.py:47 -> model.py:55-64, :165-182; the hourglass keeps 3x3, model.py:139)
+    for norm, method, ks in (("instance", "softmax", 3), ("instance", "sum", 3), ("batch", "softmax", 3),
+                             ("instance", "softmax", 5), ("batch", "softmax", 7)):
+        if True:
+            cfg = dict(joints=4, stage=2, label_size=16, features=32, level=2, kernel_size=ks,
                        norm_method=norm, heatmap_method=method)
             torch.manual_seed(0)
             proto = ref_model.PixelwiseRegression(cfg["joints"], **{k: v for k, v in cfg.items() if k != "joints"})
@@ -162,8 +162,8 @@ def gen_tiny(ref_model):
                 with torch.no_grad():
                     out, _, _ = _run_model(ref_model, cfg, sd, batch, None, train=False)
                 rec.update({"eval_" + k: v for k, v in out.items()})
-            np.savez_compressed(os.path.join(OUT, "tiny_%s_%s.npz" % (norm, method)), **rec)
-            print("tiny", norm, method, "keys", len(rec))
+            np.savez_compressed(os.path.join(OUT, "tiny_%s_%s%s.npz" % (norm, method, "" if ks == 3 else "_k%d" % ks)), **rec)
+            print("tiny", norm, method, ks, "keys", len(rec))
 
 
 def gen_c1(ref_model):
@@ -401,12 +401,12 @@ def gen_checkpoint(ref_model, ref_utils):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:     # (add named fixtures without regenerating the others): targets | wellcond | checkpoint
+    if len(sys.argv) > 1:     # (add named fixtures without regenerating the others): targets | wellcond | checkpoint | preprocess | tiny
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(8)
         ref_model, ref_utils, ref_datasets = import_reference()
         for what in sys.argv[1:]:
-            {"targets": lambda: gen_targets(ref_utils), "wellcond": lambda: gen_wellcond(ref_model),
+            {"targets": lambda: gen_targets(ref_utils), "wellcond": lambda: gen_wellcond(ref_model), "tiny": lambda: gen_tiny(ref_model),
              "checkpoint": lambda: gen_checkpoint(ref_model, ref_utils),
              "preprocess": lambda: gen_preprocess(ref_utils, ref_datasets)}[what]()
         sys.exit(0)

@@ -53,37 +53,39 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // block's pixel range (coalesced 16-byte loads, coordinates stepped incrementally: no divisions in the loop); the 3x3 (k x k)
 // image neighbourhood is loaded once per pixel and shared by the slot's channels.  Pixel lanes are combined with wave shuffles,
 // the four waves through LDS, in a fixed order.
-template <typename T, int KS>
+// KR kernel rows per pass (blockIdx.y = pass): 7x7 keeps 3 rows = 21 taps x 8 channels of accumulators in registers, not 49 x 8.
+template <typename T, int KS, int KR>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy,
                                                          float* __restrict__ slab, int B, int S, int C0,
                                                          int pix_per_block) {
-  constexpr int TT = KS * KS, pad = KS / 2, EP = Elem<T>::kPer16B;
+  constexpr int TT = KS * KS, TP = KR * KS, pad = KS / 2, EP = Elem<T>::kPer16B;
   typedef typename Vec16<T>::type V;
-  extern __shared__ float red[];           // [4 waves][C0][TT]
+  extern __shared__ float red[];           // [4 waves][C0][TP]
+  const int ky0 = blockIdx.y * KR;
   const int NSL = C0 / EP, PLN = 256 / NSL;          // channel slots, pixel lanes (C0 / EP divides 64)
   const int slot = threadIdx.x % NSL, pl = threadIdx.x / NSL;
   const long long npix = (long long)B * S * S;
   const long long p0 = (long long)blockIdx.x * pix_per_block;
   long long pend = p0 + pix_per_block;
   if (pend > npix) pend = npix;
-  float acc[EP][TT];
+  float acc[EP][TP];
 #pragma unroll
   for (int e = 0; e < EP; ++e)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) acc[e][t] = 0.f;
+    for (int t = 0; t < TP; ++t) acc[e][t] = 0.f;
   long long pp = p0 + pl;
   int x = (int)(pp % S), y = (int)((pp / S) % S), b = (int)(pp / ((long long)S * S));
 #pragma unroll 2
   for (; pp < pend; pp += PLN) {
     const V g = *reinterpret_cast<const V*>(dy + (size_t)pp * C0 + slot * EP);
-    float v[TT];
+    float v[TP];
     const float* ib = img + (size_t)b * S * S;
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
+    for (int ky = 0; ky < KR; ++ky)
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
-        const int iy = y + ky - pad, ix = x + kx - pad;
-        const bool ok = iy >= 0 && iy < S && ix >= 0 && ix < S;
+        const int iy = y + ky0 + ky - pad, ix = x + kx - pad;
+        const bool ok = ky0 + ky < KS && iy >= 0 && iy < S && ix >= 0 && ix < S;
         const float t = ib[ok ? iy * S + ix : 0];
         v[ky * KS + kx] = ok ? t : 0.f;
       }
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     for (int e = 0; e < EP; ++e) {
       const float ge = Elem<T>::to_f(g[e]);
 #pragma unroll
-      for (int t = 0; t < TT; ++t) acc[e][t] = fmaf(ge, v[t], acc[e][t]);
+      for (int t = 0; t < TP; ++t) acc[e][t] = fmaf(ge, v[t], acc[e][t]);
     }
     x += PLN;
     while (x >= S) { x -= S; if (++y == S) { y = 0; ++b; } }
@@ -100,14 +102,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
   for (int e = 0; e < EP; ++e)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < TP; ++t) {
       float a = acc[e][t];
       for (int o = NSL; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-      if (lane < NSL) red[(wid * C0 + slot * EP + e) * TT + t] = a;
+      if (lane < NSL) red[(wid * C0 + slot * EP + e) * TP + t] = a;
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < C0 * TT; i += 256)
-    slab[(size_t)blockIdx.x * C0 * TT + i] = (red[i] + red[C0 * TT + i]) + (red[2 * C0 * TT + i] + red[3 * C0 * TT + i]);
+  const int ntp = (KS - ky0 < KR ? KS - ky0 : KR) * KS;      // taps of this pass
+  for (int i = threadIdx.x; i < C0 * TP; i += 256) {
+    const int c = i / TP, tp = i - c * TP;
+    if (tp < ntp)
+      slab[(size_t)blockIdx.x * C0 * TT + c * TT + ky0 * KS + tp] = (red[i] + red[C0 * TP + i]) + (red[2 * C0 * TP + i] + red[3 * C0 * TP + i]);
+  }
 }
 
 // out[i] (+)= sum_s slab[s*n + i]
@@ -290,7 +296,7 @@ extern "C" int pwr_stem_conv_fwd(const float* img, const float* w, const float* 
 #define PWR_STEM_F(KS_) \
   if (dtype == PWR_BF16) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, KS_>), dim3(grid), dim3(256), sh, (hipStream_t)stream, img, w, bias, (bf16_t*)y, B, S, C0); \
   else hipLaunchKernelGGL((stem_fwd_kernel<float, KS_>), dim3(grid), dim3(256), sh, (hipStream_t)stream, img, w, bias, (float*)y, B, S, C0)
-  if (ksize == 1) { PWR_STEM_F(1); } else if (ksize == 3) { PWR_STEM_F(3); } else if (ksize == 5) { PWR_STEM_F(5); } else return PWR_EUNSUPPORTED;
+  if (ksize == 1) { PWR_STEM_F(1); } else if (ksize == 3) { PWR_STEM_F(3); } else if (ksize == 5) { PWR_STEM_F(5); } else if (ksize == 7) { PWR_STEM_F(7); } else return PWR_EUNSUPPORTED;
   return (int)hipGetLastError();
 }
 
@@ -304,15 +310,17 @@ extern "C" int pwr_stem_conv_wgrad(const float* img, const void* dy, float* slab
                                    int C0, int ksize, int dtype, void* stream) {
   const int EPh = dtype == PWR_BF16 ? 8 : 4;
   if (C0 % EPh || 64 % (C0 / EPh)) return PWR_EUNSUPPORTED;
-  const size_t shw = (size_t)4 * C0 * ksize * ksize * sizeof(float);
+  const int kr = ksize == 7 ? 3 : ksize, passes = (ksize + kr - 1) / kr;
+  const size_t shw = (size_t)4 * C0 * kr * ksize * sizeof(float);
   const int nb = pwr_stem_conv_wgrad_blocks(B, S);
   const long long npix = (long long)B * S * S;
   const int ppb = (int)((npix + nb - 1) / nb);
   hipStream_t s = (hipStream_t)stream;
-#define PWR_STEM_W(KS_) \
-  if (dtype == PWR_BF16) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, KS_>), dim3(nb), dim3(256), shw, s, img, (const bf16_t*)dy, slab, B, S, C0, ppb); \
-  else hipLaunchKernelGGL((stem_wgrad_kernel<float, KS_>), dim3(nb), dim3(256), shw, s, img, (const float*)dy, slab, B, S, C0, ppb)
-  if (ksize == 1) { PWR_STEM_W(1); } else if (ksize == 3) { PWR_STEM_W(3); } else if (ksize == 5) { PWR_STEM_W(5); } else return PWR_EUNSUPPORTED;
+#define PWR_STEM_W(KS_, KR_) \
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, KS_, KR_>), dim3(nb, passes), dim3(256), shw, s, img, (const bf16_t*)dy, slab, B, S, C0, ppb); \
+  else hipLaunchKernelGGL((stem_wgrad_kernel<float, KS_, KR_>), dim3(nb, passes), dim3(256), shw, s, img, (const float*)dy, slab, B, S, C0, ppb)
+  if (ksize == 1) { PWR_STEM_W(1, 1); } else if (ksize == 3) { PWR_STEM_W(3, 3); } else if (ksize == 5) { PWR_STEM_W(5, 5); }
+  else if (ksize == 7) { PWR_STEM_W(7, 3); } else return PWR_EUNSUPPORTED;
   const int n = C0 * ksize * ksize;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, slab, dw, nb, n, accumulate);
   return (int)hipGetLastError();

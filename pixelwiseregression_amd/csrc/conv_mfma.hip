@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   };
   const T* xrow[2];
   const float* strow[2];
-  unsigned vmask[2];
+  unsigned long long vmask[2];    // one bit per tap: k <= 7 -> 49 taps
   int aoff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -77,13 +77,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     int b, oy, ox;
     const bool mv = row_pixel(m, b, oy, ox);
     int by, bx;
-    unsigned mask = 0;
+    unsigned long long mask = 0;
     if (p.mode == 0) {
       by = oy * p.stride - p.pad; bx = ox * p.stride - p.pad;
       for (int ky = 0, t = 0; ky < p.ksize; ++ky)
         for (int kx = 0; kx < p.ksize; ++kx, ++t) {
           const int iy = by + ky, ix = bx + kx;
-          if (mv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+          if (mv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1ull << t;
         }
     } else {  // gather form of the stride-2 transposed conv: iy = (oy + pad - ky)/2 when even = by - (ky >> 1)
       by = (oy + p.pad) >> 1; bx = (ox + p.pad) >> 1;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
         for (int kx = 0; kx < p.ksize; ++kx, ++t) {
           const int sy = oy + p.pad - ky, sx = ox + p.pad - kx;
           const int iy = sy >> 1, ix = sx >> 1;
-          if (mv && !(sy & 1) && !(sx & 1) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+          if (mv && !(sy & 1) && !(sx & 1) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1ull << t;
         }
     }
     vmask[i] = mask;
@@ -108,13 +108,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     boff[i] = BM * 64 + lds_off(s >> 2, s & 3);
   }
   // taps that at least one row of this tile can reach (block-uniform): the K loop runs over those only
-  __shared__ unsigned s_tapmask;
+  __shared__ unsigned long long s_tapmask;
   if (tid == 0) s_tapmask = 0;
   __syncthreads();
   if (vmask[0] | vmask[1]) atomicOr(&s_tapmask, vmask[0] | vmask[1]);
   __syncthreads();
-  const unsigned tapmask = s_tapmask;
-  const int iters = __popc(tapmask) * p.KCH;
+  const unsigned long long tapmask = s_tapmask;
+  const int iters = __popcll(tapmask) * p.KCH;
+  const int kmul = (256 + p.ksize - 1) / p.ksize;       // tap / ksize == (tap * kmul) >> 8 for ksize in {1,3,5,7}, tap < ksize^2
   const size_t nplane = (size_t)p.B * p.Cin;
   const long long wstride = (long long)p.CoutPad * KE;      // elements between consecutive (tap, K chunk) weight tiles
 
@@ -123,11 +124,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   float nmu[2][EP], nsc[2][EP], nbe[2][EP];
 
   // (tap, K chunk) of the next tile to load, advanced incrementally: no integer divisions in the K loop
-  unsigned l_rem = tapmask;
+  unsigned long long l_rem = tapmask;
   int l_kch = 0;
   auto load_global = [&](int) {
-    const int tap = __ffs(l_rem) - 1, kch = l_kch;
-    const int l_ky = p.ksize == 3 ? (tap * 11) >> 5 : 0, l_kx = tap - l_ky * p.ksize;
+    const int tap = __ffsll((long long)l_rem) - 1, kch = l_kch;
+    const int l_ky = (tap * kmul) >> 8, l_kx = tap - l_ky * p.ksize;
     // wave-uniform element offset of this tap relative to tap (0,0)
     const long long tapoff = p.mode == 0 ? ((long long)l_ky * p.W + l_kx) * p.Cin : -((long long)(l_ky >> 1) * p.W + (l_kx >> 1)) * p.Cin;
     const long long koff = tapoff + kch * KE;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
     if (++l_kch == p.KCH) { l_kch = 0; l_rem &= l_rem - 1; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool ok = ((vmask[i] >> tap) & 1u) && kfull;
+      const bool ok = ((vmask[i] >> tap) & 1ull) && kfull;
       av[i] = ok;
       V v = {};
       if (ok) {
@@ -937,38 +938,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // results are bit-identical), SL slabs x TAPS items loaded back to back.  wgrad_reduce_kernel issued one slab's items, waited,
 // added, and went round again: 2.5 dependent rounds of DRAM latency on 256 blocks = 25 us for the 47 MB of a 128 -> 128 3x3 layer
 // (1.9 TB/s), more than a third of the weight gradient's own time.
-template <int TAPS, int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout,
+template <int TC, int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cout,
                                                                 int CinPad, int CoutPad, int cin_real, int accumulate) {
-  __shared__ float tile[4 * 32 * (TAPS + 1)];
-  constexpr int pitch = TAPS + 1;
-  const int co0 = blockIdx.x * 32, ci = blockIdx.y;
+  // blockIdx.z: chunk of TC taps (9 taps = one chunk; 25 / 49 taps of a 5x5 / 7x7 layer = 3 / 6 chunks)
+  __shared__ float tile[4 * 32 * (TC + 1)];
+  constexpr int pitch = TC + 1;
+  const int co0 = blockIdx.x * 32, ci = blockIdx.y, tap0 = blockIdx.z * TC;
+  const int nt = taps - tap0 < TC ? taps - tap0 : TC;
   const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3, wave = threadIdx.x >> 6;
   const int co = co0 + c4 * 4;
-  f32x4 acc[TAPS];
+  f32x4 acc[TC];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const size_t stride = (size_t)TAPS * CinPad * CoutPad, tstride = (size_t)CinPad * CoutPad;
-  const float* base = slab + (size_t)ci * CoutPad + co;
+  for (int t = 0; t < TC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)taps * CinPad * CoutPad, tstride = (size_t)CinPad * CoutPad;
+  const float* base = slab + (size_t)ci * CoutPad + co + tap0 * tstride;
   for (int k0 = grp; k0 < S; k0 += 32 * SL) {
-    f32x4 v[SL][TAPS];
+    f32x4 v[SL][TC];
 #pragma unroll
     for (int u = 0; u < SL; ++u) {
       const int k = k0 + 32 * u;
       const float* q = base + (size_t)(k < S ? k : grp) * stride;     // (unconditional loads; the add below is predicated)
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) v[u][t] = *reinterpret_cast<const f32x4*>(q + t * tstride);
+      for (int t = 0; t < TC; ++t) v[u][t] = *reinterpret_cast<const f32x4*>(q + (t < nt ? t : 0) * tstride);
     }
 #pragma unroll
     for (int u = 0; u < SL; ++u) {
       if (k0 + 32 * u < S) {
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) acc[t] += v[u][t];
+        for (int t = 0; t < TC; ++t) acc[t] += v[u][t];
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
+  for (int t = 0; t < TC; ++t) {
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
       acc[t].x += __shfl_xor(acc[t].x, o, 64); acc[t].y += __shfl_xor(acc[t].y, o, 64);
@@ -980,14 +983,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __r
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 32 * TAPS; i += 256) {
-    const int col2 = i / TAPS, rem = i - col2 * TAPS;
+  for (int i = threadIdx.x; i < 32 * TC; i += 256) {
+    const int col2 = i / TC, rem = i - col2 * TC;
     const int co2 = co0 + col2;
-    if (co2 < Cout) {
+    if (co2 < Cout && rem < nt) {
       float r = 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) r += tile[(g * 32 + col2) * pitch + rem];
-      const size_t o = ((size_t)co2 * cin_real + ci) * TAPS + rem;
+      const size_t o = ((size_t)co2 * cin_real + ci) * taps + tap0 + rem;
       dw[o] = accumulate ? dw[o] + r : r;
     }
   }
@@ -1124,7 +1127,7 @@ static int conv_params_fill(pwr::ConvParams& p, const void* x, const void* wpack
                             const void* residual, void* y, float* y_nchw, int B, int H, int W, int Cin, int Cout, int ksize,
                             int stride, int mode, int dtype) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
-  if (Cin % EP || (y && Cout % EP) || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return PWR_EUNSUPPORTED;
+  if (Cin % EP || (y && Cout % EP) || (ksize != 1 && ksize != 3 && ksize != 5 && ksize != 7) || (stride != 1 && stride != 2)) return PWR_EUNSUPPORTED;
   p.x = x; p.w = wpack; p.bias = bias; p.in_norm = in_norm; p.residual = residual;
   p.y = y; p.y_nchw = y_nchw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.ksize = ksize; p.pad = ksize / 2; p.mode = mode; p.relu_in = relu_in;
@@ -1195,7 +1198,7 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
                               float* slab, float* dw, int accumulate, int B, int H, int W, int Cin, int cin_real, int Cout,
                               int cout_real, int ksize, int stride, int splits, int dtype, void* stream) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
-  if (Cin % EP || Cout % EP || (ksize != 1 && ksize != 3) || splits < 1) return PWR_EUNSUPPORTED;
+  if (Cin % EP || Cout % EP || (ksize != 1 && ksize != 3 && ksize != 5 && ksize != 7) || splits < 1) return PWR_EUNSUPPORTED;
   pwr::WgradParams p;
   p.x = x; p.dy = dy; p.in_norm = in_norm; p.slab = slab;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ksize = ksize; p.stride = stride; p.pad = ksize / 2;
@@ -1208,15 +1211,15 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype == PWR_BF16 ? pwr::launch_wgrad<bf16_t>(p, s) : pwr::launch_wgrad<float>(p, s);
   if (rc) return rc;
-  if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin || ksize * ksize * PWR_RED_CI > PWR_RED_MAXITEMS) return PWR_EINVAL;
+  if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin) return PWR_EINVAL;
   const int taps = ksize * ksize;
   const bool fast = [] { const char* e = getenv("PWR_WGRAD_REDUCE_FAST"); return e ? atoi(e) != 0 : true; }();   // (per call: the A/B test toggles it)
-  if (fast) {
-    const dim3 g((cout_real + 31) / 32, cin_real);
-    if (taps == 9)
-      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+  if (fast || taps > 9) {
+    const dim3 g((cout_real + 31) / 32, cin_real, (taps + 8) / 9);
+    if (taps > 1)
+      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
     else
-      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + PWR_RED_CI - 1) / PWR_RED_CI), dim3(256),

@@ -9,7 +9,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["tiny_instance_softmax.npz", "tiny_instance_sum.npz", "tiny_batch_softmax.npz"])
+@pytest.mark.parametrize("name", ["tiny_instance_softmax.npz", "tiny_instance_sum.npz", "tiny_batch_softmax.npz",
+                                  "tiny_instance_softmax_k5.npz", "tiny_batch_softmax_k7.npz"])
 def test_aten_backend_tiny_golden(golden_dir, name):
     from pixelwiseregression_amd import PixelwiseRegression
     g = np.load(os.path.join(golden_dir, name))

@@ -86,6 +86,14 @@ CONV_CASES = [
     (5, 8, 8, 64, 64, 3, 1),
     (1, 16, 16, 64, 64, 3, 1),
     (3, 16, 16, 64, 40, 3, 1),
+    # --filter_size 5 / 7 of the reference's scripts (train.py:47 -> model.py:55-64, :165-182): 25 / 49 taps
+    (2, 16, 16, 32, 32, 5, 1),
+    (2, 32, 32, 128, 128, 5, 1),
+    (2, 16, 16, 32, 64, 7, 1),
+    (1, 64, 64, 128, 128, 7, 1),
+    (3, 5, 9, 64, 16, 7, 1),
+    (2, 32, 32, 128, 128, 5, 2),
+    (2, 20, 20, 64, 128, 7, 2),
 ]
 
 
@@ -127,7 +135,8 @@ def test_conv_forward_nchw_out(dtype, J, H, Cin):
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3), (2, 64, 64, 128, 128, 3), (3, 5, 7, 64, 128, 3),
                                   (2, 16, 16, 128, 64, 1), (1, 4, 4, 16, 16, 3), (2, 32, 32, 128, 16, 3),
                                   (3, 4, 4, 16, 16, 3), (3, 2, 2, 16, 16, 3), (3, 8, 8, 16, 16, 3), (3, 4, 4, 16, 32, 1),
-                                  (2, 64, 64, 128, 64, 1), (2, 32, 32, 64, 128, 1), (2, 32, 64, 128, 32, 1)])
+                                  (2, 64, 64, 128, 64, 1), (2, 32, 32, 64, 128, 1), (2, 32, 64, 128, 32, 1),
+                                  (2, 16, 16, 64, 64, 5), (2, 32, 32, 128, 128, 7), (3, 5, 7, 32, 16, 7), (1, 64, 64, 128, 16, 5)])
 def test_conv_dgrad_stride1(case, dtype):
     """data gradient = pwr_conv_fwd on dy with the kind-1 (flipped, transposed) weight pack."""
     from pixelwiseregression_amd import kernels as K
@@ -142,16 +151,16 @@ def test_conv_dgrad_stride1(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [3, 5, 7])
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 32, 64, 128), (1, 6, 16, 32), (3, 20, 128, 128), (2, 64, 128, 128)])
-def test_conv_dgrad_stride2(dtype, B, H, Cin, Cout):
+def test_conv_dgrad_stride2(dtype, B, H, Cin, Cout, k):
     """rows are processed in parity-class order (tiles of one class skip the taps it cannot reach); the small cases have
     tiles that straddle classes and samples."""
     from pixelwiseregression_amd import kernels as K
-    k = 3
     w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
     dy = rnd(B, Cout, H // 2, H // 2, seed=7)
     x = torch.zeros(B, Cin, H, H, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x, q(w, dtype), None, stride=2, padding=1).backward(q(dy, dtype))
+    F.conv2d(x, q(w, dtype), None, stride=2, padding=k // 2).backward(q(dy, dtype))
     pack = K.pack_conv(w.float().to(DEV), 2, K.BF16 if dtype == torch.bfloat16 else K.F32)
     dx, _ = K.conv_fwd(nhwc(dy, dtype), pack, Cin, k, 1, mode=1)
     assert_close(nchw(dx), x.grad, tol(dtype), "dgrad stride 2")
@@ -160,7 +169,8 @@ def test_conv_dgrad_stride2(dtype, B, H, Cin, Cout):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3, 1, 4), (2, 64, 64, 128, 128, 3, 1, 16), (3, 5, 7, 64, 64, 3, 1, 3),
                                   (2, 16, 16, 128, 64, 1, 1, 2), (2, 32, 32, 64, 128, 3, 2, 8), (1, 2, 2, 16, 16, 3, 1, 1),
-                                  (2, 8, 8, 256, 32, 3, 1, 2)])
+                                  (2, 8, 8, 256, 32, 3, 1, 2), (2, 16, 16, 32, 32, 5, 1, 4), (2, 32, 32, 128, 128, 7, 1, 9),
+                                  (3, 5, 7, 64, 16, 7, 1, 2), (2, 32, 32, 128, 128, 5, 2, 5), (2, 64, 64, 128, 16, 5, 1, 40)])
 @pytest.mark.parametrize("prologue", [False, True])
 def test_conv_wgrad(case, dtype, prologue):
     from pixelwiseregression_amd import kernels as K
@@ -220,17 +230,18 @@ def test_conv_wgrad_padded_dy(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("S", [32, 128])
-def test_stem_conv(dtype, S):
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_stem_conv(dtype, S, k):
     from pixelwiseregression_amd import kernels as K
     B, C0 = 3, 32
-    img, w, b = rnd(B, 1, S, S, seed=1), rnd(C0, 1, 3, 3, seed=2), rnd(C0, seed=3)
-    ref = F.conv2d(img.float().double(), w.float().double(), b.float().double(), padding=1)
+    img, w, b = rnd(B, 1, S, S, seed=1), rnd(C0, 1, k, k, seed=2), rnd(C0, seed=3)
+    ref = F.conv2d(img.float().double(), w.float().double(), b.float().double(), padding=k // 2)
     y = K.stem_conv_fwd(img.float().to(DEV), w.float().to(DEV), b.float().to(DEV), dtype)
     assert_close(nchw(y), ref, 1e-6 if dtype == torch.float32 else 5e-3, "stem fwd")
     dy = rnd(B, C0, S, S, seed=4)
-    wz = torch.zeros(C0, 1, 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv2d(img.float().double(), wz, None, padding=1).backward(q(dy, dtype))
-    dw = K.stem_conv_wgrad(img.float().to(DEV), nhwc(dy, dtype), 3)
+    wz = torch.zeros(C0, 1, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(img.float().double(), wz, None, padding=k // 2).backward(q(dy, dtype))
+    dw = K.stem_conv_wgrad(img.float().to(DEV), nhwc(dy, dtype), k)
     assert_close(dw.double().cpu(), wz.grad, 2e-5, "stem wgrad")
 
 

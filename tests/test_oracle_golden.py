@@ -56,7 +56,8 @@ def _tiny(golden_dir, name):
     return g, cfg, sd, batch
 
 
-@pytest.mark.parametrize("name", ["tiny_instance_softmax.npz", "tiny_instance_sum.npz", "tiny_batch_softmax.npz"])
+@pytest.mark.parametrize("name", ["tiny_instance_softmax.npz", "tiny_instance_sum.npz", "tiny_batch_softmax.npz",
+                                  "tiny_instance_softmax_k5.npz", "tiny_batch_softmax_k7.npz"])
 @pytest.mark.parametrize("alpha", [1.0, 0.5])
 def test_model_oracle_vs_reference(golden_dir, name, alpha):
     g, cfg, sd, batch = _tiny(golden_dir, name)
