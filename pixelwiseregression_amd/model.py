@@ -277,6 +277,17 @@ class PixelwiseRegression(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, img, label_img, mask):
+        # error behaviour of the reference's norm layers on a 1x1 innermost map (label_size / 2^(level+1), model.py:25-47):
+        # F.instance_norm refuses a single spatial element (in train AND eval: InstanceNorm2d keeps no running statistics),
+        # F.batch_norm refuses a single value per channel when training
+        inner = self.label_size >> (self.level + 1)
+        if inner * inner <= 1:
+            if self.norm_method == "instance":
+                raise ValueError("Expected more than 1 spatial element when training, got input size torch.Size([%d, %d, %d, %d])"
+                                 % (img.shape[0], self.features, inner, inner))
+            if self.training and img.shape[0] * inner * inner <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([%d, %d, %d, %d])"
+                                 % (img.shape[0], self.features, inner, inner))
         if not img.is_cuda:
             from ._lib import PwrError
             raise PwrError("PixelwiseRegression (MI355X build) runs on the GPU only; move the module and the "

@@ -237,3 +237,19 @@ def test_no_cross_half_packed_f32_in_shipped_code_objects():
     r = mod.scan(_lib.LIB_PATH)
     assert r["functions"] > 100 and r["instructions"] > 100000, r       # the scan really saw the library's kernels
     assert r["packed_f32_cross_half_op_sel"] == 0, r
+
+
+def test_one_pixel_innermost_map_fails_like_the_reference():
+    """label_size / 2^(level+1) == 1: the reference's InstanceNorm2d raises ValueError in F.instance_norm (train and eval), its
+    BatchNorm2d only when training on a single sample; same exceptions here, before anything touches the GPU."""
+    import pytest
+    from pixelwiseregression_amd import PixelwiseRegression
+    x = torch.zeros(2, 1, 64, 64), torch.zeros(2, 1, 32, 32), torch.ones(2, 1, 32, 32)
+    m = PixelwiseRegression(3, stage=1, label_size=32, features=32, level=4, norm_method="instance")
+    for mode in (m.train, m.eval):
+        mode()
+        with pytest.raises(ValueError, match="Expected more than 1 spatial element"):
+            m(*x)
+    mb = PixelwiseRegression(3, stage=1, label_size=32, features=32, level=4, norm_method="batch").train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        mb(*(t[:1] for t in x))
