@@ -74,6 +74,27 @@ def time_head_conv(dev, B, iters=20, precision="bf16"):
     return t, flops
 
 
+def vendor_gemm_yardstick(dev, B, iters=30):
+    """Calibration, not a product path: the vendor GEMM (hipBLASLt through torch.matmul, bf16) on this GPU at the dominant conv's
+    shape seen as an implicit GEMM -- M = B*64*64 pixels, N = 128 output channels, K = 9*128 -- i.e. what a tuned library kernel
+    reaches at N = 128 WITHOUT the im2col gather, the norm / ReLU prologue and the statistics epilogue the conv kernel carries."""
+    M, N, K = B * P * P, F_, 9 * F_
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(K, N, device=dev, dtype=torch.bfloat16)
+    for _ in range(5):
+        a @ b
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    return {"what": "torch.matmul bf16 [%d x %d] @ [%d x %d] (hipBLASLt), same FLOPs as the conv launch" % (M, K, K, N),
+            "us": t * 1e6, "TFLOP/s": 2.0 * M * N * K / t / 1e12, "frac": 2.0 * M * N * K / t / 1e12 / PEAK_BF16_TFLOPS}
+
+
 def time_decoder(dev, B, iters=50):
     """The decoder forward at the workload's shape, launched back to back through the C ABI on preallocated buffers (going through
     ops.decode_forward -- two torch.empty per call -- made the measurement host-bound: 11.8 us per call for a 7.6 us kernel)."""
@@ -358,6 +379,8 @@ def main():
                                "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                                "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": t * 1e6,
                                "flop_per_launch": flops}
+            if args.precision == "bf16":
+                out["roofline"]["vendor_gemm_same_shape"] = vendor_gemm_yardstick(dev, B_PER_GPU)
             td, nb = time_decoder(dev, B_PER_GPU)
             dtraffic = None
             fp = os.path.join(ROOT, "profiles", "r2_traffic.json")

@@ -578,8 +578,8 @@ struct Engine {
   // set, the fused ResBlocks, pools and up-samples being planned are recorded as steps instead of (bit 0: forward, bit 1:
   // backward of PWR_SUBHG) being pushed as launches of their own.  The backward program is the forward one reversed.
   // Default 0 = off, measured on one box: the forward kernel takes 177 us against 160 us for the eight block kernels + ~27 us for the
-  // six pool / up-sample launches it replaces (inference 2.015 vs 2.010 ms: the replayed hipGraph had already removed the launch
-  // gaps, and what is left is the chain of dependent global / LDS round trips INSIDE the blocks); the backward kernel delays the
+  // six pool / up-sample launches it replaces (inference 2.015 vs 2.010 ms: the host issues far ahead of the GPU, so the launches were
+  // already back to back on the stream, and what is left is the chain of dependent global / LDS round trips INSIDE the blocks); the backward kernel delays the
   // region's weight gradients until all of its data gradients are done (train step 7.17 vs 6.89 ms).
   struct SubStepH { int kind = 0, logw = 0, block = 0; Tn a, b, c; };   // POOL: a = input, b = pooled, c = the level's output (its
                                                                         // gradient is the skip addend); UP: a = h, b = skip, c = out
