@@ -288,6 +288,11 @@ class PixelwiseRegression(nn.Module):
             if self.training and img.shape[0] * inner * inner <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([%d, %d, %d, %d])"
                                  % (img.shape[0], self.features, inner, inner))
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (img, label_img, mask)):
+            # the reference's autograd would differentiate through to the inputs; the engine's backward stops at the parameters
+            # (the inputs are data: SURVEY section 8 a-D) -- refuse instead of silently returning no input gradient
+            raise NotImplementedError("PixelwiseRegression (MI355X build): gradients with respect to img / label_img / mask are not "
+                                      "computed; detach the inputs (they are data in every script of the reference)")
         if not img.is_cuda:
             from ._lib import PwrError
             raise PwrError("PixelwiseRegression (MI355X build) runs on the GPU only; move the module and the "

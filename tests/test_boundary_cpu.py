@@ -253,3 +253,13 @@ def test_one_pixel_innermost_map_fails_like_the_reference():
     mb = PixelwiseRegression(3, stage=1, label_size=32, features=32, level=4, norm_method="batch").train()
     with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
         mb(*(t[:1] for t in x))
+
+
+def test_input_gradients_are_refused_loudly():
+    """The engine's backward stops at the parameters; an input that requires grad must not silently get none."""
+    import pytest
+    from pixelwiseregression_amd import PixelwiseRegression
+    m = PixelwiseRegression(3, stage=1, label_size=16, features=32, level=1, norm_method="instance")
+    img = torch.zeros(1, 1, 32, 32, requires_grad=True)
+    with pytest.raises(NotImplementedError, match="gradients with respect to img"):
+        m(img, torch.zeros(1, 1, 16, 16), torch.ones(1, 1, 16, 16))
