@@ -1067,8 +1067,11 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       static const bool bm64 = [] { const char* e = getenv("PWR_WGRAD3_BM64"); return e ? atoi(e) != 0 : true; }();
       if (bn == 128 && bm64) {
         dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
-        static const int depth = [] { const char* e = getenv("PWR_WGRAD3_DEPTH"); return e ? atoi(e) : 2; }();
 #ifdef PWR_WGRAD3_DBG_BUILD
+        // (experiments, tools/build_wgrad3_dbg.py: register prefetch depth 4 -- measured 82.6 vs 81.7 us, not latency-bound -- and the
+        // timing-by-elimination variants)
+        static const int depth = [] { const char* e = getenv("PWR_WGRAD3_DEPTH"); return e ? atoi(e) : 2; }();
+        if (depth == 4) { hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 4>), g64, block, 0, s, p); return (int)hipGetLastError(); }
         static const int dbg = [] { const char* e = getenv("PWR_WGRAD3_DBG"); return e ? atoi(e) : 0; }();
         switch (dbg) {
           case 1: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 1>), g64, block, 0, s, p); return (int)hipGetLastError();
@@ -1082,8 +1085,7 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
           default: break;
         }
 #endif
-        if (depth == 4) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 4>), g64, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2>), g64, block, 0, s, p);
+        hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2>), g64, block, 0, s, p);
         return (int)hipGetLastError();
       }
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 2>), g3, block, 0, s, p);
