@@ -265,7 +265,19 @@ def gen_targets(ref_utils):
     rng = np.random.default_rng(11)
     uv = np.concatenate([rng.random((24, 2)) * (P - 2), np.array([[0.0, 0.0], [10.0, 20.5], [61.999, 3.25], [31.5, 31.5]])])
     heat = np.stack([ref_utils.generate_heatmap(P, float(u), float(v)) for u, v in uv])
-    np.savez_compressed(os.path.join(OUT, "targets.npz"), P=np.int64(P), uv=uv, splat=heat)
+    # round 3: positions left of / above the map (numpy wraps the negative indices, utils.py:54-57) and the ones that do raise
+    uv_edge = np.array([[-0.5, 10.3], [10.3, -0.5], [-0.25, -0.75], [-1.0, 5.0], [-17.3, 40.2], [-63.5, -63.5], [-64.0, 0.0],
+                        [-64.01, 3.0], [3.0, -65.0], [62.99, 62.99], [63.0, 3.0], [3.0, 63.0], [70.0, 3.0], [np.nan, 3.0]])
+    splat_edge, raises = [], []
+    for u, v in uv_edge:
+        try:
+            splat_edge.append(ref_utils.generate_heatmap(P, float(u), float(v)))
+            raises.append(False)
+        except Exception:
+            splat_edge.append(np.zeros((P, P)))
+            raises.append(True)
+    np.savez_compressed(os.path.join(OUT, "targets.npz"), P=np.int64(P), uv=uv, splat=heat, uv_edge=uv_edge, splat_edge=np.stack(splat_edge),
+                        raises_edge=np.array(raises))
     print("targets done")
 
 
@@ -331,6 +343,9 @@ def gen_preprocess(ref_utils, ref_datasets):
         def load_from_text(self, text):
             return text          # the "text" IS the (image, joint_uvd, com, cube) tuple here
 
+        def decode_line_txt(self, text):
+            return "synthetic", None     # (only used by the reference to word its error messages, datasets.py:363, 388)
+
     rng = np.random.default_rng(77)
     rec = {"intrinsics": np.array([fx, fy, hu, hv]), "S": np.int64(S), "P": np.int64(P)}
     n = 6
@@ -350,6 +365,34 @@ def gen_preprocess(ref_utils, ref_datasets):
         juvd = np.stack([cu + rr * np.cos(ang), cv_ + rr * np.sin(ang), cz + 50 * (rng.random(J) - 0.5)], axis=1)
         com = np.array([cu + 3 * (rng.random() - 0.5), cv_ + 3 * (rng.random() - 0.5), cz])
         frames.append((depth, juvd, com, 150))
+    # ---- round 3: the reference's edge cases (frames 6..8; the six frames above are unchanged)
+    def joint_for(frame, target_uv, a=None):
+        """Raw joint position (u, v) whose LABEL-pixel coordinates come out as target_uv on the plain (a is None) or augmented path."""
+        c = PR.shift_com(frame[2], a["shift_x"], a["shift_y"]) if a else np.array(frame[2], dtype=np.float64)
+        o = PR.process_single(frame[0], frame[1], c, 150, fx, fy, S, P, **({"angle": a["angle"], "scale": a["scale"]} if a else {}))
+        cen = (np.asarray(target_uv, dtype=np.float64) - P // 2) / (P - 1) * (S - 1)
+        if a:
+            ang = a["angle"] / 180.0 * np.pi
+            Rot = np.array([[np.cos(ang), np.sin(ang)], [-np.sin(ang), np.cos(ang)]])
+            cen = (cen / a["scale"]) @ np.linalg.inv(Rot.T)
+        return cen * (o["box_size"] - 1) / (S - 1) + o["com"][:2]
+    # frame 6: joint 0 at label pixel (-0.5, -0.4) on the UN-augmented path: numpy wraps heatmap[-1, -1] (utils.py:54-57), no error
+    f6 = [a.copy() if hasattr(a, "copy") else a for a in frames[1]]
+    f6[1][0, :2] = joint_for(f6, (-0.5, -0.4))
+    frames.append(tuple(f6))
+    # frame 7: the same on the AUGMENTED path (the draws of seed 1000 + 7 are known in advance): the reference keeps the augmented sample
+    f7 = [a.copy() if hasattr(a, "copy") else a for a in frames[2]]
+    random.seed(1000 + 7)
+    a7 = PR.draws_to_augmentation([random.random() for _ in range(5)])
+    f7[1][0, :2] = joint_for(f7, (-0.6, -0.3), a7)
+    frames.append(tuple(f7))
+    # frame 8: a hand of a few pixels -> sum(mask) < 10 -> ValueError (datasets.py:385-390), both paths
+    cz = 700.0
+    depth = np.zeros((H, W), np.float32)
+    depth[240:243, 320:323] = cz
+    juvd = np.stack([320 + 2 * rng.random(J), 240 + 2 * rng.random(J), cz + 5 * (rng.random(J) - 0.5)], axis=1)
+    frames.append((depth, juvd, np.array([321.0, 241.0, cz]), 150))
+    names = ("img", "label_img", "mask", "box_size", "cube_size", "com", "uvd", "heatmaps", "depthmaps")
     for aug in (False, True):
         ds = Synth(aug)
         for i, fr in enumerate(frames):
@@ -357,18 +400,30 @@ def gen_preprocess(ref_utils, ref_datasets):
             draws = []
             real = random.random
             random.random = lambda: (draws.append(real()) or draws[-1])
+            pre = "%s%d_" % ("aug" if aug else "plain", i)
+            import contextlib, io
             try:
-                out = ds.process_single_data((fr[0].copy(), fr[1].copy(), fr[2].copy(), fr[3]))
+                with contextlib.redirect_stdout(io.StringIO()):
+                    out = ds.process_single_data((fr[0].copy(), fr[1].copy(), fr[2].copy(), fr[3]))
+                rec[pre + "rejected"] = np.array(False)
+            except ValueError:
+                assert i >= 6, "the round-2 frames are all valid"
+                out = None
+                rec[pre + "rejected"] = np.array(True)          # the reference raised: check_text drops the sample
             finally:
                 random.random = real
-            names = ("img", "label_img", "mask", "box_size", "cube_size", "com", "uvd", "heatmaps", "depthmaps")
-            pre = "%s%d_" % ("aug" if aug else "plain", i)
-            for nm, t in zip(names, out):
+            for nm, t in zip(names, out or ()):
                 rec[pre + nm] = t.numpy()
             rec[pre + "draws"] = np.array(draws)
         print("preprocess", "augmented" if aug else "plain", "done")
+    # what the fixture must contain to be worth anything: the wrap on both paths (kept, not rejected, augmented sample kept), the rejection
+    assert not rec["plain6_rejected"] and not rec["aug7_rejected"] and rec["plain8_rejected"] and rec["aug8_rejected"]
+    assert not np.array_equal(rec["aug7_img"], rec["plain7_img"]), "frame 7 kept the augmented sample"
+    for pre in ("plain6_", "aug7_"):
+        h = rec[pre + "heatmaps"][0]
+        assert h[0, 0] > 0 and h[-1, -1] > 0 and h[0, -1] > 0 and h[-1, 0] > 0 and h[P // 2, P // 2] == 0, "footprint wrapped to the four corners"
+    rec["n_frames"] = np.int64(len(frames))
     for i, fr in enumerate(frames):
-        rec["raw%d_depth" % i] = fr[0].astype(np.float16)       # (values are exactly representable? no: store as float32 below)
         rec["raw%d_depth" % i] = fr[0]
         rec["raw%d_joints" % i] = fr[1]
         rec["raw%d_com" % i] = fr[2]

@@ -142,6 +142,34 @@ def process_single(image, joint_uvd, com, cube_size, fx, fy, image_size=128, lab
             "label_raw": label, "joint_centered_resized": cen}
 
 
+def sample_like_reference(image, joint_uvd, com, cube_size, fx, fy, image_size=128, label_size=64, aug=None):
+    """The control flow of HandDataset.process_single_data around process_single (datasets.py:221-390):
+      * with augmentation: the augmented attempt sits in a try (datasets.py:221-299); the only thing that fails in it for valid
+        frames is utils.generate_heatmap (joint footprint out of numpy's index range, or a NaN position) -> the bare `except`
+        (:300) re-does the sample WITHOUT augmentation ("fallback");
+      * the un-augmented path raises ValueError when generate_heatmap fails there (:358-365);
+      * whichever path produced the sample, it raises ValueError when anything is NaN or sum(mask) < 10 (:385-390).
+    A ValueError means the dataset drops the sample (check_text, datasets.py:159-167): "rejected".
+    aug: dict(angle, scale, shift_x, shift_y) or None.  Returns (process_single's dict or None, fallback, rejected)."""
+    from oracle import targets_ref as TR
+
+    def heat_ok(o):
+        uv = TR.label_pixels(o["uvd"], label_size)
+        return all(TR.footprint_ok(label_size, uv[j, 0], uv[j, 1]) for j in range(uv.shape[0]))
+    o, fallback = None, False
+    if aug is not None:
+        o = process_single(image, joint_uvd, shift_com(com, aug["shift_x"], aug["shift_y"]), cube_size, fx, fy, image_size, label_size,
+                           angle=aug["angle"], scale=aug["scale"])
+        if not heat_ok(o):
+            o, fallback = None, True
+    if o is None:
+        o = process_single(image, joint_uvd, com, cube_size, fx, fy, image_size, label_size)
+        if not heat_ok(o):
+            return None, fallback, True
+    bad = any(np.isnan(np.asarray(o[k], dtype=np.float64)).any() for k in ("img", "label_img", "uvd", "mask")) or o["mask"].sum() < 10
+    return (None if bad else o), fallback, bool(bad)
+
+
 def shift_com(com, shift_x, shift_y):
     """datasets.py:235-241.  The reference means to shift the COM in camera space (uvd2xyz -> += shift -> xyz2uvd), but
     HandDataset.uvd2xyz / xyz2uvd (datasets.py:85-111) only transform 2-D and 3-D arrays and return a 1-D [u, v, d] vector

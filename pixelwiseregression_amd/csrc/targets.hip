@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void make_targets_kernel(const float* __restri
   const double mind = fmax(du + dv - 1.0, 0.0), maxd = fmin(du, dv);
   const double wdd = 0.5 * (maxd + mind);                                                            // utils.py:46-53
   const float wd = (float)wdd, wb = (float)(du - wdd), wc = (float)(dv - wdd), wa = (float)(1.0 + wdd - du - dv);
-  const bool inside = lu >= 0 && lv >= 0 && lu + 1 < P && lv + 1 < P;
+  // utils.py:54-57 index the map with numpy's rule: -P <= i < P, negative indices WRAP (a joint up to P pixels left of / above the map
+  // lands on the opposite border: lu = -1 -> columns P-1 and 0); the reference fails only for lu + 1 >= P, lu < -P or a NaN position
+  const bool inside = u == u && v == v && fu >= -(double)P && fv >= -(double)P && fu + 1.0 < (double)P && fv + 1.0 < (double)P;
+  const int cu0 = inside ? (lu + P) % P : 0, cu1 = inside ? (lu + 1 + P) % P : 0;
+  const int rv0 = inside ? (lv + P) % P : 0, rv1 = inside ? (lv + 1 + P) % P : 0;
   const int r = ksize / 2;
   float* __restrict__ ho = heat + (size_t)bj * P * P;
   float* __restrict__ dout = dmap + (size_t)bj * P * P;
@@ -48,14 +52,14 @@ __global__ __launch_bounds__(256) void make_targets_kernel(const float* __restri
     const int y = i / P, x = i - y * P;
     float h = 0.f;
     if (inside) {
-      // separable blur of the 2x2 splat: column weights for source columns lu, lu+1 and row weights for lv, lv+1
+      // separable blur of the 2x2 splat: column weights for source columns lu, lu+1 and row weights for lv, lv+1 (wrapped)
       float cx0 = 0.f, cx1 = 0.f, ry0 = 0.f, ry1 = 0.f;
       for (int t = 0; t < ksize; ++t) {
         const int sx = reflect101(x + t - r, P), sy = reflect101(y + t - r, P);
-        if (sx == lu) cx0 += g[t];
-        if (sx == lu + 1) cx1 += g[t];
-        if (sy == lv) ry0 += g[t];
-        if (sy == lv + 1) ry1 += g[t];
+        if (sx == cu0) cx0 += g[t];
+        if (sx == cu1) cx1 += g[t];
+        if (sy == rv0) ry0 += g[t];
+        if (sy == rv1) ry1 += g[t];
       }
       h = ry0 * (wa * cx0 + wb * cx1) + ry1 * (wc * cx0 + wd * cx1);
     }
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(256) void make_targets_kernel(const float* __restri
 }  // namespace pwr
 
 // uvd: [B,J,3] normalised joints (datasets.py:382-384); label_img, mask: [B,P,P]; heatmaps, depthmaps: [B,J,P,P] (train.py:197-198
-// targets).  A joint whose 2x2 footprint leaves the map gets all-zero maps (the reference's dataset raises and re-samples).
+// targets).  A joint for which utils.generate_heatmap raises (footprint beyond the right / bottom border, more than P pixels left / above, or
+// NaN) gets all-zero maps; preprocess_batch reports such samples (the reference falls back to the un-augmented sample or drops it).
 extern "C" int pwr_make_targets(const float* uvd, const float* label_img, const float* mask, float* heatmaps, float* depthmaps, int B,
                                 int J, int P, int ksize, float sigma, void* stream) {
   if (ksize < 1 || ksize > PWR_MAXK || !(ksize & 1) || !(sigma > 0.f)) return PWR_EINVAL;

@@ -17,8 +17,13 @@ Behaviours of the reference that are kept on purpose:
   * the "shift" augmentation moves the COM by (shift_x, shift_y) PIXELS -- HandDataset.uvd2xyz / xyz2uvd return a 1-D vector
     unchanged (datasets.py:85-111), so the intended camera-space shift of datasets.py:235-241 never happens;
   * the rotation angle that is applied is the one utils.random_rotated draws itself (utils.py:70), not the one of datasets.py:225;
-  * a joint whose 2x2 heat-map footprint leaves the label map makes the reference fall back to the un-augmented sample
-    (datasets.py:300); ``preprocess_batch`` does the same per sample (``fallback`` in the result says which).
+  * a joint for which utils.generate_heatmap raises makes the reference fall back to the un-augmented sample (datasets.py:300);
+    ``preprocess_batch`` does the same per sample (``fallback`` in the result says which).  generate_heatmap raises only when
+    floor(u) + 1 >= P or floor(u) < -P (same for v): numpy WRAPS the negative indices in between, so a joint just left of / above
+    the label map keeps the augmented sample, with its 2x2 footprint split between the opposite borders (utils.py:54-57);
+  * a sample is dropped by the reference (ValueError -> check_text, datasets.py:159-167, 358-365, 385-390) when generate_heatmap
+    raises on the un-augmented path too, when anything is NaN, or when the mask has fewer than 10 pixels: ``rejected`` says which
+    samples of the batch those are (their tensors are still filled in; the caller drops them).
 The flip augmentation is not offered: in the reference it raises (joint_uvd_centered is used before assignment, datasets.py:268)
 and therefore always ends in the un-augmented fallback.
 """
@@ -115,10 +120,13 @@ def _joints(joint_uvd, com_i, box, cube, S, aug):
 
 
 def _footprint_ok(uvd, P):
-    """utils.generate_heatmap raises unless the 2x2 footprint of every joint is inside the label map (utils.py:54-61)."""
+    """Per sample: utils.generate_heatmap (utils.py:37-61) does not raise for any joint.  It indexes the map with numpy's rule, so
+    negative indices down to -P WRAP to the opposite border instead of failing; it raises only for floor(u) + 1 >= P,
+    floor(u) < -P (same for v) or a NaN position."""
     uv = uvd[:, :, :2] * (P - 1) + P // 2
-    lo = np.floor(uv).astype(np.int64)
-    return ((lo >= 0) & (lo + 1 < P)).all(axis=(1, 2))
+    fin = np.isfinite(uv)
+    lo = np.floor(np.where(fin, uv, 0.0))
+    return (fin & (lo >= -P) & (lo + 1 < P)).all(axis=(1, 2))
 
 
 def preprocess_batch(depth, joint_uvd, com, cube_size, intrinsics, image_size=128, label_size=64, augmentation=None, kernel_size=7,
@@ -152,9 +160,13 @@ def preprocess_batch(depth, joint_uvd, com, cube_size, intrinsics, image_size=12
             label = torch.where(fb[:, None, None, None], label0, label)
             mask = torch.where(fb[:, None, None, None], mask0, mask)
             box[fallback], com_i[fallback], uvd[fallback] = box0[fallback], com0[fallback], uvd0[fallback]
+    # datasets.py:358-365 (un-augmented heat map fails) and :385-390 (NaN anywhere, or fewer than 10 mask pixels): sample dropped
+    rejected = ~_footprint_ok(uvd, P)
+    bad = (torch.isnan(img).flatten(1).any(1) | torch.isnan(label).flatten(1).any(1) | (mask.flatten(1).sum(1) < 10)).cpu().numpy()
+    rejected |= bad | np.isnan(uvd).any(axis=(1, 2))
     out = {"img": img, "label_img": label, "mask": mask, "box_size": torch.from_numpy(box.astype(np.float32)),
            "cube_size": torch.from_numpy(cube.astype(np.float32)), "com": torch.from_numpy(com_i.astype(np.float32)),
-           "uvd": torch.from_numpy(uvd.astype(np.float32)).to(dev), "fallback": torch.from_numpy(fallback)}
+           "uvd": torch.from_numpy(uvd.astype(np.float32)).to(dev), "fallback": torch.from_numpy(fallback), "rejected": torch.from_numpy(rejected)}
     if dense_targets:
         out["heatmaps"], out["depthmaps"] = make_targets(out["uvd"], label, mask, kernel_size, sigmoid)
     return out

@@ -39,6 +39,46 @@ def test_oracle_pipeline_vs_reference(golden_dir, kind, i):
     np.testing.assert_allclose(d[0], g[pre + "depthmaps"], atol=5e-7)
 
 
+@pytest.mark.parametrize("i", [6, 7])
+@pytest.mark.parametrize("kind", ["plain", "aug"])
+def test_oracle_pipeline_vs_reference_wrapped_footprint(golden_dir, kind, i):
+    """Frames 6 / 7: joint 0 sits at label pixel (-0.5, -0.4) on the un-augmented path / (-0.6, -0.3) on the augmented one.  The
+    reference does not fail there (numpy wraps the negative indices, utils.py:54-57): it keeps the sample -- the AUGMENTED one on the
+    augmented path -- with the joint's heat map on the four corners."""
+    g = _g(golden_dir)
+    fx, fy, hu, hv = g["intrinsics"]
+    depth, joints, com = g["raw%d_depth" % i], g["raw%d_joints" % i], g["raw%d_com" % i]
+    pre = "%s%d_" % (kind, i)
+    aug = R.draws_to_augmentation(g[pre + "draws"]) if kind == "aug" else None
+    o, fallback, rejected = R.sample_like_reference(depth, joints, com, 150, fx, fy, 128, 64, aug)
+    assert not rejected and not bool(g[pre + "rejected"])
+    assert fallback == (kind == "aug" and np.array_equal(g[pre + "img"], g["plain%d_img" % i]))
+    np.testing.assert_allclose(np.asarray(o["img"], np.float64)[None], g[pre + "img"], atol=5e-7)
+    np.testing.assert_allclose(o["uvd"], g[pre + "uvd"], atol=1e-7)
+    h, d = T.make_targets(o["uvd"][None].astype(np.float32), o["label_img"][None, None].astype(np.float32), o["mask"][None, None].astype(np.float32))
+    np.testing.assert_allclose(h[0], g[pre + "heatmaps"], atol=3e-7)     # (the position goes through float32 here, float64 in the reference)
+    np.testing.assert_allclose(d[0], g[pre + "depthmaps"], atol=5e-7)
+    if (kind, i) in (("plain", 6), ("aug", 7)):
+        uv = T.label_pixels(o["uvd"], 64)[0]
+        assert -1 < uv[0] < 0 and -1 < uv[1] < 0
+        assert not fallback and h[0, 0, 0, 0] > 0 and h[0, 0, -1, -1] > 0 and h[0, 0, 32, 32] == 0
+
+
+@pytest.mark.parametrize("kind", ["plain", "aug"])
+def test_oracle_rejects_what_the_reference_rejects(golden_dir, kind):
+    """Frame 8 (a hand of nine pixels): the reference raises ValueError (sum(mask) < 10, datasets.py:385-390) on both paths; every
+    other frame is accepted."""
+    g = _g(golden_dir)
+    fx, fy, hu, hv = g["intrinsics"]
+    n = int(g["n_frames"])
+    assert n == 9
+    for i in range(n):
+        pre = "%s%d_" % (kind, i)
+        aug = R.draws_to_augmentation(g[pre + "draws"]) if kind == "aug" else None
+        o, fallback, rejected = R.sample_like_reference(g["raw%d_depth" % i], g["raw%d_joints" % i], g["raw%d_com" % i], 150, fx, fy, 128, 64, aug)
+        assert rejected == bool(g[pre + "rejected"]) == (i == 8), (kind, i)
+
+
 def test_draw_augmentation_replays_the_reference_draw_order(golden_dir):
     from pixelwiseregression_amd.preprocess import draw_augmentation
     g = _g(golden_dir)

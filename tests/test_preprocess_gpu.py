@@ -49,6 +49,72 @@ def test_device_pipeline_matches_reference(golden_dir, kind):
     np.testing.assert_allclose(out["depthmaps"].cpu().numpy()[sure], ref("depthmaps")[sure], atol=5e-7)
 
 
+def _load_all(golden_dir):
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    n = int(g["n_frames"])
+    depth = torch.from_numpy(np.stack([g["raw%d_depth" % i] for i in range(n)])).to(DEV)
+    return g, n, depth, np.stack([g["raw%d_joints" % i] for i in range(n)]), np.stack([g["raw%d_com" % i] for i in range(n)])
+
+
+@pytest.mark.parametrize("kind", ["plain", "aug"])
+def test_device_pipeline_edge_cases_match_reference(golden_dir, kind):
+    """Frames 6 / 7 / 8 of the fixture, written by the reference's process_single_data: a joint at label pixel (-0.5, -0.4) on the plain
+    path (6) and (-0.6, -0.3) on the augmented path (7) -- numpy wraps heatmap[-1, -1], the reference keeps the sample, the augmented
+    one on the augmented path -- and a nine-pixel hand (8) which the reference drops (sum(mask) < 10, datasets.py:385-390)."""
+    from pixelwiseregression_amd import preprocess_batch, draw_augmentation
+    g, n, depth, joints, com = _load_all(golden_dir)
+    aug = None
+    if kind == "aug":
+        parts = []
+        for i in range(n):
+            random.seed(1000 + i)
+            parts.append(draw_augmentation(1, rng=random))
+        aug = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    out = preprocess_batch(depth, joints, com, 150, INTR, 128, 64, augmentation=aug)
+    want_rej = np.array([bool(g["%s%d_rejected" % (kind, i)]) for i in range(n)])
+    assert np.array_equal(out["rejected"].numpy(), want_rej) and want_rej.tolist() == [False] * 8 + [True]
+    want_fb = np.array([kind == "aug" and not want_rej[i] and np.array_equal(g["aug%d_img" % i], g["plain%d_img" % i]) for i in range(n)])
+    assert np.array_equal(out["fallback"].numpy()[:8], want_fb[:8])
+    for i in (6, 7):
+        pre = "%s%d_" % (kind, i)
+        np.testing.assert_allclose(out["uvd"][i].cpu().numpy(), g[pre + "uvd"], atol=1e-7)
+        np.testing.assert_allclose(out["img"][i].cpu().numpy(), g[pre + "img"], atol=5e-7)
+        assert np.array_equal(out["mask"][i].cpu().numpy(), g[pre + "mask"])
+        np.testing.assert_allclose(out["heatmaps"][i].cpu().numpy(), g[pre + "heatmaps"], atol=4e-7)
+        h = g[pre + "heatmaps"]
+        sure = (h > 1e-12) | (h == 0)
+        np.testing.assert_allclose(out["depthmaps"][i].cpu().numpy()[sure], g[pre + "depthmaps"][sure], atol=5e-7)
+    i = 6 if kind == "plain" else 7
+    h = out["heatmaps"][i, 0].cpu().numpy()
+    assert h[0, 0] > 0 and h[-1, -1] > 0 and h[0, -1] > 0 and h[-1, 0] > 0 and h[32, 32] == 0     # the wrapped footprint, on the device
+
+
+def test_make_targets_wraps_and_zeroes_like_the_reference_splat(golden_dir):
+    """pwr_make_targets at the reference's edge positions (tests/golden/targets.npz: utils.generate_heatmap's own outputs): blurred
+    wrapped splat where the reference returns one, all-zero maps where it raises (incl. NaN)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import targets_ref as T
+    from pixelwiseregression_amd.targets import make_targets
+    g = np.load(os.path.join(golden_dir, "targets.npz"))
+    P = int(g["P"])
+    uv = g["uv_edge"]
+    uvd = np.zeros((1, len(uv), 3), np.float32)
+    uvd[0, :, :2] = ((uv - P // 2) / (P - 1)).astype(np.float32)
+    label = torch.zeros(1, 1, P, P, device=DEV)
+    heat, _ = make_targets(torch.from_numpy(uvd).to(DEV), label, label)
+    heat = heat.cpu().numpy()[0]
+    uv32 = uvd[0, :, :2].astype(np.float64) * (P - 1) + P // 2           # what the kernel sees (float32 positions)
+    for j, raises in enumerate(g["raises_edge"]):
+        if not T.footprint_ok(P, uv32[j, 0], uv32[j, 1]) == (not raises):
+            continue                                                        # float32 moved the position across an integer: not this test's business
+        if raises:
+            assert not heat[j].any(), uv[j]
+        else:
+            ref = T.gaussian_blur(T.generate_heatmap(P, uv32[j, 0], uv32[j, 1]), 7, 1.5)
+            np.testing.assert_allclose(heat[j], ref, atol=2e-7, err_msg=str(uv[j]))
+
+
 def test_device_pipeline_falls_back_per_sample_like_the_reference(golden_dir):
     """A joint that leaves the label map after the augmentation makes the reference return the UN-augmented sample
     (datasets.py:300): same here, for that sample only."""
