@@ -231,6 +231,39 @@ def accuracy_block(steps, dev):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (torch.distributed.run), before this
+    process has touched the GPU, relay rank 0's JSON line and return non-zero if any rank failed.  (Never a re-exec of a process that
+    has initialised HIP.)"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l_ in proc.stdout:
+        if l_.startswith("{") and '"metric"' in l_:
+            line = l_.rstrip("\n")
+        else:
+            sys.stderr.write(l_)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,7 +284,13 @@ def main():
                     help="debug: take the data-parallel path (process group, per-segment all-reduce) even with one rank -- exercises RCCL on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share cuda:0 (with --dist-backend gloo) to exercise the data-parallel path on a 1-GPU box")
+    ap.add_argument("--debug-lib", action="store_true",
+                    help="A/B measurements only: load the DEBUG build of the library (tools/build_debug.py) so that the PWR_* experiment "
+                         "switches apply; the result line says so")
     args = ap.parse_args()
+    if args.debug_lib:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import dbglib  # noqa: F401
 
     if args.roofline_only:
         torch.cuda.set_device(0)
@@ -267,8 +306,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  Nothing in this process has touched the GPU yet (device_count does not initialise HIP).
+        if not args.same_device and torch.cuda.device_count() < args.gpus:
+            print("bench.py --gpus %d: only %d GPU(s) visible (add --same-device --dist-backend gloo for the 1-GPU debug mode)"
+                  % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
+        sys.exit(self_launch(args.gpus))
+    if args.gpus != world and not args.force_dist:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if args.same_device:
         local = 0
@@ -355,7 +401,8 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: NYU 14-joint, 128x128 depth crops, batch 32 per GPU, train (AdamW, %s), "
                                    "features 128, level 4, stage 2, instance norm" % args.precision,
-                       "global_batch": world * B_PER_GPU, "backend": "hip", "harness": args.harness,
+                       "global_batch": world * B_PER_GPU, "backend": "hip" if not args.debug_lib else "hip (DEBUG build of the library)",
+                       "harness": args.harness,
                        "parallelism": "dp%d" % world if use_dist else "single"},
             "infer_frames_per_s": world * B_PER_GPU / dt_inf,
             "final_loss": final_loss,

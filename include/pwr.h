@@ -34,10 +34,8 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 1
+#define PWR_ABI_VERSION 3   /* 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h (debug build only) */
 int pwr_abi_version(void);
-/* debugging aid: dst = src (bytes % 16 == 0) iff *flag != 0, decided on the device (tools/race_hunt.py) */
-int pwr_debug_copy_if(const int* flag, const void* src, void* dst, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder (SURVEY.md section 8 a-D)
@@ -155,25 +153,6 @@ int pwr_norm_bwd_from_partial(const void* g, const void* y, const float* state, 
 int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);
 
-/* InstanceNorm backward split so that the batch reduction of dgamma / dbeta can run beside the critical path:
- * pwr_norm_bwd_main = partial sums into `partial` (pwr_norm_bwd_partial_bytes; keep it until pwr_norm_bwd_params ran) + apply,
- * pwr_norm_bwd_params = dgamma / dbeta from `partial`. */
-size_t pwr_norm_bwd_partial_bytes(int B, int HW, int C);
-int pwr_norm_bwd_main(const void* g, const void* y, const float* state, float* partial, const void* addend, void* dy, int relu, int B,
-                      int HW, int C, int dtype, void* stream);
-int pwr_norm_bwd_params(const float* partial, float* dgamma, float* dbeta, int accumulate, int B, int HW, int C, void* stream);
-
-/* InstanceNorm + ReLU backward for maps of at most 512 pixels in ONE launch (one workgroup owns a sample); the
- * per-sample sums [B][2][C] feed pwr_norm_param_grad (dgamma / dbeta over the batch), which is off the critical path. */
-int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* sums, const void* addend, void* dy, int relu, int B,
-                       int HW, int C, int dtype, void* stream);
-int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream);
-/* InstanceNorm (+ReLU) backward with the parameter gradients deferred (round 2): reductions from `partial` (`chunks` rows per sample
- * written by a data-gradient conv's epilogue, or chunks = 0: computed here first; partial then needs pwr_norm_partial_bytes), S1 / S2 and
- * the apply on `stream`; the raw per-sample sums go to `sums` [B][2][C] for pwr_norm_param_grad, which may run later on any stream. */
-int pwr_norm_bwd_deferred(const void* g, const void* y, const float* state, float* partial, int chunks, float* S1, float* S2, float* sums,
-                          const void* addend, void* dy, int relu, int B, int HW, int C, int dtype, void* stream);
-
 /* Dense training targets on the device (datasets.py:285-294 heat maps = Gaussian blur, default border, of the bilinear 2x2
  * splat utils.py:37-64; datasets.py:365-383 depth-offset maps) from the normalised joints uvd [B,J,3], label_img and mask
  * [B,P,P]: heatmaps / depthmaps [B,J,P,P] fp32, the alpha < 1 targets of the loss (train.py:197-198).  ksize odd <= 15. */
@@ -205,39 +184,6 @@ int pwr_resblock_bwd_small(const void* gout, const void* x, const void* t1, cons
 int pwr_resblock_param_grads(const float* sums_a, const float* sums_b, const float* sums_c, const float* bias_sums, float* dgamma_a,
                              float* dbeta_a, float* dgamma_b, float* dbeta_b, float* dgamma_c, float* dbeta_c, float* dbias_c,
                              int B, int C, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * The inner hourglass (model.py:25-47: the recursion below the 32x32 level, maps of 16x16 down to 2x2) as ONE launch per
- * direction.  A workgroup owns a sample and runs a program of `nsteps` steps in order: PWR_SUBHG_BLOCK = the ResBlock
- * blocks[step.block] (arguments as for pwr_resblock_fwd_small / pwr_resblock_bwd_small) on a map of width 2^logw;
- * PWR_SUBHG_POOL = MaxPool2d(2,2) (forward: s0 [B,W,W,C] -> d [B,W/2,W/2,C], logw = log2 W; backward: d = dx [B,W,W,C] from
- * s0 = x, s1 = dh [B,W/2,W/2,C], s2 = addend or NULL -- pwr_maxpool_bwd); PWR_SUBHG_UP = nearest up-sample by two + skip add
- * (forward: d [B,W,W,C] = s1 (skip) + up(s0 [B,W/2,W/2,C]); backward: d = dh [B,W/2,W/2,C] from s0 = dout [B,W,W,C]; logw =
- * log2 of the larger map).  Every tensor the per-block launches write is written, with the same values (bit-identical): the
- * call replaces the launches, nothing else.  bf16, InstanceNorm, C == 128, maps of 2..16 pixels a side.
- * ------------------------------------------------------------------------------------------- */
-#define PWR_SUBHG_MAX_BLOCKS 8
-#define PWR_SUBHG_MAX_STEPS 16
-enum { PWR_SUBHG_BLOCK = 0, PWR_SUBHG_POOL = 1, PWR_SUBHG_UP = 2 };
-typedef struct {
-  const void* x; void* t1; void* t2; void* out;
-  const void* wa; const void* wb; const void* wc;
-  const float* bias_a; const float* bias_b; const float* bias_c;
-  const float* gamma_a; const float* beta_a; const float* gamma_b; const float* beta_b; const float* gamma_c; const float* beta_c;
-  float* state_a; float* state_b; float* state_c;
-} pwr_resblock_fwd_args;
-typedef struct {
-  const void* gout; const void* x; const void* t1; const void* t2;
-  void* dx; void* dt1; void* dt2;
-  const void* wc_d; const void* wb_d; const void* wa_d;
-  const float* state_a; const float* state_b; const float* state_c;
-  float* sums_a; float* sums_b; float* sums_c; float* bias_sums;
-} pwr_resblock_bwd_args;
-typedef struct { int kind; int logw; int block; int reserved; const void* s0; const void* s1; const void* s2; void* d; } pwr_subhg_step;
-int pwr_subhourglass_fwd(const pwr_resblock_fwd_args* blocks, int nblocks, const pwr_subhg_step* steps, int nsteps, int B, int C,
-                         float eps, int dtype, void* stream);
-int pwr_subhourglass_bwd(const pwr_resblock_bwd_args* blocks, int nblocks, const pwr_subhg_step* steps, int nsteps, int B, int C,
-                         int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hourglass plumbing (model.py:40, :45-47), NHWC.
@@ -277,10 +223,6 @@ const char* pwr_last_error(void);
 void* pwr_engine_create(const int* cfg, int B, int dtype, int training, const long long* param_off,
                         const long long* param_numel, int n_params, const long long* buffer_off, int n_buffers);
 void pwr_engine_destroy(void* engine);
-void pwr_debug_set_pingpong(int v);   /* debugging aid: force the ping-pong 3x3 conv on (1) / off (0); -1 = default */
-void pwr_debug_set_stamps(void* stamps);   /* debugging aid: per-workgroup phase time stamps of the 3x3 patch conv (8 x int64 each); NULL = off */
-size_t pwr_engine_layout(void* engine, char* buf, size_t cap);   /* debugging aid: arena layout as text lines "offset bytes tag"; returns the size needed */
-void pwr_engine_set_join(void* engine, int each_segment);   /* 1 (default): every backward segment ends with its parameter gradients complete on the stream (needed to all-reduce per segment); 0: only the last one does */
 size_t pwr_engine_arena_bytes(void* engine);   /* activation + gradient + scratch arena the caller must provide */
 size_t pwr_engine_pack_bytes(void* engine);    /* packed-weight buffer (includes the descriptor table) */
 size_t pwr_engine_desc_offset(void* engine);   /* where in the pack buffer the descriptor table must be uploaded */

@@ -1,0 +1,22 @@
+/* pwr_debug.h -- debugging aids of libpwr_hip_dbg.so, the DEBUG build of the library (-DPWR_DEBUG_BUILD, tools/build_debug.py).
+ * NOT part of the product ABI: the shipped libpwr_hip.so exports none of these, reads no experiment environment variable, and has
+ * one configuration.  tools/dbglib.py loads the debug build for the measurement scripts under tools/. */
+#ifndef PWR_DEBUG_H_
+#define PWR_DEBUG_H_
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* dst = src (bytes % 16 == 0) iff *flag != 0, decided on the device (tools/race_hunt.py) */
+int pwr_debug_copy_if(const int* flag, const void* src, void* dst, size_t bytes, void* stream);
+/* per-workgroup phase time stamps of the 3x3 patch conv (8 x int64 each); NULL = off */
+void pwr_debug_set_stamps(void* stamps);
+/* arena layout as text lines "offset bytes tag"; returns the size needed */
+size_t pwr_engine_layout(void* engine, char* buf, size_t cap);
+/* 1 (the product's only mode): every backward segment ends with its parameter gradients complete on the stream; 0: only the last
+ * one does (1 % faster on one GPU; the configuration under which round 1's rare non-reproducible step occurred) */
+void pwr_engine_set_join(void* engine, int each_segment);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -7,8 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PWR_LIB", os.path.join(_HERE, "libpwr_hip.so"))   # PWR_LIB: another build of the same ABI, for A/B timing
-ABI_VERSION = 1
+LIB_PATH = os.path.join(_HERE, "libpwr_hip.so")     # the one product library (tools/dbglib.py swaps in the debug build for measurements)
+ABI_VERSION = 3
+_HEADERS = ["pwr.h"]
 
 _lib = None
 
@@ -16,11 +17,12 @@ _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size
            "void": None, "void*": ctypes.c_void_p, "const char*": ctypes.c_char_p}
 
 
-def _parse_header():
+def _parse_header(names=None):
     """name -> (restype, [argtypes]) parsed from include/pwr.h, so the binding cannot drift from the header."""
     import re
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "pwr.h")
-    txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    txt = ""
+    for h in (names or _HEADERS):
+        txt += re.sub(r"/\*.*?\*/", "", open(os.path.join(os.path.dirname(_HERE), "include", h)).read(), flags=re.S)
     sigs = {}
     for m in re.finditer(r"\b(int|size_t|void\*|void|long long|const char\*)\s+(pwr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
@@ -51,12 +53,13 @@ def lib():
             raise PwrError("libpwr_hip.so not built (%s). Run `python -m pixelwiseregression_amd.build` "
                            "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
+        if l.pwr_abi_version() != ABI_VERSION:
+            raise PwrError("%s has ABI %d, this binding needs %d: rebuild (python -m pixelwiseregression_amd.build)"
+                           % (LIB_PATH, l.pwr_abi_version(), ABI_VERSION))
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(l, name)       # AttributeError if the symbol is missing -> loud
             fn.argtypes = argtypes
             fn.restype = restype
-        if l.pwr_abi_version() != ABI_VERSION:
-            raise PwrError("libpwr_hip.so ABI %d != binding %d: rebuild" % (l.pwr_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

@@ -1,7 +1,7 @@
 """In-tree build of libpwr_hip.so (gfx950) with hipcc.  No torch C++ ABI involved: the library is a
 plain C ABI (include/pwr.h) loaded with ctypes, which side-steps the hipcc 7.2 / torch-HIP 7.0 skew.
 
-    python -m pixelwiseregression_amd.build [--force]
+    python -m pixelwiseregression_amd.build [--force] [--debug]
 """
 import hashlib
 import os
@@ -39,20 +39,27 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True, extra_flags=(), lib=None, obj=None):
-    """extra_flags / lib / obj: build a VARIANT of the library beside the product one (A/B experiments, e.g.
-    build(extra_flags=["-fno-slp-vectorize"], lib=".../libpwr_hip_noslp.so", obj=".../_obj_noslp"); load it with PWR_LIB)."""
+def build(force=False, verbose=True, debug=False, extra_flags=()):
+    """Compile csrc/*.hip for gfx950 and link libpwr_hip.so (in-tree, next to this file).
+
+    debug=True builds the DEBUG variant instead: -DPWR_DEBUG_BUILD (experiment switches read PWR_* environment variables, the
+    debugging entry points of include/pwr_debug.h exist), into tools/_build/libpwr_hip_dbg.so -- never into the package directory;
+    tools/dbglib.py loads it for the measurement scripts.  extra_flags: further -D / -f flags for a debug variant.
+    Every freshly linked library is scanned for the packed-f32 instruction form of DESIGN.md section 2 (codeobj_scan)."""
     global FLAGS, LIB, OBJ
-    if extra_flags or lib or obj:
+    if debug or extra_flags:
+        if not debug:
+            raise ValueError("extra_flags only with debug=True: the product library has one configuration")
         saved = (FLAGS, LIB, OBJ)
-        FLAGS, LIB, OBJ = FLAGS + list(extra_flags), lib or LIB, obj or OBJ
+        bdir = os.path.join(ROOT, "tools", "_build")
+        FLAGS, LIB, OBJ = FLAGS + ["-DPWR_DEBUG_BUILD"] + list(extra_flags), os.path.join(bdir, "libpwr_hip_dbg.so"), os.path.join(bdir, "obj")
         try:
             return build(force, verbose)
         finally:
             FLAGS, LIB, OBJ = saved
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
-    headers.append(os.path.join(ROOT, "include", "pwr.h"))
+    headers += [os.path.join(ROOT, "include", "pwr.h"), os.path.join(ROOT, "include", "pwr_debug.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs = []
     for src in _sources():
@@ -86,8 +93,26 @@ def build(force=False, verbose=True, extra_flags=(), lib=None, obj=None):
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
             print("[pwr build] linked", LIB, flush=True)
+        _scan_gate(LIB, verbose)
     return LIB
 
 
+def _scan_gate(lib, verbose=True):
+    """No packed f32 instruction with a cross-half op_sel may ship: checked on every link."""
+    from . import codeobj_scan
+    if not codeobj_scan.available():
+        if verbose:
+            print("[pwr build] llvm-objdump not found: code-object scan skipped", flush=True)
+        return
+    r = codeobj_scan.scan(lib)
+    if r["packed_f32_cross_half_op_sel"]:
+        os.remove(lib)
+        raise RuntimeError("%s contains %d packed f32 instructions with a cross-half op_sel (e.g. %s): the build flags lost "
+                           "-fno-slp-vectorize or hand-written packed math was added -- see DESIGN.md section 2"
+                           % (lib, r["packed_f32_cross_half_op_sel"], r["examples"][:2]))
+    if verbose:
+        print("[pwr build] code-object scan ok: %d functions, %d packed f32, 0 with cross-half op_sel" % (r["functions"], r["packed_f32"]), flush=True)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, debug="--debug" in sys.argv)

@@ -1,14 +1,19 @@
 """Disassemble the gfx950 code objects embedded in libpwr_hip.so and report instruction forms.
 
-    python tools/codeobj_scan.py [lib.so]         # prints counts of packed-f32 forms per kernel family
+    python -m pixelwiseregression_amd.codeobj_scan [lib.so]         # prints counts of packed-f32 forms
 
-Used by tests/test_boundary_cpu.py as the static regression test of the round-2 reproducibility fix: the shipped library must
-contain no packed f32 instruction whose LOW result selects a source's HIGH register (op_sel:[..1..]) -- the instruction form that
-was caught producing a wrong addend in lanes 48-63.
+The static gate of the round-2 reproducibility fix: the shipped library must contain no packed f32 instruction whose LOW result
+selects a source's HIGH register (op_sel:[..1..]) -- the instruction form that was caught producing a wrong addend in lanes 48-63
+(DESIGN.md section 2).  build.build() runs it on every freshly linked library (a flag change cannot ship silently) and
+tests/test_boundary_cpu.py on the library that is loaded.
 """
 import os, re, struct, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def available():
+    return all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "llvm-objdump"))
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 

@@ -2,9 +2,13 @@
 #include <hip/hip_runtime.h>
 
 #include "pwr.h"
+#ifdef PWR_DEBUG_BUILD
+#include "pwr_debug.h"
+#endif
 
 extern "C" int pwr_abi_version(void) { return PWR_ABI_VERSION; }
 
+#ifdef PWR_DEBUG_BUILD
 namespace {
 // dst = src if *flag != 0 (grid-stride, 16-byte vectors); every workgroup leaves at once otherwise
 __global__ __launch_bounds__(256) void copy_if_kernel(const int* __restrict__ flag, const uint4* __restrict__ src, uint4* __restrict__ dst,
@@ -21,3 +25,4 @@ extern "C" int pwr_debug_copy_if(const int* flag, const void* src, void* dst, si
   hipLaunchKernelGGL(copy_if_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, flag, (const uint4*)src, (uint4*)dst, bytes / 16);
   return (int)hipGetLastError();
 }
+#endif   // PWR_DEBUG_BUILD

@@ -198,9 +198,4 @@ bool conv_tr2_applicable(const ConvParams& p, int dtype);   // stride-2 data gra
 int launch_conv_tr2(const ConvParams& p, hipStream_t s);
 void set_debug_stamps(long long* ptr);
 
-// conv_pingpong.hip
-bool conv_pingpong_applicable(const ConvParams& p, int dtype);
-int launch_conv_pingpong(const ConvParams& p, hipStream_t s);
-void set_debug_pingpong(int v);
-
 }  // namespace pwr

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
 // is incremental (no divisions in the loop).  192 accumulator registers per wave -> one workgroup per CU; global
 // loads are prefetched two tiles ahead in registers.
 // ---------------------------------------------------------------------------------------------
-// DBG (only instantiated with -DPWR_WGRAD3_DBG_BUILD, tools/build_wgrad3_dbg.py): timing by elimination, results are WRONG --
+// DBG (only instantiated in the debug build, tools/build_debug.py; PWR_WGRAD3_DBG selects): timing by elimination, results are WRONG --
 // 1 no MFMAs, 2 no fragment reads, 4 no norm / ReLU math in the staging, 16 no staging stores, 32 no global loads in the loop
 template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
@@ -841,103 +841,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
   }
 }
 
-// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic).  One block per (32 co, 2 ci) tile.
-// Threads: 8 lanes x float4 = 32 co, times 32 slab groups; every thread keeps one independent float4 sum per (ci, tap)
-// item over its share of the S slabs (16-byte loads).  The 8 groups of a wave are combined with shuffles, the 4 waves
-// through LDS in a fixed order, and the OIHW rows are written in runs of 2*taps floats.
-#define PWR_RED_CI 2
-#define PWR_RED_MAXITEMS 18
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps,
-                                                           int Cin, int Cout, int CinPad, int CoutPad, int cin_real, int accumulate) {
-  extern __shared__ float tile[];                 // [4 waves][32 co][items + 1]
-  const int items = PWR_RED_CI * taps, pitch = items + 1;
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * PWR_RED_CI;
-  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3, wave = threadIdx.x >> 6;
-  const int co = co0 + c4 * 4;                    // CoutPad % 32 == 0: the float4 stays inside the padded row
-  f32x4 acc[PWR_RED_MAXITEMS];
-#pragma unroll
-  for (int it = 0; it < PWR_RED_MAXITEMS; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const size_t stride = (size_t)taps * CinPad * CoutPad;
-  if (items <= 4) {
-    // 1x1 layers: few items per slab and MANY slabs (S up to 512): keep four slabs' loads in flight per thread
-    int k = grp;
-    for (; k + 96 < S; k += 128) {
-      f32x4 v[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* base = slab + (size_t)(k + 32 * u) * stride + co;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          v[u][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (it < items) {
-            const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
-            if (ci < Cin) v[u][it] = *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) acc[it] += v[u][it];
-    }
-    for (; k < S; k += 32) {
-      const float* base = slab + (size_t)k * stride + co;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        if (it < items) {
-          const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
-          if (ci < Cin) acc[it] += *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
-        }
-      }
-    }
-  } else {
-    for (int k = grp; k < S; k += 32) {
-      const float* base = slab + k * stride + co;
-#pragma unroll
-      for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
-        if (it < items) {
-          const int cil = it / taps, tap = it - cil * taps, ci = ci0 + cil;
-          if (ci < Cin) acc[it] += *reinterpret_cast<const f32x4*>(base + ((size_t)tap * CinPad + ci) * CoutPad);
-        }
-      }
-    }
-  }
-  // combine the 8 slab groups inside each wave (lanes l, l^8, l^16, l^32 hold the same co)
-#pragma unroll
-  for (int it = 0; it < PWR_RED_MAXITEMS; ++it) {
-    if (it < items) {
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        acc[it].x += __shfl_xor(acc[it].x, o, 64); acc[it].y += __shfl_xor(acc[it].y, o, 64);
-        acc[it].z += __shfl_xor(acc[it].z, o, 64); acc[it].w += __shfl_xor(acc[it].w, o, 64);
-      }
-      if ((threadIdx.x & 63) < 8) {
-        float* t = tile + (wave * 32 + c4 * 4) * pitch + it;
-        t[0] = acc[it].x; t[pitch] = acc[it].y; t[2 * pitch] = acc[it].z; t[3 * pitch] = acc[it].w;
-      }
-    }
-  }
-  __syncthreads();
-  const int nci = min(PWR_RED_CI, cin_real - ci0);
-  if (nci <= 0) return;
-  for (int i = threadIdx.x; i < 32 * items; i += 256) {
-    const int col2 = i / items, rem = i - col2 * items;
-    const int co2 = co0 + col2;
-    if (co2 < Cout && rem < nci * taps) {
-      float v = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) v += tile[(g * 32 + col2) * pitch + rem];
-      const size_t o = ((size_t)co2 * cin_real + ci0) * taps + rem;
-      dw[o] = accumulate ? dw[o] + v : v;
-    }
-  }
-}
-
-// The same reduction with ALL of a thread's slab loads of a round in flight before the first add: one block per (32 co, 1 ci) row,
-// thread = (float4 of co, slab group g of 32), slabs k = g, g + 32, ... ascending (the summation order of wgrad_reduce_kernel: the
-// results are bit-identical), SL slabs x TAPS items loaded back to back.  wgrad_reduce_kernel issued one slab's items, waited,
-// added, and went round again: 2.5 dependent rounds of DRAM latency on 256 blocks = 25 us for the 47 MB of a 128 -> 128 3x3 layer
-// (1.9 TB/s), more than a third of the weight gradient's own time.
+// dW[co][ci][ky][kx] (+)= sum_s slab[s][tap][ci][co]   (fixed order -> deterministic): one block per (32 co, 1 ci) row,
+// thread = (float4 of co, slab group g of 32), slabs k = g, g + 32, ... ascending, ALL of a thread's slab loads of a round (SL slabs x
+// TAPS items) in flight before the first add; the 8 groups of a wave are combined with shuffles, the 4 waves through LDS in a fixed
+// order, and the OIHW rows are written in runs of `taps` floats.  (Round 1's form issued one slab's items, waited, added, and went
+// round again: 2.5 dependent rounds of DRAM latency on 256 blocks = 25 us for the 47 MB of a 128 -> 128 3x3 layer, 1.9 TB/s; this
+// form sums in the same order -- bit-identical, checked in round 2 -- and takes 13 us.)
 template <int TC, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cout,
                                                                 int CinPad, int CoutPad, int cin_real, int accumulate) {
@@ -1040,7 +949,6 @@ template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   if (p.CoutPad % bn) return PWR_EINVAL;
-  if (conv_pingpong_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_pingpong(p, s);
   if (conv_tr2_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_tr2(p, s);
   if (conv_patch_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
   // mode 1: four parity classes of M/4 rows each, every class padded to whole tiles
@@ -1064,15 +972,15 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       // 128 output channels: 64 (ci) x 128 (co) x 3 taps per workgroup = 96 accumulator registers -> TWO workgroups per CU,
       // so one's norm/ReLU staging (VALU) and waits overlap the other's MFMAs; the x tile (the operand that needs VALU work)
       // is split between them, not duplicated.  (128 x 128 x 3 = 192 registers allows one wave per SIMD only: 25 % MFMA busy.)
-      static const bool bm64 = [] { const char* e = getenv("PWR_WGRAD3_BM64"); return e ? atoi(e) != 0 : true; }();
+      static const bool bm64 = (PWR_DBG_ENV("PWR_WGRAD3_BM64", 1) != 0);
       if (bn == 128 && bm64) {
         dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
-#ifdef PWR_WGRAD3_DBG_BUILD
-        // (experiments, tools/build_wgrad3_dbg.py: register prefetch depth 4 -- measured 82.6 vs 81.7 us, not latency-bound -- and the
+#ifdef PWR_DEBUG_BUILD
+        // (experiments, debug build only: register prefetch depth 4 -- measured 82.6 vs 81.7 us, not latency-bound -- and the
         // timing-by-elimination variants)
-        static const int depth = [] { const char* e = getenv("PWR_WGRAD3_DEPTH"); return e ? atoi(e) : 2; }();
+        static const int depth = PWR_DBG_ENV("PWR_WGRAD3_DEPTH", 2);
         if (depth == 4) { hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 4>), g64, block, 0, s, p); return (int)hipGetLastError(); }
-        static const int dbg = [] { const char* e = getenv("PWR_WGRAD3_DBG"); return e ? atoi(e) : 0; }();
+        static const int dbg = PWR_DBG_ENV("PWR_WGRAD3_DBG", 0);
         switch (dbg) {
           case 1: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 1>), g64, block, 0, s, p); return (int)hipGetLastError();
           case 2: hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 2>), g64, block, 0, s, p); return (int)hipGetLastError();
@@ -1156,16 +1064,17 @@ extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias,
 
 // Debugging aid: while set, every 3x3 patch-conv workgroup writes 8 int64 (s_memtime at start / patch loaded / patch staged /
 // K loop done / end, -, HW_ID, XCC_ID) to stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8].  NULL switches it off.
+#ifdef PWR_DEBUG_BUILD
 extern "C" void pwr_debug_set_stamps(void* stamps) { pwr::set_debug_stamps((long long*)stamps); }
+#endif
 // Debugging aid: 1 / 0 forces the ping-pong form of the 3x3 128->128 conv on / off (where it applies), -1 = the default (env PWR_PINGPONG)
-extern "C" void pwr_debug_set_pingpong(int v) { pwr::set_debug_pingpong(v); }
 
 // slab rows per sample that pwr_conv_fwd_stats writes for this conv shape; 0 = the shape cannot produce column statistics
 // (a 128-pixel tile would straddle samples, or the transposed mode)
 extern "C" int pwr_conv_stats_chunks(int H, int W, int Cin, int Cout, int ksize, int stride, int mode, int dtype) {
   pwr::ConvParams p;
   if (conv_params_fill(p, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (void*)1, nullptr, 1, H, W, Cin, Cout, ksize, stride, mode, dtype)) return 0;
-  static const bool on = [] { const char* e = getenv("PWR_CONV_STATS"); return e ? atoi(e) != 0 : true; }();
+  static const bool on = (PWR_DBG_ENV("PWR_CONV_STATS", 1) != 0);
   if (!on || mode != 0) return 0;
   if (pwr::conv_patch_applicable(p, dtype)) return pwr::conv_patch_stats_chunks(p, dtype);
   const int HoWo = p.Ho * p.Wo;
@@ -1215,17 +1124,10 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
   if (rc) return rc;
   if (cout_real <= 0 || cout_real > Cout || cin_real <= 0 || cin_real > Cin) return PWR_EINVAL;
   const int taps = ksize * ksize;
-  const bool fast = [] { const char* e = getenv("PWR_WGRAD_REDUCE_FAST"); return e ? atoi(e) != 0 : true; }();   // (per call: the A/B test toggles it)
-  if (fast || taps > 9) {
-    const dim3 g((cout_real + 31) / 32, cin_real, (taps + 8) / 9);
-    if (taps > 1)
-      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
-    else
-      hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
-    return (int)hipGetLastError();
-  }
-  hipLaunchKernelGGL(pwr::wgrad_reduce_kernel, dim3((cout_real + 31) / 32, (cin_real + PWR_RED_CI - 1) / PWR_RED_CI), dim3(256),
-                     (size_t)4 * 32 * (PWR_RED_CI * taps + 1) * sizeof(float), s, slab, dw, p.S, taps, Cin, cout_real, p.CinPad, p.CoutPad, cin_real,
-                     accumulate);
+  const dim3 g((cout_real + 31) / 32, cin_real, (taps + 8) / 9);
+  if (taps > 1)
+    hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+  else
+    hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
   return (int)hipGetLastError();
 }

@@ -19,13 +19,15 @@
 
 namespace pwr {
 
-static long long* g_stamps = nullptr;
+static long long* g_stamps = nullptr;     // (debug build: pwr_debug_set_stamps; always null in the shipped library)
 __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
+#ifdef PWR_DEBUG_BUILD
   if (p.stamps && threadIdx.x == 0) {
     long long* d = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
     d[slot] = (long long)__builtin_amdgcn_s_memtime();
     if (slot == 0) { d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
   }
+#endif
 }
 
 // Patch pixels are padded by one 16-byte slot: with a pitch of NSLOT*16+16 bytes the 16-lane groups of ds_read_b128
@@ -511,14 +513,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
 
 // small square maps of the inner hourglass levels (64 -> 64 channels): whole images per tile
 static bool small_map(const ConvParams& p, int dtype) {
-  static const bool on = [] { const char* e = getenv("PWR_PATCH_SMALL"); return e ? atoi(e) != 0 : true; }();
+  static const bool on = (PWR_DBG_ENV("PWR_PATCH_SMALL", 1) != 0);
   if (!on || p.H != p.W || p.Cin != 64 || pick_bn(p.Cout) != 64) return false;
   if (p.W == 2) return dtype == PWR_BF16;     // fp32: 16 channel slots > the 8 threads a 2x2 image gets
   return p.W == 4 || p.W == 8 || p.W == 16;
 }
 
 static bool conv1x1_applicable(const ConvParams& p, int dtype) {
-  static const bool on = [] { const char* e = getenv("PWR_PATCH_1X1"); return e ? atoi(e) != 0 : true; }();
+  static const bool on = (PWR_DBG_ENV("PWR_PATCH_1X1", 1) != 0);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.W % 32 == 0 && p.H % 4 == 0 &&
          (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && p.y != nullptr;
 }
@@ -534,7 +536,7 @@ bool conv_patch_applicable(const ConvParams& p, int dtype) {
 // CU -- with 64 output channels a 4 x 32 tile does half the MFMA work per staged patch, the 8 x 32 tile stages 1.33x instead of 1.6x
 // the input and streams the weights once per 256 pixels
 static bool big64(const ConvParams& p, int dtype) {
-  static const bool on = [] { const char* e = getenv("PWR_PATCH_BIG64"); return e ? atoi(e) != 0 : false; }();   // measured: 103 vs 97 us isolated, 6.95 vs 6.90 ms/step -> off
+  static const bool on = (PWR_DBG_ENV("PWR_PATCH_BIG64", 0) != 0);   // measured: 103 vs 97 us isolated, 6.95 vs 6.90 ms/step -> off
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && pick_bn(p.Cout) == 64 &&
          p.H % 8 == 0 && p.W % 32 == 0 && p.H * p.W >= 128 * 128;
 }
@@ -564,11 +566,11 @@ template <typename T, int CIN>
 static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
-  static const bool dma = [] { const char* e = getenv("PWR_PATCH_DMA"); return e ? atoi(e) != 0 : true; }();
+  static const bool dma = (PWR_DBG_ENV("PWR_PATCH_DMA", 1) != 0);
   const_cast<ConvParams&>(p).stamps = g_stamps;
   // fp32 (parity mode) patches leave no room for a third weight stage next to a second workgroup: register staging
   if (dma && sizeof(T) == 2) {
-    static const bool big = [] { const char* e = getenv("PWR_PATCH_BIG"); return e ? atoi(e) != 0 : false; }();   // measured: 61 us vs 59 us for the 4x32 tile -> off
+    static const bool big = (PWR_DBG_ENV("PWR_PATCH_BIG", 0) != 0);   // measured: 61 us vs 59 us for the 4x32 tile -> off
     if constexpr (sizeof(T) == 2 && CIN == 128) {
       if (bn == 128 && p.H % 8 == 0 && big && !p.st_partial && !p.nb_partial) {
         // 8 waves, 8x32-pixel tile: the per-CU weight stream from L2 (the limiter of the 4x32 form) is halved
@@ -602,8 +604,7 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
   return launch_patch_cin<T, 32>(p, s);
 }
 
-void set_debug_stamps_pp(long long* ptr);
-void set_debug_stamps(long long* ptr) { g_stamps = ptr; set_debug_stamps_pp(ptr); }
+void set_debug_stamps(long long* ptr) { g_stamps = ptr; }
 
 template <int CIN>
 static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
@@ -617,7 +618,7 @@ static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
 
 // data gradient of a stride-2 3x3 conv (ConvParams::mode 1: x = dy [B,H,W,Cin], output [B,2H,2W,Cout]) as four parity-class launches
 bool conv_tr2_applicable(const ConvParams& p, int dtype) {
-  static const bool on = [] { const char* e = getenv("PWR_PATCH_TR2"); return e ? atoi(e) != 0 : true; }();
+  static const bool on = (PWR_DBG_ENV("PWR_PATCH_TR2", 1) != 0);
   return on && dtype == PWR_BF16 && p.mode == 1 && p.ksize == 3 && p.Cin == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr &&
          !p.y_nchw && !p.st_partial && !p.nb_partial && !p.in_norm;
 }

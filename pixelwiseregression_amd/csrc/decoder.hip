@@ -358,7 +358,7 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
     // 128x128 maps.  A/B switch (tools/bench_decoder.py), measured at B=128, J=42 on MI355X (profiles/r2_decoder_bench.jsonl):
     // 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU: 4.28 TB/s (default); 1 = 1024 threads x 4 vectors: 4.24 TB/s;
     // 2 = 512 x 8 held to 128 VGPRs (two workgroups per CU, a few spilled registers): 3.87 TB/s
-    static const int v = [] { const char* e = getenv("PWR_DEC_FWD128"); return e ? atoi(e) : 0; }();
+    static const int v = PWR_DBG_ENV("PWR_DEC_FWD128", 0);
     if (v == 1 && 4096 % P == 0)
       hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
     else if (v == 2)
@@ -378,7 +378,7 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
   if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int N = P * P, maps = B * J;
-  static const int sc1 = [] { const char* e = getenv("PWR_DEC_SCALAR_SC1"); return e ? atoi(e) : 0; }();   // experiment switch (tools/race_hunt.py)
+  static const int sc1 = PWR_DBG_ENV("PWR_DEC_SCALAR_SC1", 0);   // experiment switch (tools/race_hunt.py)
   if (sc1 && P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, false, true>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
   else if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
@@ -389,7 +389,7 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
     // 128x128 maps.  A/B switch, measured like the forward: 0 = 512 x 8 with everything in registers (204 VGPRs, one workgroup per
     // CU): 4.74 TB/s (default; the two-reduction form of round 1: 3.04); 1 = 1024 x 4 (108 VGPRs, one 16-wave workgroup per CU): 4.38;
     // 2 = 512 x 8 RELOAD (softmax only; 128 VGPRs with spills, two workgroups per CU): 2.51
-    static const int v = [] { const char* e = getenv("PWR_DEC_BWD128"); return e ? atoi(e) : 0; }();
+    static const int v = PWR_DBG_ENV("PWR_DEC_BWD128", 0);
     if (v == 1 && 4096 % P == 0)
       hipLaunchKernelGGL((pwr::decode_bwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
     else if (v == 2 && method == 0)

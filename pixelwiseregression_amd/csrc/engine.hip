@@ -16,10 +16,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "pwr.h"
+#include "pwr_common.h"
+#ifdef PWR_DEBUG_BUILD
+#include "pwr_debug.h"
+#endif
 
 namespace {
 
@@ -60,24 +65,27 @@ struct Ctx {
 // The side streams, their join events and the pool of fork events are PROCESS-wide (one set per device), shared by every engine:
 // HIP streams map onto a limited number of hardware queues, and every further pair of side streams kept alive by another plan (a
 // second batch size, the previous model of a sweep not yet garbage-collected) made ALL of them slower -- C3's train step took
-// 20.2 ms instead of 11.5 ms when it ran after C2's plan in the same process.  Engines run one at a time on the caller's stream, so
-// sharing is safe; the streams live as long as the process.
+// 20.2 ms instead of 11.5 ms when it ran after C2's plan in the same process.  The streams live as long as the process.
+// Threading contract (as in the reference: a single-threaded caller): the pool's creation is locked, but the
+// fork / join events are shared, so backward calls of different engines on the same device must not run concurrently.
 struct SidePool {
   hipStream_t side[Ctx::kMaxSide] = {};
   hipEvent_t ev_fork[Ctx::kForkPool] = {}, ev_join[Ctx::kMaxSide] = {};
   int n_side = -1, n_fork = 0;     // -1: not created yet
 };
-static SidePool& side_pool() {
+static std::mutex g_side_mu;
+static void side_pool_attach(Ctx& c, hipStream_t caller) {
+  // keyed by the device the CALLER's stream lives on (not the thread's current device), created once under a lock: two host
+  // threads may enter pwr_engine_backward together (ctypes drops the GIL)
+  std::lock_guard<std::mutex> lk(g_side_mu);
   static SidePool pools[16];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  return pools[dev & 15];
-}
-static void side_pool_attach(Ctx& c) {
-  SidePool& sp = side_pool();
+  int dev = 0, cur = 0;
+  (void)hipGetDevice(&cur);
+  if (hipStreamGetDevice(caller, &dev) != hipSuccess) { (void)hipGetLastError(); dev = cur; }
+  SidePool& sp = pools[dev & 15];
   if (sp.n_side < 0) {
-    const char* env = getenv("PWR_SIDE_STREAM");   // number of side streams, 0 = everything on the caller's stream
-    int want = env ? atoi(env) : 2;
+    if (dev != cur) (void)hipSetDevice(dev);
+    int want = PWR_DBG_ENV("PWR_SIDE_STREAM", 2);   // number of side streams, 0 = everything on the caller's stream
     if (want > Ctx::kMaxSide) want = Ctx::kMaxSide;
     sp.n_side = 0;
     for (int k = 0; want > 0 && k < Ctx::kForkPool; ++k) {
@@ -88,13 +96,26 @@ static void side_pool_attach(Ctx& c) {
     // workgroups to place, the chain goes first and the weight gradients fill what is left
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const char* pe = getenv("PWR_SIDE_PRIORITY");
-    const bool low = pe ? atoi(pe) != 0 : true;
+    const bool low = PWR_DBG_ENV("PWR_SIDE_PRIORITY", 1) != 0;
+    // DEBUG build: side streams confined to PWR_SIDE_CUS compute units (hipExtStreamCreateWithCUMask; pattern 0 = the first n mask
+    // bits, 1 = every (256/n)-th bit, 2 = the LAST n bits) -- the CU-partitioning experiment of tools/step_elimination.py
+    const int side_cus = PWR_DBG_ENV("PWR_SIDE_CUS", 0), side_pat = PWR_DBG_ENV("PWR_SIDE_CU_PATTERN", 0);
     for (int k = 0; sp.n_fork > 0 && k < want; ++k) {
-      if (hipStreamCreateWithPriority(&sp.side[k], hipStreamNonBlocking, low ? prio_lo : 0) != hipSuccess ||
-          hipEventCreateWithFlags(&sp.ev_join[k], hipEventDisableTiming) != hipSuccess) break;
+      hipError_t er;
+      if (side_cus > 0 && side_cus < 256) {
+        uint32_t mask[8] = {};
+        for (int i = 0; i < side_cus; ++i) {
+          const int bit = side_pat == 1 ? i * (256 / side_cus) : (side_pat == 2 ? 255 - i : i);
+          mask[bit >> 5] |= 1u << (bit & 31);
+        }
+        er = hipExtStreamCreateWithCUMask(&sp.side[k], 8, mask);
+      } else {
+        er = hipStreamCreateWithPriority(&sp.side[k], hipStreamNonBlocking, low ? prio_lo : 0);
+      }
+      if (er != hipSuccess || hipEventCreateWithFlags(&sp.ev_join[k], hipEventDisableTiming) != hipSuccess) break;
       sp.n_side = k + 1;
     }
+    if (dev != cur) (void)hipSetDevice(cur);
   }
   for (int k = 0; k < sp.n_side; ++k) { c.side[k] = sp.side[k]; c.ev_join[k] = sp.ev_join[k]; }
   for (int k = 0; k < sp.n_fork; ++k) c.ev_fork[k] = sp.ev_fork[k];
@@ -103,8 +124,17 @@ static void side_pool_attach(Ctx& c) {
   c.attached = true;
 }
 
+// DEBUG build only -- step-level timing by elimination (tools/step_elimination.py; the results are WRONG by construction):
+// bit 0: no parameter-gradient launches (everything that goes to the side streams), bit 1: no norm-backward launches,
+// bit 2: no data-gradient convs / fused ResBlock backwards.  Constant 0 in the shipped library.
+static int elim_mask() {
+  static const int m = PWR_DBG_ENV("PWR_ELIM", 0);
+  return m;
+}
+
 // run `op` on the side stream, ordered after everything enqueued so far on the main stream
 static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
+  if (elim_mask() & 1) return 0;
   if (!c.use_side || c.n_side == 0) return op(c);
   const int k = c.side_rr;
   c.side_rr = (k + 1) % c.n_side;
@@ -172,76 +202,7 @@ struct Engine {
   std::string err;
   long long generation = 0;
   Ctx ctx;
-  // ---- hipGraph replay.  A forward / backward segment is a fixed list of 100-300 launches over fixed arena addresses; issuing
-  // them one by one costs 3-4 us of host time each, more than the small-map kernels take to run.  Each call is captured once
-  // per distinct set of external pointers (inputs, outputs, output gradients: PyTorch's caching allocator hands back the same
-  // addresses every step of a steady loop) on an engine-owned stream and replayed afterwards; the caller's stream is ordered
-  // before and after it with events, so any caller stream works (including the legacy default stream, which cannot be
-  // captured itself).
-  struct GraphEntry { std::vector<const void*> key; hipGraphExec_t exec; };
-  struct GraphCache { std::vector<GraphEntry> entries; int strikes = 0, misses = 0; };
-  GraphCache gc_fwd;
-  std::vector<GraphCache> gc_bwd;
-  hipStream_t own = nullptr;
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  int use_graph = -1;   // -1 undecided, 0 off, 1 on
   bool join_each_segment = true;
-
-  bool graph_ready() {
-    if (use_graph < 0) {
-      const char* env = getenv("PWR_GRAPH");
-      use_graph = env ? (atoi(env) != 0) : 0;   // measured on MI355X / ROCm 7.2: replay 8.5 ms vs 7.7 ms per step issued directly -> opt-in
-      if (use_graph && (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess))
-        use_graph = 0;
-    }
-    return use_graph == 1;
-  }
-  // run(stream) issues the launches.  Returns its error code.
-  int run_graphed(GraphCache& gc, const std::vector<const void*>& key, void* caller, const std::function<int(void*)>& run) {
-    if (!graph_ready() || gc.strikes > 2) return run(caller);
-    hipEventRecord(ev_in, (hipStream_t)caller);
-    hipStreamWaitEvent(own, ev_in, 0);
-    int rc = 0;
-    GraphEntry* hit = nullptr;
-    for (auto& en : gc.entries) if (en.key == key) { hit = &en; break; }
-    if (hit) {
-      gc.misses = 0;
-      if (hipGraphLaunch(hit->exec, own) != hipSuccess) { gc.strikes = 99; rc = run(own); }
-    } else if (++gc.misses > 8) {   // the caller's addresses never repeat: capturing every call would cost more than it saves
-      gc.strikes = 99;
-      rc = run(own);
-    } else {
-      hipGraph_t g = nullptr;
-      hipGraphExec_t ex = nullptr;
-      bool ok = hipStreamBeginCapture(own, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (ok) {
-        rc = run(own);
-        ok = hipStreamEndCapture(own, &g) == hipSuccess && g != nullptr && rc == 0;
-      }
-      if (ok) ok = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess;
-      if (g) hipGraphDestroy(g);
-      if (ok && hipGraphLaunch(ex, own) == hipSuccess) {
-        if (gc.entries.size() >= 4) { hipGraphExecDestroy(gc.entries.front().exec); gc.entries.erase(gc.entries.begin()); }
-        gc.entries.push_back({key, ex});
-      } else {
-        (void)hipGetLastError();
-        if (ex) hipGraphExecDestroy(ex);
-        ++gc.strikes;
-        if (rc == 0) rc = run(own);     // nothing ran during the failed capture: issue directly
-      }
-    }
-    hipEventRecord(ev_out, own);
-    hipStreamWaitEvent((hipStream_t)caller, ev_out, 0);
-    return rc;
-  }
-  void destroy_graphs() {
-    for (auto& en : gc_fwd.entries) hipGraphExecDestroy(en.exec);
-    for (auto& gc : gc_bwd) for (auto& en : gc.entries) hipGraphExecDestroy(en.exec);
-    gc_fwd.entries.clear(); gc_bwd.clear();
-    if (own) { hipStreamSynchronize(own); hipStreamDestroy(own); hipEventDestroy(ev_in); hipEventDestroy(ev_out); own = nullptr; }
-  }
 
   // arena layout record (debugging aid: pwr_engine_layout)
   struct AllocRec { size_t off, bytes; std::string tag; };
@@ -323,11 +284,11 @@ struct Engine {
     // one workgroup per CU); everything else one tap per workgroup at >= 2 workgroups per CU
     const bool w3 = dtype == PWR_BF16 && k == 3 && M % 32 == 0;
     const int tiles = (w3 ? 3 : k * k) * per;
-    static const int w3_target = [] { const char* e = getenv("PWR_WGRAD3_SLOTS"); return e ? atoi(e) : 256; }();
+    static const int w3_target = PWR_DBG_ENV("PWR_WGRAD3_SLOTS", 256);
     // w3: one wave of workgroups, whole XCD groups (no tail).  The <= 64-channel kernels fit two workgroups per CU; on the big
     // stem maps (>= 2^18 pixels: 205 K steps per workgroup otherwise, at the tail of the step) they get two waves of them.
     const int target = (w3 && cout <= 64 && M >= (1 << 18)) ? 2 * w3_target : w3_target;
-    static const int tr_target = [] { const char* e = getenv("PWR_WGRAD_TR_SLOTS"); return e ? atoi(e) : 512; }();
+    static const int tr_target = PWR_DBG_ENV("PWR_WGRAD_TR_SLOTS", 512);
     int s = w3 ? (target / tiles) / 8 * 8 : (tr_target + tiles - 1) / tiles;
     if (w3 && s < 8) s = 8;
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
@@ -338,16 +299,8 @@ struct Engine {
 
   // A/B switch: bit 0 = forward statistics from the conv epilogues, bit 1 = norm-backward reductions from the data-gradient epilogues
   static int stats_mask() {
-    static const int m = [] { const char* e = getenv("PWR_CONV_STATS_MASK"); return e ? atoi(e) : 3; }();
+    static const int m = PWR_DBG_ENV("PWR_CONV_STATS_MASK", 3);
     return m;
-  }
-  // A/B switch: InstanceNorm backward with the chunk reduction spread over 8 threads per (sample, channel) and dgamma / dbeta on a side
-  // stream (pwr_norm_bwd_deferred + pwr_norm_param_grad) instead of the one-thread-per-(b, c) reduction that also does dgamma / dbeta
-  // 0 = off (measured default: 6.94 ms/step), 1 = dgamma / dbeta on a side stream (7.31 ms: 34 more forked launches per step cost more
-  // than the shorter reduction saves), 2 = dgamma / dbeta right behind on the chain
-  static int deferred_norm_grads() {
-    static const int v = [] { const char* e = getenv("PWR_NORM_BWD_PAR"); return e ? atoi(e) : 0; }();
-    return v;
   }
   // ---- norm statistics of tensor t (forward) and its backward (g -> dy, in place in t.goff, + addend)
   void norm_fwd_sizes(const Tn& t) {
@@ -376,83 +329,15 @@ struct Engine {
     Engine* E = this;
     const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
     if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
-    if (chunks > 0) {
-      static const bool dbg = getenv("PWR_DEBUG_NB") != nullptr;
-      const bool dbg_here = dbg && (scope.find("plane") != std::string::npos || scope.find("depth") != std::string::npos);
-      const size_t dP = dbg_here ? alloc((size_t)B * chunks * 2 * C * 4, "dbg_partial") : 0;
-      const size_t dS = dbg_here ? alloc((size_t)2 * B * C * 4, "dbg_S") : 0;
-      const size_t dG = dbg_here ? alloc((size_t)B * HW * C * esz, "dbg_g") : 0;
-      const int es = esz;
-      bwd_cur.push_back([=](Ctx& c) {
-        const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
-        if (dbg_here) {
-          hipMemcpyAsync(c.arena + dP, c.arena + E->*cpart, (size_t)Bc * chunks * 2 * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
-          hipMemcpyAsync(c.arena + dG, c.arena + t.goff, (size_t)Bc * HW * C * es, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
-          int rc = pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart),
-                                         chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
-                                         has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
-                                         c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
-          hipMemcpyAsync(c.arena + dS, c.arena + E->scr_S1, (size_t)Bc * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
-          hipMemcpyAsync(c.arena + dS + (size_t)Bc * C * 4, c.arena + E->scr_S2, (size_t)Bc * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)c.stream);
-          return rc;
-        }
-        if (mode == 2)   // eval-mode batch norm: statistics are constants, the plain path handles it
-          return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
-                              (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), has_addend ? c.arena + addend_goff : nullptr,
-                              c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
-        if (mode == 0 && deferred_norm_grads()) {
-          // S1 / S2 + apply on the chain; dgamma / dbeta (a reduction over the batch of the per-sample sums) beside it
-          int rc = pwr_norm_bwd_deferred(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart), chunks,
-                                         (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), (float*)(c.arena + n.sums),
-                                         has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
-          if (rc) return rc;
-          if (deferred_norm_grads() == 2)
-            return pwr_norm_param_grad((float*)(c.arena + n.sums), c.grads + n.gamma, c.grads + n.beta, Bc, C, 0, c.stream);
-          return run_on_side(c, [=](Ctx& c2) {
-            return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
-          });
-        }
+    // (Measured and dropped, DESIGN.md section 4: one-block-per-sample, split and deferred-dgamma forms of this step.)
+    bwd_cur.push_back([=](Ctx& c) {
+      if (elim_mask() & 2) return 0;
+      const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
+      if (chunks > 0 && mode != 2)   // (eval-mode batch norm: statistics are constants, the plain path handles it)
         return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart),
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
                                          c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
-      });
-      return;
-    }
-    // measured on MI355X (C2): the split form (apply blocks combine the partials; dgamma/dbeta on the side stream) is SLOWER
-    // than the plain three-launch form, 10.7 vs 9.9 ms per step -> opt-in only
-    static const bool split = [] { const char* e = getenv("PWR_NORM_BWD_SPLIT"); return e ? atoi(e) != 0 : false; }();
-    const size_t bpart = (nm == 0 && split) ? alloc(pwr_norm_bwd_partial_bytes(B, HW, C)) : 0;
-    bwd_cur.push_back([=](Ctx& c) {
-      int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
-      static const int small_max = [] { const char* e = getenv("PWR_NORM_BWD_SMALL"); return e ? atoi(e) : 0; }();   // measured on MI355X: 9.94 ms/step off, 10.12 at 16, 10.22 at 64 -> off
-      if (mode == 0 && HW <= small_max) {   // one launch on the critical path; dgamma / dbeta beside it
-        int rc = pwr_norm_bwd_small(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + n.sums),
-                                    has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
-        if (rc) return rc;
-        return run_on_side(c, [=](Ctx& c2) {
-          return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
-        });
-      }
-      if (mode == 0 && split) {   // 2 launches on the critical path; dgamma / dbeta beside it
-        int rc = pwr_norm_bwd_main(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + bpart),
-                                   has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
-        if (rc) return rc;
-        return run_on_side(c, [=](Ctx& c2) {
-          return pwr_norm_bwd_params((float*)(c2.arena + bpart), c2.grads + n.gamma, c2.grads + n.beta, 0, Bc, HW, C, c2.stream);
-        });
-      }
-      if (mode == 0 && deferred_norm_grads()) {
-        int rc = pwr_norm_bwd_deferred(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial), 0,
-                                       (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2), (float*)(c.arena + n.sums),
-                                       has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, 1, Bc, HW, C, dt, c.stream);
-        if (rc) return rc;
-        if (deferred_norm_grads() == 2)
-          return pwr_norm_param_grad((float*)(c.arena + n.sums), c.grads + n.gamma, c.grads + n.beta, Bc, C, 0, c.stream);
-        return run_on_side(c, [=](Ctx& c2) {
-          return pwr_norm_param_grad((float*)(c2.arena + n.sums), c2.grads + n.gamma, c2.grads + n.beta, Bc, C, 0, c2.stream);
-        });
-      }
       return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                           (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                           has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0,
@@ -550,6 +435,7 @@ struct Engine {
       const int nm = norm_mode;
       const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
       bwd_cur.push_back([=](Ctx& c) {
+        if (elim_mask() & 4) return 0;
         const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
         if (mode == 2)
           return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W,
@@ -561,6 +447,7 @@ struct Engine {
       return chunks;
     }
     bwd_cur.push_back([=](Ctx& c) {
+      if (elim_mask() & 4) return 0;
       if (cv.stride == 1)
         return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0,
                             accumulate_dx ? c.arena + x.goff : nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W, cv.Cout, cv.Cin, cv.k,
@@ -574,19 +461,6 @@ struct Engine {
 
   // ---- ResBlock (model.py:6-23)
   struct ResB { NormL na, nb, nc; ConvL ca, cb, cc; Tn t1, t2; };
-  // ---- the inner hourglass below the 32x32 level as one launch per direction (pwr_subhourglass_fwd / _bwd): while `sub` is
-  // set, the fused ResBlocks, pools and up-samples being planned are recorded as steps instead of (bit 0: forward, bit 1:
-  // backward of PWR_SUBHG) being pushed as launches of their own.  The backward program is the forward one reversed.
-  // Default 0 = off, measured on one box: the forward kernel takes 177 us against 160 us for the eight block kernels + ~27 us for the
-  // six pool / up-sample launches it replaces (inference 2.015 vs 2.010 ms: the host issues far ahead of the GPU, so the launches were
-  // already back to back on the stream, and what is left is the chain of dependent global / LDS round trips INSIDE the blocks); the backward kernel delays the
-  // region's weight gradients until all of its data gradients are done (train step 7.17 vs 6.89 ms).
-  struct SubStepH { int kind = 0, logw = 0, block = 0; Tn a, b, c; };   // POOL: a = input, b = pooled, c = the level's output (its
-                                                                        // gradient is the skip addend); UP: a = h, b = skip, c = out
-  struct SubCollect { std::vector<ResB> blocks; std::vector<Tn> bx, bout; std::vector<size_t> bsum; std::vector<SubStepH> steps; };
-  SubCollect* sub = nullptr;
-  int subhg_mask = [] { const char* e = getenv("PWR_SUBHG"); return e ? atoi(e) : 0; }();
-  static int log2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
   Tn resblock(const Tn& x) {
     const bool tr = training;
     ResB r;
@@ -625,13 +499,7 @@ struct Engine {
     if (tr) { r.t1 = tensor(x.H, x.W, Fh, true); r.t2 = tensor(x.H, x.W, Fh, true); }
     Tn out = tensor(x.H, x.W, x.C, tr);
     const ResB rb = r;
-    if (sub) {
-      SubStepH st;
-      st.kind = PWR_SUBHG_BLOCK; st.logw = log2i(x.W); st.block = (int)sub->blocks.size();
-      sub->blocks.push_back(rb); sub->bx.push_back(x); sub->bout.push_back(out); sub->bsum.push_back(0);
-      sub->steps.push_back(st);
-    }
-    if (!(sub && (subhg_mask & 1))) fwd.push_back([=](Ctx& c) {
+    fwd.push_back([=](Ctx& c) {
       return pwr_resblock_fwd_small(c.arena + x.off, tr ? c.arena + rb.t1.off : nullptr, tr ? c.arena + rb.t2.off : nullptr, c.arena + out.off,
                                     c.packs + rb.ca.pack_f, c.packs + rb.cb.pack_f, c.packs + rb.cc.pack_f, c.params + rb.ca.b,
                                     c.params + rb.cb.b, c.params + rb.cc.b, c.params + rb.na.gamma, c.params + rb.na.beta,
@@ -643,9 +511,9 @@ struct Engine {
       std::vector<Op> blk;
       std::swap(blk, bwd_cur);
       const size_t bsum = alloc((size_t)B * x.C * 4);           // per-sample column sums of out.g (bias gradient of conv c)
-      if (sub) sub->bsum.back() = bsum;
       conv_bwd(r.t2, &r.nc, r.cc, out, false, false, false);    // side stream: dW_c (needs only out.g)
-      if (!(sub && (subhg_mask & 2))) bwd_cur.push_back([=](Ctx& c) {
+      bwd_cur.push_back([=](Ctx& c) {
+        if (elim_mask() & 4) return 0;
         return pwr_resblock_bwd_small(c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
                                       c.arena + rb.t1.goff, c.arena + rb.t2.goff, c.packs + rb.cc.pack_d, c.packs + rb.cb.pack_d,
                                       c.packs + rb.ca.pack_d, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
@@ -674,115 +542,38 @@ struct Engine {
   }
 
   // ---- Hourglass (model.py:25-47)
+  // (One launch per direction for the whole region below the 32x32 level was built and measured in round 2: bit-identical, not
+  // faster -- DESIGN.md section 4 -- and removed in round 3.)
   Tn hourglass(const Tn& x, int lvl) {
     const bool tr = training;
     scope = "s" + std::to_string(cur_stage) + ".hg" + std::to_string(lvl);
     const int Bc = B, dt = dtype;
     Tn a = resblock(x);
     Tn h0 = tensor(a.H / 2, a.W / 2, a.C, tr);
-    const bool in_sub = sub != nullptr;                  // this level's pool / up-sample belong to an enclosing fused region
-    int pool_step = -1;
-    if (in_sub) {
-      SubStepH st;
-      st.kind = PWR_SUBHG_POOL; st.logw = log2i(a.W); st.a = a; st.b = h0;
-      pool_step = (int)sub->steps.size();
-      sub->steps.push_back(st);
-    }
-    if (!(in_sub && (subhg_mask & 1)))
-      fwd.push_back([=](Ctx& c) { return pwr_maxpool_fwd(c.arena + a.off, c.arena + h0.off, Bc, a.H, a.W, a.C, dt, c.stream); });
+    fwd.push_back([=](Ctx& c) { return pwr_maxpool_fwd(c.arena + a.off, c.arena + h0.off, Bc, a.H, a.W, a.C, dt, c.stream); });
     // the ops pushed by resblock(x) must run after everything below: take them out, put them back at the end
     std::vector<Op> after_a;
     std::swap(after_a, bwd_cur);
-    // everything between this level's pool and its up-sample lives on maps of 16x16 .. 2x2: one launch per direction
-    SubCollect col;
-    const bool own = !in_sub && subhg_mask != 0 && h0.H == 16 && h0.W == 16 && lvl <= 3 &&
-                     pwr_resblock_small_supported(h0.H, h0.W, h0.C, norm_mode, dtype);
-    if (own) sub = &col;
     Tn h1 = lvl > 0 ? hourglass(h0, lvl - 1) : resblock(h0);
     std::vector<Op> after_inner;
     std::swap(after_inner, bwd_cur);
     Tn h2 = resblock(h1);
     std::vector<Op> after_h2;
     std::swap(after_h2, bwd_cur);
-    if (own) sub = nullptr;
     Tn out = tensor(a.H, a.W, a.C, tr);
-    if (in_sub) {
-      sub->steps[pool_step].c = out;
-      SubStepH st;
-      st.kind = PWR_SUBHG_UP; st.logw = log2i(a.W); st.a = h2; st.b = a; st.c = out;
-      sub->steps.push_back(st);
-    }
-    if (own && (subhg_mask & 1)) fwd.push_back(subhg_fwd_op(col));
-    if (!(in_sub && (subhg_mask & 1)))
-      fwd.push_back([=](Ctx& c) {
-        return pwr_upsample_add_fwd(c.arena + h2.off, c.arena + a.off, c.arena + out.off, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream);
-      });
+    fwd.push_back([=](Ctx& c) {
+      return pwr_upsample_add_fwd(c.arena + h2.off, c.arena + a.off, c.arena + out.off, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream);
+    });
     if (tr) {
-      if (!(in_sub && (subhg_mask & 2)))
-        bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
-      if (own && (subhg_mask & 2)) bwd_cur.push_back(subhg_bwd_op(col));      // all data gradients of the region; its blocks left
-                                                                              // only their side-stream ops in after_h2 / after_inner
+      bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
       bwd_cur.insert(bwd_cur.end(), after_h2.begin(), after_h2.end());        // resblock h1 -> h2
       bwd_cur.insert(bwd_cur.end(), after_inner.begin(), after_inner.end());  // inner
-      if (!(in_sub && (subhg_mask & 2)))
-        bwd_cur.push_back([=](Ctx& c) {
-          return pwr_maxpool_bwd(c.arena + a.off, c.arena + h0.goff, c.arena + out.goff, c.arena + a.goff, Bc, a.H, a.W, a.C, dt, c.stream);
-        });
+      bwd_cur.push_back([=](Ctx& c) {
+        return pwr_maxpool_bwd(c.arena + a.off, c.arena + h0.goff, c.arena + out.goff, c.arena + a.goff, Bc, a.H, a.W, a.C, dt, c.stream);
+      });
       bwd_cur.insert(bwd_cur.end(), after_a.begin(), after_a.end());          // resblock x -> a
     }
     return out;
-  }
-  Op subhg_fwd_op(const SubCollect& col) {
-    const bool tr = training;
-    const int Bc = B, dt = dtype, C = F;
-    if (col.blocks.size() > PWR_SUBHG_MAX_BLOCKS || col.steps.size() > PWR_SUBHG_MAX_STEPS) err = "sub-hourglass program too long";
-    return [=](Ctx& c) {
-      pwr_resblock_fwd_args blk[PWR_SUBHG_MAX_BLOCKS];
-      pwr_subhg_step st[PWR_SUBHG_MAX_STEPS];
-      for (size_t k = 0; k < col.blocks.size(); ++k) {
-        const ResB& rb = col.blocks[k];
-        blk[k] = pwr_resblock_fwd_args{c.arena + col.bx[k].off, tr ? c.arena + rb.t1.off : nullptr, tr ? c.arena + rb.t2.off : nullptr,
-                                       c.arena + col.bout[k].off, c.packs + rb.ca.pack_f, c.packs + rb.cb.pack_f, c.packs + rb.cc.pack_f,
-                                       c.params + rb.ca.b, c.params + rb.cb.b, c.params + rb.cc.b, c.params + rb.na.gamma,
-                                       c.params + rb.na.beta, c.params + rb.nb.gamma, c.params + rb.nb.beta, c.params + rb.nc.gamma,
-                                       c.params + rb.nc.beta, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
-                                       (float*)(c.arena + rb.nc.state)};
-      }
-      for (size_t i = 0; i < col.steps.size(); ++i) {
-        const SubStepH& h = col.steps[i];
-        st[i] = pwr_subhg_step{h.kind, h.logw, h.block, 0, nullptr, nullptr, nullptr, nullptr};
-        if (h.kind == PWR_SUBHG_POOL) { st[i].s0 = c.arena + h.a.off; st[i].d = c.arena + h.b.off; }
-        else if (h.kind == PWR_SUBHG_UP) { st[i].s0 = c.arena + h.a.off; st[i].s1 = c.arena + h.b.off; st[i].d = c.arena + h.c.off; }
-      }
-      return pwr_subhourglass_fwd(blk, (int)col.blocks.size(), st, (int)col.steps.size(), Bc, C, 1e-5f, dt, c.stream);
-    };
-  }
-  Op subhg_bwd_op(const SubCollect& col) {
-    const int Bc = B, dt = dtype, C = F;
-    return [=](Ctx& c) {
-      pwr_resblock_bwd_args blk[PWR_SUBHG_MAX_BLOCKS];
-      pwr_subhg_step st[PWR_SUBHG_MAX_STEPS];
-      for (size_t k = 0; k < col.blocks.size(); ++k) {
-        const ResB& rb = col.blocks[k];
-        const Tn &x = col.bx[k], &out = col.bout[k];
-        blk[k] = pwr_resblock_bwd_args{c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
-                                       c.arena + rb.t1.goff, c.arena + rb.t2.goff, c.packs + rb.cc.pack_d, c.packs + rb.cb.pack_d,
-                                       c.packs + rb.ca.pack_d, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
-                                       (float*)(c.arena + rb.nc.state), (float*)(c.arena + rb.na.sums), (float*)(c.arena + rb.nb.sums),
-                                       (float*)(c.arena + rb.nc.sums), (float*)(c.arena + col.bsum[k])};
-      }
-      const size_t n = col.steps.size();
-      for (size_t i = 0; i < n; ++i) {
-        const SubStepH& h = col.steps[n - 1 - i];       // the forward program, reversed
-        st[i] = pwr_subhg_step{h.kind, h.logw, h.block, 0, nullptr, nullptr, nullptr, nullptr};
-        if (h.kind == PWR_SUBHG_POOL) {                 // a.g = route(h0.g) + out.g (the level's skip connection)
-          st[i].s0 = c.arena + h.a.off; st[i].s1 = c.arena + h.b.goff; st[i].s2 = c.arena + h.c.goff; st[i].d = c.arena + h.a.goff;
-        } else if (h.kind == PWR_SUBHG_UP) {            // h2.g = sum of out.g over each 2x2
-          st[i].s0 = c.arena + h.c.goff; st[i].d = c.arena + h.a.goff;
-        }
-      }
-      return pwr_subhourglass_bwd(blk, (int)col.blocks.size(), st, (int)n, Bc, C, dt, c.stream);
-    };
   }
 
   // ---- one regression head (model.py:54-65 / 103-114) ending in an NCHW fp32 map
@@ -1051,9 +842,9 @@ extern "C" void* pwr_engine_create(const int* cfg, int B, int dtype, int trainin
 extern "C" void pwr_engine_destroy(void* h) {
   Engine* e = (Engine*)h;
   for (int k = 0; k < e->ctx.n_side; ++k) hipStreamSynchronize(e->ctx.side[k]);    // (shared streams: drained, not destroyed)
-  e->destroy_graphs();
   delete e;
 }
+#ifdef PWR_DEBUG_BUILD
 // Debugging aid: the arena layout as text lines "offset bytes tag".  Returns the number of bytes needed (incl. the NUL);
 // writes at most cap bytes.
 extern "C" size_t pwr_engine_layout(void* h, char* buf, size_t cap) {
@@ -1064,6 +855,7 @@ extern "C" size_t pwr_engine_layout(void* h, char* buf, size_t cap) {
   return s.size() + 1;
 }
 extern "C" void pwr_engine_set_join(void* h, int each_segment) { ((Engine*)h)->join_each_segment = each_segment != 0; }
+#endif   // PWR_DEBUG_BUILD
 extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
 extern "C" size_t pwr_engine_pack_bytes(void* h) { return ((Engine*)h)->pack_bytes; }
 extern "C" int pwr_engine_num_segments(void* h) { return (int)((Engine*)h)->bwd.size(); }
@@ -1084,12 +876,6 @@ extern "C" int pwr_engine_get_descs(void* h, void* host_dst) {
 
 extern "C" int pwr_engine_bind(void* h, void* arena, void* packs, const float* params, float* grads, float* buffers) {
   Engine* e = (Engine*)h;
-  if (e->ctx.arena != (char*)arena || e->ctx.packs != (char*)packs || e->ctx.params != params || e->ctx.grads != grads ||
-      e->ctx.buffers != buffers) {   // captured graphs hold the old addresses
-    for (auto& en : e->gc_fwd.entries) hipGraphExecDestroy(en.exec);
-    e->gc_fwd.entries.clear();
-    for (auto& gc : e->gc_bwd) { for (auto& en : gc.entries) hipGraphExecDestroy(en.exec); gc.entries.clear(); }
-  }
   e->ctx.arena = (char*)arena; e->ctx.packs = (char*)packs; e->ctx.params = params; e->ctx.grads = grads; e->ctx.buffers = buffers;
   return 0;
 }
@@ -1121,9 +907,9 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
     }
     return 0;
   };
-  std::vector<const void*> key = {img, label, mask, (const void*)(intptr_t)(training + 1)};
-  for (int s = 0; s < 3 * e->stages; ++s) key.push_back(outs[s]);
-  const int rc = e->run_graphed(e->gc_fwd, key, stream, run);
+  // (hipGraph capture + replay of this launch list was measured in round 1: 8.5 vs 7.7 ms per step on ROCm 7.2 -- the host issues
+  // a step's launches in 2.6 ms, the step is not launch-bound -- and removed in round 3.)
+  const int rc = run(stream);
   c.stream = stream;
   return rc;
 }
@@ -1139,7 +925,7 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
   for (int s = 0; s < e->stages; ++s) {
     c.g_p[s] = (const float*)gouts[3 * s]; c.g_D[s] = (const float*)gouts[3 * s + 1]; c.g_uvd[s] = (const float*)gouts[3 * s + 2];
   }
-  if (!c.attached) side_pool_attach(c);
+  if (!c.attached) side_pool_attach(c, (hipStream_t)stream);
   auto run = [&](void* st) -> int {
     c.stream = st;
     c.side_rr = 0;
@@ -1153,9 +939,9 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
       rc = ops[i](c);
       if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
     }
-    // join: the parameter gradients are complete before anything later on the stream.  Per segment when the caller all-reduces
-    // each segment's slice as it finishes (data-parallel mode, pwr_engine_set_join); otherwise once, after the last segment
-    // (1 % faster: the stem's data-gradient chain does not wait for stage 0's weight gradients).
+    // join: the parameter gradients of this segment are complete before anything later on the stream (the caller all-reduces each
+    // segment's slice as it finishes).  Joining once after the last segment is 1 % faster on one GPU; it is the configuration under
+    // which round 1's rare non-reproducible step occurred and exists in the debug build only (pwr_engine_set_join, pwr_debug.h).
     const bool join_now = e->join_each_segment || seg + 1 == (int)e->bwd.size();
     for (int k = 0; join_now && c.use_side && k < c.n_side; ++k) {
       hipEventRecord(c.ev_join[k], c.side[k]);
@@ -1163,13 +949,7 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
     }
     return rc;
   };
-  if (e->gc_bwd.size() != e->bwd.size()) e->gc_bwd.resize(e->bwd.size());
-  std::vector<const void*> key = {(const void*)(intptr_t)n_grad_floats, (const void*)(intptr_t)(c.training + 1)};
-  for (int s = 0; s < 3 * e->stages; ++s) key.push_back(gouts[s]);
-  // the backward also reads what the forward call was given: inputs (stem weight gradient, decoder) and outputs (decoder)
-  key.push_back(c.img); key.push_back(c.label); key.push_back(c.mask);
-  for (int s = 0; s < e->stages; ++s) { key.push_back(c.out_p[s]); key.push_back(c.out_D[s]); key.push_back(c.out_uvd[s]); }
-  const int rc = e->run_graphed(e->gc_bwd[seg], key, stream, run);
+  const int rc = run(stream);
   c.stream = stream;
   return rc;
 }

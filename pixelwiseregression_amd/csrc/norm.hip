@@ -405,104 +405,6 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   }
 }
 
-// Small maps (HW <= 512): ONE block owns a whole sample, so the two reductions and the element-wise apply of the
-// InstanceNorm backward fit in one launch; the per-sample sums go to `sums` [B][2][C] for the (off-critical-path)
-// dgamma / dbeta reduction over the batch.
-template <typename T>
-__global__ __launch_bounds__(256) void norm_bwd_small_kernel(const T* __restrict__ g, const T* __restrict__ y,
-                                                             const float* __restrict__ state, float* __restrict__ sums,
-                                                             const T* __restrict__ addend, T* __restrict__ dy, int B, int HW, int C,
-                                                             int relu) {
-  constexpr int EP = Elem<T>::kPer16B;
-  typedef typename Vec16<T>::type V;
-  extern __shared__ float red[];   // [pl][2][C] + [2][C]
-  const int b = blockIdx.x;
-  const int cpp = C / EP, pl = 256 / cpp;
-  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
-  float* tot = red + (size_t)pl * 2 * C;
-  const size_t base = (size_t)b * HW * C;
-  const size_t plane = (size_t)B * C;
-  float mu[EP], rs[EP], sc[EP], sh[EP], s1[EP], s2[EP];
-#pragma unroll
-  for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  if (pj < pl) {
-#pragma unroll
-    for (int e = 0; e < EP; ++e) {
-      const int c = b * C + cq * EP + e;
-      mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
-    }
-#pragma unroll 2
-    for (int pp = pj; pp < HW; pp += pl) {
-      V gv = *reinterpret_cast<const V*>(g + base + (size_t)pp * C + cq * EP);
-      V yv = *reinterpret_cast<const V*>(y + base + (size_t)pp * C + cq * EP);
-#pragma unroll
-      for (int e = 0; e < EP; ++e) {
-        const float yy = Elem<T>::to_f(yv[e]);
-        float gg = Elem<T>::to_f(gv[e]);
-        if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
-        s1[e] += gg;
-        s2[e] = fmaf(gg, (yy - mu[e]) * rs[e], s2[e]);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < EP; ++e) {
-      red[(pj * 2 + 0) * C + cq * EP + e] = s1[e];
-      red[(pj * 2 + 1) * C + cq * EP + e] = s2[e];
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    float t = 0.f;
-    for (int j = 0; j < pl; ++j) t += red[j * 2 * C + i];
-    tot[i] = t;
-    sums[(size_t)b * 2 * C + i] = t;
-  }
-  __syncthreads();
-  if (pj >= pl) return;
-  const float inv = 1.f / (float)HW;
-#pragma unroll
-  for (int e = 0; e < EP; ++e) { s1[e] = tot[cq * EP + e] * inv; s2[e] = tot[C + cq * EP + e] * inv; }
-#pragma unroll 2
-  for (int pp = pj; pp < HW; pp += pl) {
-    const size_t off = base + (size_t)pp * C + cq * EP;
-    V gv = *reinterpret_cast<const V*>(g + off);
-    V yv = *reinterpret_cast<const V*>(y + off);
-    V av = {};
-    if (addend) av = *reinterpret_cast<const V*>(addend + off);
-    V o;
-#pragma unroll
-    for (int e = 0; e < EP; ++e) {
-      const float yy = Elem<T>::to_f(yv[e]);
-      float gg = Elem<T>::to_f(gv[e]);
-      if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
-      const float xn = (yy - mu[e]) * rs[e];
-      float r = sc[e] * (gg - s1[e] - xn * s2[e]);
-      if (addend) r += Elem<T>::to_f(av[e]);
-      o[e] = Elem<T>::from_f(r);
-    }
-    *reinterpret_cast<V*>(dy + off) = o;
-  }
-}
-
-// dgamma[c] (+)= sum_b sums[b][1][c]; dbeta[c] (+)= sum_b sums[b][0][c]   (fixed order)
-__global__ void norm_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-                                       int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float t1 = 0.f, t2 = 0.f;
-  int b = 0;
-  for (; b + 8 <= B; b += 8) {
-    float a[8], q[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { a[u] = sums[((size_t)(b + u) * 2 + 0) * C + c]; q[u] = sums[((size_t)(b + u) * 2 + 1) * C + c]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { t1 += a[u]; t2 += q[u]; }
-  }
-  for (; b < B; ++b) { t1 += sums[((size_t)b * 2 + 0) * C + c]; t2 += sums[((size_t)b * 2 + 1) * C + c]; }
-  dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
-  dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
-}
-
 static inline int norm_chunks(int B, int HW) {
   int n = (1024 + B - 1) / B;
   int maxc = (HW + 31) / 32;
@@ -545,8 +447,8 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   // Measured on MI355X (BASELINE C2): the in-kernel hand-off costs more than the launch it saves (1024 blocks x release
   // fence): train step 13.0 ms fused vs 12.6 ms as two launches.  So it is opt-in; small maps, where ONE block owns the
   // whole sample and no hand-off is needed, always take the single-launch form.
-  static const bool fuse = [] { const char* e = getenv("PWR_NORM_FUSED"); return e ? atoi(e) != 0 : false; }();
-  static const int fwd_small = [] { const char* e = getenv("PWR_NORM_FWD_SMALL"); return e ? atoi(e) : 512; }();
+  const bool fuse = false;     // (measured: see above; the hand-off form is unreachable in the shipped configuration)
+  static const int fwd_small = PWR_DBG_ENV("PWR_NORM_FWD_SMALL", 512);
   if (mode == 0 && HW <= fwd_small) {
     if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t, true>), dim3(1, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
     else hipLaunchKernelGGL((norm_stats_fused_kernel<float, true>), dim3(1, B), dim3(256), sh, s, (const float*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
@@ -682,41 +584,6 @@ __global__ __launch_bounds__(256) void norm_finalize_chunks_par_kernel(const flo
   }
 }
 
-// InstanceNorm backward reductions with the pixel chunks of one (sample, channel) spread over 8 threads (block = 32 channels x 8 chunk
-// groups, grid = (C/32, B): 128 blocks at C2 instead of the 16 of norm_bwd_sum_kernel, whose threads each walked all chunks of one
-// (b, c) -- 7.4 us on the critical chain 34 times per step).  Writes S1, S2 = sums / HW for the apply kernel and the raw per-sample
-// sums to `sums` [B][2][C]; dgamma / dbeta are reduced over the batch from `sums` by pwr_norm_param_grad, off the critical path.
-__global__ __launch_bounds__(256) void norm_bwd_sum_par_kernel(const float* __restrict__ partial, float* __restrict__ S1, float* __restrict__ S2,
-                                                               float* __restrict__ sums, int HW, int C, int nchunks) {
-  __shared__ float r1[8][33], r2[8][33];
-  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int b = blockIdx.y, c = blockIdx.x * 32 + cl;
-  float s1 = 0.f, s2 = 0.f;
-  if (c < C) {
-    const float* pp = partial + ((size_t)b * nchunks * 2) * C + c;
-    for (int k0 = grp; k0 < nchunks; k0 += 64) {       // this thread's chunks: grp, grp + 8, ...; 8 of them in flight
-      float a[8], q[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = k0 + 8 * u;
-        const bool ok = k < nchunks;
-        a[u] = ok ? pp[((size_t)k * 2 + 0) * C] : 0.f; q[u] = ok ? pp[((size_t)k * 2 + 1) * C] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += q[u]; }
-    }
-  }
-  r1[grp][cl] = s1; r2[grp][cl] = s2;
-  __syncthreads();
-  if (grp == 0 && c < C) {
-    float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { a1 += r1[t][cl]; a2 += r2[t][cl]; }
-    S1[(size_t)b * C + c] = a1 / (float)HW; S2[(size_t)b * C + c] = a2 / (float)HW;
-    sums[((size_t)b * 2 + 0) * C + c] = a1; sums[((size_t)b * 2 + 1) * C + c] = a2;
-  }
-}
-
 }  // namespace pwr
 
 extern "C" int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
@@ -724,7 +591,7 @@ extern "C" int pwr_norm_finalize_partial(const float* partial, int chunks, const
                                          float eps, float momentum, void* stream) {
   if ((mode != 0 && mode != 1) || chunks < 1 || HW % chunks) return PWR_EINVAL;
   const int n = mode == 1 ? C : B * C;
-  static const bool par = [] { const char* e = getenv("PWR_NORM_PAR"); return e ? atoi(e) != 0 : true; }();
+  static const bool par = (PWR_DBG_ENV("PWR_NORM_PAR", 1) != 0);
   if (mode == 0 && par && chunks % 8 == 0 && chunks >= 16)
     hipLaunchKernelGGL(norm_finalize_chunks_par_kernel, dim3((C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, state, B,
                        HW, C, chunks, eps);
@@ -788,86 +655,5 @@ extern "C" int pwr_norm_bwd_from_partial(const void* g, const void* y, const flo
     hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
                        S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
   }
-  return (int)hipGetLastError();
-}
-
-// InstanceNorm (+ReLU) backward with the parameter gradients DEFERRED: the two reductions come from `partial` (rows per sample:
-// `chunks` when a data-gradient conv's epilogue wrote them, pwr_conv_fwd_stats; 0 = compute them here from (g, y) first), S1 / S2 and
-// the apply run on `stream`, and the per-sample sums go to `sums` [B][2][C] for pwr_norm_param_grad (any stream, any time later).
-extern "C" int pwr_norm_bwd_deferred(const void* g, const void* y, const float* state, float* partial, int chunks, float* S1, float* S2,
-                                     float* sums, const void* addend, void* dy, int relu, int B, int HW, int C, int dtype, void* stream) {
-  const int EP = dtype == PWR_BF16 ? 8 : 4;
-  if (C % EP || C / EP > 256 || chunks < 0) return PWR_EUNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  const int nch = norm_chunks(B, HW);
-  int rows = chunks;
-  if (chunks == 0) {
-    const int pl = 256 / (C / EP);
-    const size_t sh = (size_t)pl * 2 * C * 4;
-    partial = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + norm_counter_bytes(B));
-    if (dtype == PWR_BF16)
-      hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y, state, B, partial, HW, C, nch, relu);
-    else
-      hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state, B, partial, HW, C, nch, relu);
-    rows = nch;
-  }
-  hipLaunchKernelGGL(norm_bwd_sum_par_kernel, dim3((C + 31) / 32, B), dim3(256), 0, s, partial, S1, S2, sums, HW, C, rows);
-  if (dtype == PWR_BF16)
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, false>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B, S1, S2,
-                       (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
-  else
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B, S1, S2,
-                       (const float*)addend, (float*)dy, HW, C, nch, relu);
-  return (int)hipGetLastError();
-}
-
-// The same for InstanceNorm as two entry points, so that the batch reduction of dgamma / dbeta can leave the critical path:
-//   pwr_norm_bwd_main:   partial sums (written to `partial`, which must stay untouched until pwr_norm_bwd_params ran)
-//                        + apply; the apply blocks combine the partials of their sample themselves (2 launches)
-//   pwr_norm_bwd_params: dgamma / dbeta from `partial` (any stream, any time later)
-extern "C" size_t pwr_norm_bwd_partial_bytes(int B, int HW, int C) { return (size_t)B * norm_chunks(B, HW) * 2 * C * sizeof(float); }
-
-extern "C" int pwr_norm_bwd_main(const void* g, const void* y, const float* state, float* partial, const void* addend, void* dy,
-                                 int relu, int B, int HW, int C, int dtype, void* stream) {
-  const int EP = dtype == PWR_BF16 ? 8 : 4;
-  if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  const int nch = norm_chunks(B, HW);
-  const int pl = 256 / (C / EP);
-  const size_t sh = (size_t)pl * 2 * C * 4;
-  if (dtype == PWR_BF16) {
-    hipLaunchKernelGGL((norm_bwd_partial_kernel<bf16_t>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)g, (const bf16_t*)y, state, B, partial, HW, C, nch, relu);
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, true>), dim3(nch, B), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, state, B,
-                       partial, nullptr, (const bf16_t*)addend, (bf16_t*)dy, HW, C, nch, relu);
-  } else {
-    hipLaunchKernelGGL((norm_bwd_partial_kernel<float>), dim3(nch, B), dim3(256), sh, s, (const float*)g, (const float*)y, state, B, partial, HW, C, nch, relu);
-    hipLaunchKernelGGL((norm_bwd_apply_kernel<float, true>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
-                       partial, nullptr, (const float*)addend, (float*)dy, HW, C, nch, relu);
-  }
-  return (int)hipGetLastError();
-}
-
-extern "C" int pwr_norm_bwd_params(const float* partial, float* dgamma, float* dbeta, int accumulate, int B, int HW, int C, void* stream) {
-  const int nch = norm_chunks(B, HW);
-  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, (float*)nullptr, (float*)nullptr,
-                     dgamma, dbeta, B, HW, C, nch, 0, accumulate);
-  return (int)hipGetLastError();
-}
-
-// InstanceNorm + ReLU backward for small maps (HW <= 512) in one launch; `sums` ([B][2][C] floats) receives the per-sample
-// reductions for pwr_norm_param_grad, which may run later / on another stream.
-extern "C" int pwr_norm_bwd_small(const void* g, const void* y, const float* state, float* sums, const void* addend, void* dy, int relu,
-                                  int B, int HW, int C, int dtype, void* stream) {
-  const int EP = dtype == PWR_BF16 ? 8 : 4;
-  if (C % EP || C / EP > 256 || HW > 512) return PWR_EUNSUPPORTED;
-  const int pl = 256 / (C / EP);
-  const size_t sh = ((size_t)pl * 2 * C + 2 * C) * 4;
-  if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_bwd_small_kernel<bf16_t>), dim3(B), dim3(256), sh, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)y, state, sums, (const bf16_t*)addend, (bf16_t*)dy, B, HW, C, relu);
-  else hipLaunchKernelGGL((norm_bwd_small_kernel<float>), dim3(B), dim3(256), sh, (hipStream_t)stream, (const float*)g, (const float*)y, state, sums, (const float*)addend, (float*)dy, B, HW, C, relu);
-  return (int)hipGetLastError();
-}
-
-extern "C" int pwr_norm_param_grad(const float* sums, float* dgamma, float* dbeta, int B, int C, int accumulate, void* stream) {
-  hipLaunchKernelGGL(norm_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, dgamma, dbeta, B, C, accumulate);
   return (int)hipGetLastError();
 }

@@ -13,6 +13,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// Experiment switches exist only in the DEBUG build (-DPWR_DEBUG_BUILD: tools/build_debug.py -> tools/_build/libpwr_hip_dbg.so, loaded
+// by tools/dbglib.py).  The shipped library has ONE configuration: in it PWR_DBG_ENV("X", d) is the constant d, no environment
+// variable is read, and the branches of the other values fold away.  Measured negative results are recorded in DESIGN.md.
+#ifdef PWR_DEBUG_BUILD
+#include <cstdlib>
+static inline int pwr_dbg_env_(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define PWR_DBG_ENV(name, dflt) pwr_dbg_env_(name, dflt)
+#else
+#define PWR_DBG_ENV(name, dflt) (dflt)
+#endif
+
 // dtype tags of the C ABI (include/pwr.h)
 #define PWR_F32 0
 #define PWR_BF16 1

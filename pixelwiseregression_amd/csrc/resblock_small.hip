@@ -66,11 +66,11 @@ struct RbWaves {
 
 // The helpers and bodies exist twice: `rbp` reads threadIdx.x directly, `rbo` takes the work-item id as an OPAQUE value (an empty
 // asm volatile), so that every helper derives its lane / wave / slot indices from its own copy and nothing derived from the id can
-// be shared between helpers, or hoisted out of the step loop of the sub-hourglass kernels, and kept live across the GEMM phases.
+// be shared between helpers and kept live across the GEMM phases.
 // At the 256-register limit of a 512-thread workgroup each such value was a spill: the 16x16 backward kernel went from 267 spilled
-// registers to none (69.2 -> 31.8 us, same box), the sub-hourglass kernels from 118 / 367 to none.  The kernels that did not spill
+// registers to none (69.2 -> 31.8 us, same box).  The kernels that did not spill
 // are ~5 % slower with the opaque id (recomputed indices, wave index through v_readfirstlane) and keep the plain one.
-// PWR_RB_OPAQUE_TID=0 (tools/build_rb_variant.py) builds everything plain, for the A/B.
+// -DPWR_RB_OPAQUE_TID=0 builds everything plain, for the A/B.
 #ifndef PWR_RB_OPAQUE_TID
 #define PWR_RB_OPAQUE_TID 1
 #endif
@@ -96,63 +96,6 @@ __global__ __launch_bounds__(64 * NW) void resblock_bwd_small_kernel(RbBwdParams
   __shared__ __attribute__((aligned(16))) char smem[RbGeom<LOGW>::TOTAL];
   if constexpr (LOGW == 4 && NW == 8) rbo::rb_bwd_body<LOGW, NW>(p, blockIdx.x, smem);   // (the one that spilled)
   else rbp::rb_bwd_body<LOGW, NW>(p, blockIdx.x, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The inner hourglass below the 32x32 level (model.py:25-47 recursion on maps of 16x16 and smaller) as ONE launch per
-// direction: a workgroup owns a sample and interprets a short program of steps -- ResBlock (the bodies above),
-// MaxPool2d(2,2), nearest up-sample + skip add, and their gradients -- in the order the per-block launches had.
-// Between steps the sample's tensors go through global memory exactly as before (same tensors, same rounding points:
-// bit-identical results, the weight-gradient kernels of the side streams are unchanged); what is saved is the 14 (16x16 -> 2x2)
-// dependent launches per direction, each of which paid a dispatch and ran ~5 us of pool / up-sample work on a cold start.
-// __syncthreads() orders the global hand-off inside the workgroup (workgroup-scope release / acquire; one CU, one L1).
-// ---------------------------------------------------------------------------------------------
-struct SubStep { int kind, logw, block, pad; const bf16_t* s0; const bf16_t* s1; const bf16_t* s2; bf16_t* d; };
-struct SubFwdProg { RbFwdParams rb[PWR_SUBHG_MAX_BLOCKS]; SubStep st[PWR_SUBHG_MAX_STEPS]; int nsteps; };
-struct SubBwdProg { RbBwdParams rb[PWR_SUBHG_MAX_BLOCKS]; SubStep st[PWR_SUBHG_MAX_STEPS]; int nsteps; };
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void subhourglass_fwd_kernel(SubFwdProg p) {
-  __shared__ __attribute__((aligned(16))) char smem[RbGeom<4>::TOTAL];
-  const int b = blockIdx.x;
-  for (int i = 0; i < p.nsteps; ++i) {
-    const SubStep& st = p.st[i];
-    const size_t so = (size_t)b * 128 << (2 * st.logw);         // this sample's offset in a [B][HW][128] tensor of width 2^logw
-    if (st.kind == PWR_SUBHG_BLOCK) {
-      const RbFwdParams& q = p.rb[st.block];
-      if (st.logw == 4) rbo::rb_fwd_body<4, NW>(q, b, smem);
-      else if (st.logw == 3) rbo::rb_fwd_body<3, NW>(q, b, smem);
-      else if (st.logw == 2) rbo::rb_fwd_body<2, NW>(q, b, smem);
-      else rbo::rb_fwd_body<1, NW>(q, b, smem);
-    } else if (st.kind == PWR_SUBHG_POOL) {
-      rbo::sub_pool_fwd<NW>(st.s0 + so, st.d + (so >> 2), st.logw);
-    } else {
-      rbo::sub_up_add<NW>(st.s0 + (so >> 2), st.s1 + so, st.d + so, st.logw);
-    }
-    __syncthreads();
-  }
-}
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void subhourglass_bwd_kernel(SubBwdProg p) {
-  __shared__ __attribute__((aligned(16))) char smem[RbGeom<4>::TOTAL];
-  const int b = blockIdx.x;
-  for (int i = 0; i < p.nsteps; ++i) {
-    const SubStep& st = p.st[i];
-    const size_t so = (size_t)b * 128 << (2 * st.logw);
-    if (st.kind == PWR_SUBHG_BLOCK) {
-      const RbBwdParams& q = p.rb[st.block];
-      if (st.logw == 4) rbo::rb_bwd_body<4, NW>(q, b, smem);
-      else if (st.logw == 3) rbo::rb_bwd_body<3, NW>(q, b, smem);
-      else if (st.logw == 2) rbo::rb_bwd_body<2, NW>(q, b, smem);
-      else rbo::rb_bwd_body<1, NW>(q, b, smem);
-    } else if (st.kind == PWR_SUBHG_POOL) {
-      rbo::sub_pool_bwd<NW>(st.s0 + so, st.s1 + (so >> 2), st.s2 ? st.s2 + so : nullptr, st.d + so, st.logw);
-    } else {
-      rbo::sub_up_bwd<NW>(st.s0 + so, st.d + (so >> 2), st.logw);
-    }
-    __syncthreads();
-  }
 }
 
 // dst[c] = sum_b src[b * stride + c]  (fixed order), one block per job: the three norms' dgamma / dbeta and conv c's bias
@@ -198,7 +141,7 @@ extern "C" int pwr_resblock_param_grads(const float* sums_a, const float* sums_b
 }
 
 extern "C" int pwr_resblock_small_supported(int H, int W, int C, int norm_mode, int dtype) {
-  static const bool on = [] { const char* e = getenv("PWR_RESBLOCK_FUSED"); return e ? atoi(e) != 0 : true; }();
+  static const bool on = (PWR_DBG_ENV("PWR_RESBLOCK_FUSED", 1) != 0);
   return on && dtype == PWR_BF16 && norm_mode == 0 && C == 128 && H == W && (W == 2 || W == 4 || W == 8 || W == 16);
 }
 
@@ -216,9 +159,8 @@ extern "C" int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* o
   p.sa = state_a; p.sb = state_b; p.sc = state_c;
   p.B = B; p.eps = eps;
   hipStream_t s = (hipStream_t)stream;
-  const int wide = [] { const char* e = getenv("PWR_RESBLOCK_WAVES"); return e ? atoi(e) : 1; }();
-  // 0: four waves everywhere (round 1); 1: eight on the 16x16 / 8x8 maps; 2: eight everywhere (what the sub-hourglass kernels run).
-  // Read per call: the tests toggle it.
+  const int wide = PWR_DBG_ENV("PWR_RESBLOCK_WAVES", 1);
+  // 0: four waves everywhere (round 1); 1: eight on the 16x16 / 8x8 maps (measured best); 2: eight everywhere.
   if (W == 16 && wide) hipLaunchKernelGGL((resblock_fwd_small_kernel<4, 8>), dim3(B), dim3(512), 0, s, p);
   else if (W == 16) hipLaunchKernelGGL((resblock_fwd_small_kernel<4, 4>), dim3(B), dim3(256), 0, s, p);
   else if (W == 8 && wide) hipLaunchKernelGGL((resblock_fwd_small_kernel<3, 8>), dim3(B), dim3(512), 0, s, p);
@@ -243,9 +185,8 @@ extern "C" int pwr_resblock_bwd_small(const void* gout, const void* x, const voi
   p.sums_a = sums_a; p.sums_b = sums_b; p.sums_c = sums_c; p.bias_sums = bias_sums;
   p.B = B;
   hipStream_t s = (hipStream_t)stream;
-  const int wide = [] { const char* e = getenv("PWR_RESBLOCK_WAVES"); return e ? atoi(e) : 1; }();
-  // 0: four waves everywhere (round 1); 1: eight on the 16x16 / 8x8 maps; 2: eight everywhere (what the sub-hourglass kernels run).
-  // Read per call: the tests toggle it.
+  const int wide = PWR_DBG_ENV("PWR_RESBLOCK_WAVES", 1);
+  // 0: four waves everywhere (round 1); 1: eight on the 16x16 / 8x8 maps (measured best); 2: eight everywhere.
   if (W == 16 && wide) hipLaunchKernelGGL((resblock_bwd_small_kernel<4, 8>), dim3(B), dim3(512), 0, s, p);
   else if (W == 16) hipLaunchKernelGGL((resblock_bwd_small_kernel<4, 4>), dim3(B), dim3(256), 0, s, p);
   else if (W == 8 && wide) hipLaunchKernelGGL((resblock_bwd_small_kernel<3, 8>), dim3(B), dim3(512), 0, s, p);
@@ -257,61 +198,3 @@ extern "C" int pwr_resblock_bwd_small(const void* gout, const void* x, const voi
   return (int)hipGetLastError();
 }
 
-static bool subhg_steps_ok(const pwr_subhg_step* steps, int nsteps, int nblocks) {
-  if (nsteps < 1 || nsteps > PWR_SUBHG_MAX_STEPS || nblocks < 1 || nblocks > PWR_SUBHG_MAX_BLOCKS) return false;
-  for (int i = 0; i < nsteps; ++i) {
-    const pwr_subhg_step& s = steps[i];
-    if (s.kind == PWR_SUBHG_BLOCK) { if (s.logw < 1 || s.logw > 4 || s.block < 0 || s.block >= nblocks) return false; }
-    else if (s.kind == PWR_SUBHG_POOL || s.kind == PWR_SUBHG_UP) { if (s.logw < 2 || s.logw > 4 || !s.s0 || !s.d) return false; }
-    else return false;
-  }
-  return true;
-}
-
-extern "C" int pwr_subhourglass_fwd(const pwr_resblock_fwd_args* blocks, int nblocks, const pwr_subhg_step* steps, int nsteps, int B,
-                                    int C, float eps, int dtype, void* stream) {
-  if (!(dtype == PWR_BF16 && C == 128) || !blocks || !steps || !subhg_steps_ok(steps, nsteps, nblocks)) return (int)hipErrorInvalidValue;
-  SubFwdProg g;
-  for (int k = 0; k < nblocks; ++k) {
-    const pwr_resblock_fwd_args& a = blocks[k];
-    RbFwdParams& p = g.rb[k];
-    p.x = (const bf16_t*)a.x; p.t1 = (bf16_t*)a.t1; p.t2 = (bf16_t*)a.t2; p.out = (bf16_t*)a.out;
-    p.wa = (const char*)a.wa; p.wb = (const char*)a.wb; p.wc = (const char*)a.wc;
-    p.ba = a.bias_a; p.bb = a.bias_b; p.bc = a.bias_c;
-    p.ga = a.gamma_a; p.bta = a.beta_a; p.gb = a.gamma_b; p.btb = a.beta_b; p.gc = a.gamma_c; p.btc = a.beta_c;
-    p.sa = a.state_a; p.sb = a.state_b; p.sc = a.state_c;
-    p.B = B; p.eps = eps;
-  }
-  for (int i = 0; i < nsteps; ++i) {
-    if (steps[i].kind == PWR_SUBHG_UP && !steps[i].s1) return (int)hipErrorInvalidValue;
-    g.st[i] = SubStep{steps[i].kind, steps[i].logw, steps[i].block, 0, (const bf16_t*)steps[i].s0, (const bf16_t*)steps[i].s1,
-                      (const bf16_t*)steps[i].s2, (bf16_t*)steps[i].d};
-  }
-  g.nsteps = nsteps;
-  hipLaunchKernelGGL((subhourglass_fwd_kernel<8>), dim3(B), dim3(512), 0, (hipStream_t)stream, g);
-  return (int)hipGetLastError();
-}
-
-extern "C" int pwr_subhourglass_bwd(const pwr_resblock_bwd_args* blocks, int nblocks, const pwr_subhg_step* steps, int nsteps, int B,
-                                    int C, int dtype, void* stream) {
-  if (!(dtype == PWR_BF16 && C == 128) || !blocks || !steps || !subhg_steps_ok(steps, nsteps, nblocks)) return (int)hipErrorInvalidValue;
-  SubBwdProg g;
-  for (int k = 0; k < nblocks; ++k) {
-    const pwr_resblock_bwd_args& a = blocks[k];
-    RbBwdParams& p = g.rb[k];
-    p.gout = (const bf16_t*)a.gout; p.x = (const bf16_t*)a.x; p.t1 = (const bf16_t*)a.t1; p.t2 = (const bf16_t*)a.t2;
-    p.dx = (bf16_t*)a.dx; p.dt1 = (bf16_t*)a.dt1; p.dt2 = (bf16_t*)a.dt2;
-    p.wcd = (const char*)a.wc_d; p.wbd = (const char*)a.wb_d; p.wad = (const char*)a.wa_d;
-    p.sa = a.state_a; p.sb = a.state_b; p.sc = a.state_c;
-    p.sums_a = a.sums_a; p.sums_b = a.sums_b; p.sums_c = a.sums_c; p.bias_sums = a.bias_sums;
-    p.B = B;
-  }
-  for (int i = 0; i < nsteps; ++i) {
-    if (steps[i].kind == PWR_SUBHG_POOL && !steps[i].s1) return (int)hipErrorInvalidValue;
-    g.st[i] = SubStep{steps[i].kind, steps[i].logw, steps[i].block, 0, (const bf16_t*)steps[i].s0, (const bf16_t*)steps[i].s1,
-                      (const bf16_t*)steps[i].s2, (bf16_t*)steps[i].d};
-  }
-  g.nsteps = nsteps;
-  hipLaunchKernelGGL((subhourglass_bwd_kernel<8>), dim3(B), dim3(512), 0, (hipStream_t)stream, g);
-  return (int)hipGetLastError();
-}

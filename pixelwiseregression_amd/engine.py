@@ -12,10 +12,8 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-# Side streams (parameter-gradient kernels) are joined at the end of EVERY backward segment by default.  PWR_JOIN_ONCE=1 joins
-# them only after the last segment (single-GPU runs; ~1 % faster): opt-in, see DESIGN.md section 2 ("reproducibility").
-import os as _os
-JOIN_ONCE = _os.environ.get("PWR_JOIN_ONCE", "0") not in ("", "0")
+# Side streams (parameter-gradient kernels) are joined at the end of EVERY backward segment (joining once is a
+# debug-build experiment, include/pwr_debug.h).
 
 
 class _Plan:
@@ -99,7 +97,7 @@ def _get_plan(model, B, dtype, need_grad):
         if old_key == key:
             break
         old = cache.pop(old_key)
-        torch.cuda.current_stream(model._flat.device).synchronize()    # its launches may still be in flight
+        torch.cuda.synchronize(model._flat.device)    # its launches may still be in flight, on ANY stream it was last run on (rare path)
         del old
     return plan
 
@@ -169,7 +167,6 @@ class _EngineFn(torch.autograd.Function):
         plan.bind(model, target)
         n = flat_grad.numel()
         ddp = model._ddp
-        l.pwr_engine_set_join(plan.h, 1 if (ddp is not None or not JOIN_ONCE) else 0)
         for seg in range(plan.n_seg):
             _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
             if ddp is not None and fresh:

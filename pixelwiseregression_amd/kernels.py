@@ -246,34 +246,6 @@ def planesum_nchw(x):
     return out
 
 
-def norm_bwd_small(g, y, state, relu=True, addend=None):
-    """InstanceNorm+ReLU backward for maps of <= 512 pixels in one launch (+ the batch reduction of dgamma / dbeta)."""
-    l = _lib.lib()
-    B, H, W, C = y.shape
-    sums = torch.empty(B, 2, C, dtype=torch.float32, device=y.device)
-    dy = torch.empty_like(y)
-    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
-    dbeta = torch.empty_like(dgamma)
-    _lib.check(l.pwr_norm_bwd_small(_p(g), _p(y), _p(state), _p(sums), _p(addend), _p(dy), int(relu), B, H * W, C, _dt(y), _s(y)),
-               "pwr_norm_bwd_small")
-    _lib.check(l.pwr_norm_param_grad(_p(sums), _p(dgamma), _p(dbeta), B, C, 0, _s(y)), "pwr_norm_param_grad")
-    return dy, dgamma, dbeta
-
-
-def norm_bwd_split(g, y, state, relu=True, addend=None):
-    """InstanceNorm+ReLU backward as the engine issues it: main part (partials + apply) and the parameter part."""
-    l = _lib.lib()
-    B, H, W, C = y.shape
-    partial = torch.empty(l.pwr_norm_bwd_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=y.device)
-    dy = torch.empty_like(y)
-    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
-    dbeta = torch.empty_like(dgamma)
-    _lib.check(l.pwr_norm_bwd_main(_p(g), _p(y), _p(state), _p(partial), _p(addend), _p(dy), int(relu), B, H * W, C, _dt(y), _s(y)),
-               "pwr_norm_bwd_main")
-    _lib.check(l.pwr_norm_bwd_params(_p(partial), _p(dgamma), _p(dbeta), 0, B, H * W, C, _s(y)), "pwr_norm_bwd_params")
-    return dy, dgamma, dbeta
-
-
 def resblock_small_supported(H, W, C, norm_mode, dtype):
     return bool(_lib.lib().pwr_resblock_small_supported(H, W, C, norm_mode, dtype))
 
@@ -358,21 +330,3 @@ def norm_bwd_from_partial(g, y, state, partial, chunks, relu=True, addend=None, 
     return dy, dgamma, dbeta
 
 
-def norm_bwd_deferred(g, y, state, partial=None, chunks=0, relu=True, addend=None):
-    """InstanceNorm backward with the parameter gradients deferred (pwr_norm_bwd_deferred + pwr_norm_param_grad)."""
-    l = _lib.lib()
-    B, H, W, C = y.shape
-    dev = y.device
-    if partial is None:
-        partial = torch.empty(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=dev)
-        chunks = 0
-    S1 = torch.empty(B, C, dtype=torch.float32, device=dev)
-    S2 = torch.empty_like(S1)
-    sums = torch.empty(B, 2, C, dtype=torch.float32, device=dev)
-    dy = torch.empty_like(y)
-    _lib.check(l.pwr_norm_bwd_deferred(_p(g), _p(y), _p(state), _p(partial), chunks, _p(S1), _p(S2), _p(sums), _p(addend), _p(dy), int(relu),
-                                       B, H * W, C, _dt(y), _s(y)), "pwr_norm_bwd_deferred")
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty_like(dgamma)
-    _lib.check(l.pwr_norm_param_grad(_p(sums), _p(dgamma), _p(dbeta), B, C, 0, _s(y)), "pwr_norm_param_grad")
-    return dy, dgamma, dbeta

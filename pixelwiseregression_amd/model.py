@@ -191,6 +191,10 @@ class PixelwiseRegression(nn.Module):
         self._trig = None
         self._param_list = params
         self._byte_offsets = [4 * o for (o, _) in self._offsets.values()]
+        if getattr(self, "_engine", None):
+            # plans (and their arenas) are dropped here: their launches may still be in flight on whatever stream ran them
+            for d in {p.arena.device for p in self._engine.values() if p.arena.is_cuda}:
+                torch.cuda.synchronize(d)
         self._engine = None
 
     def _set_buffer(self, dotted, tensor):

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .engine import _get_plan, _run_forward, BF16, F32, JOIN_ONCE
+from .engine import _get_plan, _run_forward, BF16, F32
 
 
 class TrainStep:
@@ -101,7 +101,6 @@ class TrainStep:
         plan.bind(m, grad)
         n = grad.numel()
         ddp = m._ddp
-        l.pwr_engine_set_join(plan.h, 1 if (ddp is not None or not JOIN_ONCE) else 0)
         for seg in range(plan.n_seg):
             _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
             if ddp is not None:

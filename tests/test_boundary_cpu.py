@@ -130,8 +130,8 @@ def test_metric_tail_matches_reference_golden(golden_dir):
 
 
 def test_engine_plan_builds_without_a_gpu_and_names_its_arena():
-    """The launch plan is built on the host (no HIP call): the parameter table of the module must be consumed exactly, the plan has
-    stage + 1 backward segments, and pwr_engine_layout names every arena buffer (debugging aid used by tools/determinism_arena.py)."""
+    """The launch plan is built on the host (no HIP call): the parameter table of the module must be consumed exactly and the plan has
+    stage + 1 backward segments."""
     import ctypes
     import torch
     from pixelwiseregression_amd import PixelwiseRegression, _lib
@@ -147,17 +147,7 @@ def test_engine_plan_builds_without_a_gpu_and_names_its_arena():
         try:
             assert l.pwr_engine_num_segments(h) == 3
             arena = l.pwr_engine_arena_bytes(h)
-            need = l.pwr_engine_layout(h, None, 0)
-            buf = ctypes.create_string_buffer(need)
-            l.pwr_engine_layout(h, buf, need)
-            recs = [line.split(" ", 2) for line in buf.value.decode().splitlines()]
-            assert len(recs) > 100
-            end = 0
-            for off, nbytes, tag in recs:
-                assert int(off) >= end and int(off) % 256 == 0, tag      # buffers are disjoint, in order, 256-byte aligned
-                end = int(off) + int(nbytes)
-            assert end <= arena
-            assert any("scratch:cpartial" in t for _, _, t in recs) and any(".plane:" in t for _, _, t in recs)
+            assert arena > 2 * B * (2 * P) ** 2 * 128 * 2 and l.pwr_engine_num_launch_ops(h, 0) > 50     # more than the widest stem tensor + its gradient
         finally:
             l.pwr_engine_destroy(h)
     # a parameter table that does not match the architecture is refused
@@ -193,8 +183,9 @@ def test_plan_cache_is_bounded():
     engine._Plan, engine._plan_budget_bytes = FakePlan, (lambda dev: 10 ** 12)
     try:
         m = PixelwiseRegression(4, stage=1, label_size=16, features=32, level=1, norm_method="instance")
-        sync = torch.cuda.current_stream
-        torch.cuda.current_stream = lambda dev=None: type("S", (), {"synchronize": staticmethod(lambda: None)})()
+        sync = torch.cuda.synchronize
+        synced = []
+        torch.cuda.synchronize = lambda dev=None: synced.append(dev)       # eviction synchronises the whole device (any stream)
         try:
             for B in (1, 2, 3, 4, 5, 6):
                 engine._get_plan(m, B, 0, False)
@@ -204,9 +195,9 @@ def test_plan_cache_is_bounded():
             assert (3, 0, False) in m._engine and (4, 0, False) not in m._engine
             engine._plan_budget_bytes = lambda dev: 9000            # byte budget: only what fits stays
             engine._get_plan(m, 8, 0, False)
-            assert list(m._engine) == [(8, 0, False)]
+            assert list(m._engine) == [(8, 0, False)] and len(synced) >= 7
         finally:
-            torch.cuda.current_stream = sync
+            torch.cuda.synchronize = sync
     finally:
         engine._Plan, engine._plan_budget_bytes = real, real_budget
 
@@ -227,16 +218,34 @@ def test_no_cross_half_packed_f32_in_shipped_code_objects():
     """Static regression test of the round-2 reproducibility fix: the gfx950 code objects inside
     libpwr_hip.so contain no packed f32 instruction whose low result reads a source's high register (op_sel:[..1..]) -- the
     compiler-generated (SLP) form caught producing a wrong addend in lanes 48-63 beside MFMA kernels of another stream."""
-    import importlib.util
-    from pixelwiseregression_amd import _lib, build
+    import pytest
+    from pixelwiseregression_amd import _lib, build, codeobj_scan as mod
     assert "-fno-slp-vectorize" in build.FLAGS
-    spec = importlib.util.spec_from_file_location("codeobj_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                                "tools", "codeobj_scan.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    if not mod.available() or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs llvm-objdump / llvm-objcopy of the ROCm toolchain and a built libpwr_hip.so")
     r = mod.scan(_lib.LIB_PATH)
     assert r["functions"] > 100 and r["instructions"] > 100000, r       # the scan really saw the library's kernels
     assert r["packed_f32_cross_half_op_sel"] == 0, r
+
+
+def test_shipped_library_has_one_configuration():
+    """Round-3 hygiene: the product library reads no experiment switch (no getenv among its undefined symbols: every PWR_* switch is a
+    compile-time constant outside the debug build), exports none of the debugging entry points of include/pwr_debug.h, and the
+    variant libraries of earlier rounds are gone from the package directory."""
+    import glob
+    import subprocess
+    import pytest
+    from pixelwiseregression_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpwr_hip.so not built")
+    assert _lib.LIB_PATH.endswith(os.path.join("pixelwiseregression_amd", "libpwr_hip.so")) and "PWR_LIB" not in open(_lib.__file__).read()
+    nm = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+    undefined = {l.split()[-1].split("@")[0] for l in nm if " U " in l}
+    exported = {l.split()[-1] for l in nm if " T " in l}
+    assert "getenv" not in undefined and "secure_getenv" not in undefined
+    assert not [e for e in exported if e.startswith("pwr_debug")] and "pwr_engine_set_join" not in exported and "pwr_engine_layout" not in exported
+    assert set(_lib.SIGNATURES) <= exported
+    assert glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "*.so")) == [_lib.LIB_PATH]
 
 
 def test_one_pixel_innermost_map_fails_like_the_reference():

@@ -6,6 +6,8 @@ arena is kept and analysed buffer by buffer (pwr_engine_layout names them).
 """
 import os, sys, time, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dbglib  # noqa: F401  (the debug build: pwr_debug.h entry points, PWR_* experiment switches)
 from pixelwiseregression_amd import PixelwiseRegression, _lib
 from pixelwiseregression_amd.synthetic import make_batch
 from pixelwiseregression_amd.train import TrainStep

@@ -10,6 +10,8 @@ snapshot is compared with a reference step's.
 """
 import os, sys, time, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dbglib  # noqa: F401  (the debug build: pwr_debug.h entry points, PWR_* experiment switches)
 from pixelwiseregression_amd import PixelwiseRegression, _lib
 from pixelwiseregression_amd.synthetic import make_batch
 from pixelwiseregression_amd.train import TrainStep
@@ -25,6 +27,7 @@ ts(*args); ts(*args)
 torch.cuda.synchronize()
 plan = [p for p in m._engine.values() if p.need_grad][0]
 l = _lib.lib()
+l.pwr_engine_set_join(plan.h, 0 if os.environ.get("PWR_JOIN_ONCE", "0") not in ("", "0") else 1)   # (debug build only: pwr_debug.h)
 need = l.pwr_engine_layout(plan.h, None, 0)
 buf = ctypes.create_string_buffer(need)
 l.pwr_engine_layout(plan.h, buf, need)

@@ -1,6 +1,8 @@
 """Phase timeline of the 3x3 patch conv (heads shape): per-workgroup s_memtime stamps -> where the time goes, per CU."""
 import os, sys, torch, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dbglib  # noqa: F401  (the debug build: pwr_debug.h entry points, PWR_* experiment switches)
 from pixelwiseregression_amd import kernels as K, _lib
 dev = "cuda:0"
 B, P, F_ = 32, 64, 128
