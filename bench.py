@@ -264,6 +264,40 @@ def self_launch(n):
     return rc
 
 
+def pipeline_block(model, trainer, dev, steps):
+    """End to end: RAW 640x480 depth frames (resident in HBM) -> preprocess_batch (crop around the COM, depth cut, resize, the rotation /
+    scale / shift augmentation drawn per step like datasets.py:224-238, label image, mask, normalisation; csrc/preprocess.hip) ->
+    TrainStep, every step.  Reported beside `value`, never as it (the bench's step starts from crops already in HBM)."""
+    import random
+    from pixelwiseregression_amd import preprocess_batch, draw_augmentation, INTRINSICS
+    from pixelwiseregression_amd.synthetic import make_raw_frames
+    raw = make_raw_frames(B_PER_GPU, J, seed=4321, device=dev)
+    rng = random.Random(99)
+
+    def prep():
+        return preprocess_batch(raw["depth"], raw["joint_uvd"], raw["com"], raw["cube_size"], INTRINSICS["NYU"], S, P,
+                                augmentation=draw_augmentation(B_PER_GPU, rng=rng), dense_targets=False)
+
+    def both():
+        b = prep()
+        return trainer(b["img"], b["label_img"], b["mask"], b["uvd"])
+    out = {}
+    for name, fn in (("preprocess_only", prep), ("preprocess_plus_train_step", both)):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize()
+        out[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
+    out["frames_per_s"] = B_PER_GPU / (out["preprocess_plus_train_step_ms"] * 1e-3)
+    out["fallback_or_rejected_last_batch"] = int((prep()["fallback"] | prep()["rejected"]).sum())
+    out["what"] = ("%d raw 480x640 fp32 frames in HBM -> preprocess_batch with a fresh augmentation draw per step -> TrainStep; %d timed steps; the "
+                   "per-sample crop geometry and joint transforms are float64 host arithmetic like the reference's" % (B_PER_GPU, steps))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,6 +318,8 @@ def main():
                     help="debug: take the data-parallel path (process group, per-segment all-reduce) even with one rank -- exercises RCCL on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share cuda:0 (with --dist-backend gloo) to exercise the data-parallel path on a 1-GPU box")
+    ap.add_argument("--with-pipeline", action="store_true",
+                    help="also time raw frames -> preprocess_batch -> train step (rank 0, N=1; reported as `pipeline`, outside `value`)")
     ap.add_argument("--debug-lib", action="store_true",
                     help="A/B measurements only: load the DEBUG build of the library (tools/build_debug.py) so that the PWR_* experiment "
                          "switches apply; the result line says so")
@@ -437,6 +473,9 @@ def main():
                                        "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": dtraffic, "traffic_source": "profiles/r2_traffic.json",
                                        "us_per_launch": td * 1e6,
                                        "note": "23 MB per launch: launch / latency bound at this shape; HBM bound at the C5 shape (profiles/r2_dec_bench.jsonl: 4.3 / 4.7 TB/s)"}
+        if world == 1 and args.with_pipeline and native:
+            model.train()
+            out["pipeline"] = pipeline_block(model, trainer, dev, max(10, min(args.steps, 100)))
         if world == 1 and not use_dist and args.accuracy_steps > 0:
             out["accuracy"] = accuracy_block(args.accuracy_steps, dev)
         if world == 1 and not args.no_cpu_baseline:

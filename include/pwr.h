@@ -103,7 +103,6 @@ int pwr_conv_fwd_stats(const void* x, const void* wpack, const float* bias, cons
                        void* stream);
 
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
-
 /* dw[cout_real][cin_real][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
  * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout]; Cin / Cout may include zero-padded channels beyond cin_real /
  * cout_real (the stage-input concat is padded 2J+1 -> multiple of 8, the heads' dy J -> multiple of 8);
@@ -130,6 +129,17 @@ int pwr_catconv_dgrad(const void* dy, const float* w, float* gp, float* gd, int 
 int pwr_catconv_wgrad_blocks(int B, int N); /* slab floats = blocks * (2J+2) * F */
 int pwr_catconv_wgrad(const float* pmap, const float* dmap, const float* label, const void* dy, float* slab, float* dw,
                       float* db, int accumulate, int B, int N, int J, int F, int dtype, void* stream);
+
+/* The weight gradients of SEVERAL layers in one launch (+ two split-K reduce launches): the 24 conv layers per stage on the 16x16 ..
+ * 2x2 maps of the inner hourglass (model.py:25-47 below the 32x32 level) are microseconds of arithmetic each.  bf16, stride 1,
+ * ksize 1 or 3, at most 48 jobs; every job as for pwr_conv_wgrad with relu_in / in_norm per job, accumulate = 0.  slab: workspace
+ * of pwr_conv_wgrad_group_slab_bytes (0 = unsupported job list). */
+typedef struct {
+  const void* x; const void* dy; const float* in_norm; float* dw;
+  int H, W, Cin, cin_real, Cout, cout_real, ksize, relu_in;
+} pwr_wgrad_job;
+size_t pwr_conv_wgrad_group_slab_bytes(const pwr_wgrad_job* jobs, int njobs, int B);
+int pwr_conv_wgrad_group(const pwr_wgrad_job* jobs, int njobs, float* slab, int B, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Norm + ReLU (model.py: every `norm(...)`, ReLU pair).  mode: 0 InstanceNorm2d, 1 BatchNorm2d training,

@@ -198,4 +198,8 @@ bool conv_tr2_applicable(const ConvParams& p, int dtype);   // stride-2 data gra
 int launch_conv_tr2(const ConvParams& p, hipStream_t s);
 void set_debug_stamps(long long* ptr);
 
+// conv_wgrad_dma.hip: 3x3 weight gradient with both operands staged by LDS-DMA (operand already normalised: in_norm == null)
+bool wgrad3d_applicable(const WgradParams& p);
+int launch_wgrad3d(const WgradParams& p, hipStream_t s);
+
 }  // namespace pwr

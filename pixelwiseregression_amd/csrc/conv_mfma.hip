@@ -484,24 +484,30 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int pitch, int k0, i
 }
 
 template <int WM, int WN, int MR, int NR>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
+struct WgradTrGeom {
+  static constexpr int KP = 32, EP = 8;
+  static constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
+  static constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;          // row pitches in bytes
+  static constexpr int TILE_A = KP * PA, TILE_B = KP * PB;
+  static constexpr int LDS = 2 * (TILE_A + TILE_B);
+};
+
+// one workgroup = (tap, output tile `tile_yx`, K split) of one layer
+template <int WM, int WN, int MR, int NR>
+__device__ __forceinline__ void wgrad_tr_body(const WgradParams& p, int tap, int tile_yx, int split, char* smem) {
   typedef bf16_t T;
   typedef bf16x8 V;
-  constexpr int KP = 32, EP = 8;
-  constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
-  constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;          // row pitches in bytes
-  constexpr int TILE_A = KP * PA, TILE_B = KP * PB;
+  typedef WgradTrGeom<WM, WN, MR, NR> G;
+  constexpr int KP = G::KP, EP = G::EP, BM = G::BM, BN = G::BN, PA = G::PA, PB = G::PB, TILE_A = G::TILE_A, TILE_B = G::TILE_B;
   constexpr int ACH = BM / EP, BCH = BN / EP;                // 16-byte chunks per pixel row
   constexpr int NA = (KP * ACH + 255) / 256, NBL = (KP * BCH + 255) / 256;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (TILE_A + TILE_B)];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int tap = blockIdx.x, ky = tap / p.ksize, kx = tap - ky * p.ksize;
+  const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
   const int ntn = p.CoutPad / BN;
-  const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
+  const int mtile = tile_yx / ntn, ntile = tile_yx - mtile * ntn;
   const int ci0 = mtile * BM, co0 = ntile * BN;
-  const int split = blockIdx.z;
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
   const int HoWo = p.Ho * p.Wo;
@@ -616,6 +622,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
         const int co = co0 + wn * NR * 32 + j * 32 + r;
         out[(size_t)ci * p.CoutPad + co] = acc[i][j][e];
       }
+}
+
+template <int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[WgradTrGeom<WM, WN, MR, NR>::LDS];
+  wgrad_tr_body<WM, WN, MR, NR>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GROUPED form: the weight gradients of up to PWR_WGRAD_GROUP_MAX layers in ONE launch.  The 16x16 .. 2x2 maps of the inner
+// hourglass (model.py:25-47) carry 8 ResBlocks per stage = 24 conv layers whose weight gradients are microseconds of arithmetic
+// each: as 24 launches + 24 split-K reduce launches they were ~16 us apiece of launch latency and tail on the side streams (0.76 ms
+// of the 3.4 ms of parameter-gradient work per train step, profiles/r3_serial_kernel_stats.csv).  Workgroup b of the launch looks its
+// layer up in a prefix table (wave-uniform), then runs the same body as the single-layer kernel; each layer has its own slab region.
+// ---------------------------------------------------------------------------------------------
+#define PWR_WGRAD_GROUP_MAX 24
+struct WgradGroup {
+  WgradParams job[PWR_WGRAD_GROUP_MAX];
+  int start[PWR_WGRAD_GROUP_MAX + 1];     // first workgroup of job j; start[n] = grid size
+  int n;
+};
+template <int WM, int WN, int MR, int NR>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_group_kernel(WgradGroup g) {
+  __shared__ __attribute__((aligned(16))) char smem[WgradTrGeom<WM, WN, MR, NR>::LDS];
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.n && b >= g.start[j + 1]) ++j;
+  const WgradParams& p = g.job[j];
+  int r = b - g.start[j];
+  const int taps = p.ksize * p.ksize;
+  const int tiles = (p.CinPad / WgradTrGeom<WM, WN, MR, NR>::BM) * (p.CoutPad / WgradTrGeom<WM, WN, MR, NR>::BN);
+  const int tap = r % taps;
+  r /= taps;
+  wgrad_tr_body<WM, WN, MR, NR>(p, tap, r % tiles, r / tiles, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -848,12 +888,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
 // round again: 2.5 dependent rounds of DRAM latency on 256 blocks = 25 us for the 47 MB of a 128 -> 128 3x3 layer, 1.9 TB/s; this
 // form sums in the same order -- bit-identical, checked in round 2 -- and takes 13 us.)
 template <int TC, int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cout,
-                                                                int CinPad, int CoutPad, int cin_real, int accumulate) {
-  // blockIdx.z: chunk of TC taps (9 taps = one chunk; 25 / 49 taps of a 5x5 / 7x7 layer = 3 / 6 chunks)
-  __shared__ float tile[4 * 32 * (TC + 1)];
+__device__ __forceinline__ void wgrad_reduce_fast_body(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cout,
+                                                       int CinPad, int CoutPad, int cin_real, int accumulate, int bx, int by, int bz,
+                                                       float* tile) {
+  // bz: chunk of TC taps (9 taps = one chunk; 25 / 49 taps of a 5x5 / 7x7 layer = 3 / 6 chunks)
   constexpr int pitch = TC + 1;
-  const int co0 = blockIdx.x * 32, ci = blockIdx.y, tap0 = blockIdx.z * TC;
+  const int co0 = bx * 32, ci = by, tap0 = bz * TC;
   const int nt = taps - tap0 < TC ? taps - tap0 : TC;
   const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3, wave = threadIdx.x >> 6;
   const int co = co0 + c4 * 4;
@@ -903,6 +943,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __r
       dw[o] = accumulate ? dw[o] + r : r;
     }
   }
+}
+template <int TC, int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_fast_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int taps, int Cout,
+                                                                int CinPad, int CoutPad, int cin_real, int accumulate) {
+  __shared__ float tile[4 * 32 * (TC + 1)];
+  wgrad_reduce_fast_body<TC, SL>(slab, dw, S, taps, Cout, CinPad, CoutPad, cin_real, accumulate, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+}
+
+// grouped form (see conv_wgrad_tr_group_kernel): block b -> (job, 32-co tile, ci); <= 9 taps per layer
+struct ReduceJob { const float* slab; float* dw; int S, taps, Cout, CinPad, CoutPad, cin_real, accumulate, start; };
+struct ReduceGroup { ReduceJob job[PWR_WGRAD_GROUP_MAX]; int n, total; };
+template <int TC, int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(ReduceGroup g) {
+  __shared__ float tile[4 * 32 * (TC + 1)];
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.n && b >= g.job[j + 1].start) ++j;
+  const ReduceJob& q = g.job[j];
+  const int r = b - q.start, ncb = (q.Cout + 31) / 32;
+  wgrad_reduce_fast_body<TC, SL>(q.slab, q.dw, q.S, q.taps, q.Cout, q.CinPad, q.CoutPad, q.cin_real, q.accumulate, r % ncb, r / ncb, 0, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -967,6 +1027,7 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   const int taps = p.ksize * p.ksize;
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
   if constexpr (sizeof(T) == 2) {
+    if (wgrad3d_applicable(p)) return launch_wgrad3d(p, s);                  // operands by LDS-DMA (no norm to apply on the way)
     if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
       dim3 g3(24 * ((p.S + 7) / 8), grid.y, 1);
       // 128 output channels: 64 (ci) x 128 (co) x 3 taps per workgroup = 96 accumulator registers -> TWO workgroups per CU,
@@ -1129,5 +1190,103 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
     hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
   else
     hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+  return (int)hipGetLastError();
+}
+
+
+// ---- grouped weight gradients (bf16, stride 1, ksize 1 or 3): see conv_wgrad_tr_group_kernel
+namespace {
+struct GroupPlan { pwr::WgradParams p; int bn, S, blocks; size_t slab_off; };
+// K splits of one layer inside a grouped launch: ~16 K steps (512 pixels) per workgroup, at most 32 splits
+static int group_splits(int M) {
+  const int steps = (M + 31) / 32;
+  int s = (steps + 15) / 16;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+static int plan_group(const pwr_wgrad_job* jobs, int njobs, int B, GroupPlan* out, size_t* slab_bytes) {
+  size_t off = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const pwr_wgrad_job& q = jobs[j];
+    if (q.Cin % 8 || q.Cout % 8 || (q.ksize != 1 && q.ksize != 3) || q.cin_real <= 0 || q.cin_real > q.Cin || q.cout_real <= 0 || q.cout_real > q.Cout)
+      return PWR_EUNSUPPORTED;
+    pwr::WgradParams& p = out[j].p;
+    p.x = q.x; p.dy = q.dy; p.in_norm = q.in_norm; p.slab = nullptr;
+    p.B = B; p.H = q.H; p.W = q.W; p.Cin = q.Cin; p.Cout = q.Cout; p.ksize = q.ksize; p.stride = 1; p.pad = q.ksize / 2;
+    p.Ho = q.H; p.Wo = q.W;
+    p.CoutPad = pwr_conv_out_pad(q.Cout); p.CinPad = (q.Cin + 127) / 128 * 128;
+    p.relu_in = q.relu_in; p.M = B * q.H * q.W;
+    const int total_steps = (p.M + 31) / 32, want = group_splits(p.M);
+    p.steps_per_split = (total_steps + want - 1) / want;
+    p.S = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
+    out[j].bn = pwr::pick_bn(q.Cout);
+    out[j].S = p.S;
+    out[j].blocks = q.ksize * q.ksize * (p.CinPad / 128) * (p.CoutPad / out[j].bn) * p.S;
+    out[j].slab_off = off;
+    off += (size_t)p.S * q.ksize * q.ksize * p.CinPad * p.CoutPad * sizeof(float);
+  }
+  *slab_bytes = off;
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t pwr_conv_wgrad_group_slab_bytes(const pwr_wgrad_job* jobs, int njobs, int B) {
+  if (njobs < 1 || njobs > 2 * PWR_WGRAD_GROUP_MAX) return 0;
+  GroupPlan plan[2 * PWR_WGRAD_GROUP_MAX];
+  size_t bytes = 0;
+  if (plan_group(jobs, njobs, B, plan, &bytes)) return 0;
+  return bytes;
+}
+
+extern "C" int pwr_conv_wgrad_group(const pwr_wgrad_job* jobs, int njobs, float* slab, int B, int dtype, void* stream) {
+  if (dtype != PWR_BF16) return PWR_EUNSUPPORTED;
+  if (njobs < 1 || njobs > 2 * PWR_WGRAD_GROUP_MAX) return PWR_EINVAL;
+  GroupPlan plan[2 * PWR_WGRAD_GROUP_MAX];
+  size_t bytes = 0;
+  int rc = plan_group(jobs, njobs, B, plan, &bytes);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // one launch per N-tile class (the kernels' register tiles are template parameters)
+  for (int bn = 32; bn <= 128; bn *= 2) {
+    pwr::WgradGroup g;
+    g.n = 0;
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+      if (plan[j].bn != bn) continue;
+      if (g.n == PWR_WGRAD_GROUP_MAX) return PWR_EINVAL;
+      g.job[g.n] = plan[j].p;
+      g.job[g.n].slab = reinterpret_cast<float*>(reinterpret_cast<char*>(slab) + plan[j].slab_off);
+      g.start[g.n++] = total;
+      total += plan[j].blocks;
+    }
+    if (!g.n) continue;
+    g.start[g.n] = total;
+    if (bn == 128) hipLaunchKernelGGL((pwr::conv_wgrad_tr_group_kernel<2, 2, 2, 2>), dim3(total), dim3(256), 0, s, g);
+    else if (bn == 64) hipLaunchKernelGGL((pwr::conv_wgrad_tr_group_kernel<2, 2, 2, 1>), dim3(total), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((pwr::conv_wgrad_tr_group_kernel<4, 1, 1, 1>), dim3(total), dim3(256), 0, s, g);
+  }
+  // split-K reduce of all layers: one launch for the 3x3 layers, one for the 1x1 layers
+  for (int ks = 1; ks <= 3; ks += 2) {
+    pwr::ReduceGroup r;
+    r.n = 0;
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+      if (jobs[j].ksize != ks) continue;
+      while (r.n == PWR_WGRAD_GROUP_MAX) {      // (more layers of one kind than a launch takes: flush)
+        r.total = total;
+        if (ks == 3) hipLaunchKernelGGL((pwr::wgrad_reduce_group_kernel<9, 3>), dim3(total), dim3(256), 0, s, r);
+        else hipLaunchKernelGGL((pwr::wgrad_reduce_group_kernel<1, 16>), dim3(total), dim3(256), 0, s, r);
+        r.n = 0; total = 0;
+      }
+      const pwr::WgradParams& p = plan[j].p;
+      r.job[r.n++] = pwr::ReduceJob{reinterpret_cast<const float*>(reinterpret_cast<const char*>(slab) + plan[j].slab_off), jobs[j].dw, p.S, ks * ks,
+                                    jobs[j].cout_real, p.CinPad, p.CoutPad, jobs[j].cin_real, 0, total};
+      total += ((jobs[j].cout_real + 31) / 32) * jobs[j].cin_real;
+    }
+    if (!r.n) continue;
+    r.total = total;
+    if (ks == 3) hipLaunchKernelGGL((pwr::wgrad_reduce_group_kernel<9, 3>), dim3(total), dim3(256), 0, s, r);
+    else hipLaunchKernelGGL((pwr::wgrad_reduce_group_kernel<1, 16>), dim3(total), dim3(256), 0, s, r);
+  }
   return (int)hipGetLastError();
 }

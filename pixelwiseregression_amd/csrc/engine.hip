@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -126,22 +127,29 @@ static void side_pool_attach(Ctx& c, hipStream_t caller) {
 
 // DEBUG build only -- step-level timing by elimination (tools/step_elimination.py; the results are WRONG by construction):
 // bit 0: no parameter-gradient launches (everything that goes to the side streams), bit 1: no norm-backward launches,
-// bit 2: no data-gradient convs / fused ResBlock backwards.  Constant 0 in the shipped library.
+// bit 2: no data-gradient convs / fused ResBlock backwards, bit 3: no fork events (side launches unordered).  Constant 0 in the
+// shipped library.
 static int elim_mask() {
   static const int m = PWR_DBG_ENV("PWR_ELIM", 0);
   return m;
 }
 
-// run `op` on the side stream, ordered after everything enqueued so far on the main stream
+// run `op` on a side stream (round-robin), ordered after everything enqueued so far on the caller's stream.
+// One fork event per op.  Measured in round 3 (profiles/r3_step_elimination.json): with the side launches NOT ordered behind the chain
+// the step takes 0.33 ms less -- but batching several ops behind one event (fewer markers in the chain's queue, each op issued a few
+// chain kernels later) made the step SLOWER, 6.47 ms at one op per event against 6.8 - 7.1 ms at 2 .. 12: what counts is that the
+// parameter-gradient work starts as early as it can, because the chain waits for it at the end of every segment.
 static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
   if (elim_mask() & 1) return 0;
   if (!c.use_side || c.n_side == 0) return op(c);
   const int k = c.side_rr;
   c.side_rr = (k + 1) % c.n_side;
-  hipEvent_t ev = c.ev_fork[c.fork_rr];
-  c.fork_rr = (c.fork_rr + 1) % c.n_fork;
-  hipEventRecord(ev, (hipStream_t)c.stream);
-  hipStreamWaitEvent(c.side[k], ev, 0);
+  if (!(elim_mask() & 8)) {     // (bit 3, debug build: side ops NOT ordered behind the chain)
+    hipEvent_t ev = c.ev_fork[c.fork_rr];
+    c.fork_rr = (c.fork_rr + 1) % c.n_fork;
+    hipEventRecord(ev, (hipStream_t)c.stream);
+    hipStreamWaitEvent(c.side[k], ev, 0);
+  }
   void* main_stream = c.stream;
   c.stream = c.side[k];
   c.slab_off = (size_t)k * c.slab_stride;
@@ -371,15 +379,15 @@ struct Engine {
         float* rv = on.rv >= 0 ? c.buffers + on.rv : nullptr;
         if (mode == 2) {
           int rc = pwr_conv_fwd(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.state) : nullptr,
-                                1, has_res ? c.arena + roff : nullptr, c.arena + y.off, nullptr, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k,
-                                cv.stride, 0, dt, c.stream);
+                                1, has_res ? c.arena + roff : nullptr, c.arena + y.off, nullptr, Bc, x.H, x.W,
+                                cv.Cin, cv.Cout, cv.k, cv.stride, 0, dt, c.stream);
           if (rc) return rc;
           return pwr_norm_stats(c.arena + y.off, c.params + on.gamma, c.params + on.beta, rm, rv, (float*)(c.arena + E->scr_partial),
                                 (float*)(c.arena + on.state), Bc, HWo, cv.Cout, mode, 1e-5f, 0.1f, dt, c.stream);
         }
         int rc = pwr_conv_fwd_stats(c.arena + x.off, c.packs + cv.pack_f, c.params + cv.b, has_nr ? (float*)(c.arena + n.state) : nullptr,
-                                    1, has_res ? c.arena + roff : nullptr, c.arena + y.off, Bc, x.H, x.W, cv.Cin, cv.Cout, cv.k, cv.stride,
-                                    0, (float*)(c.arena + E->scr_cpartial), nullptr, nullptr, nullptr, 1, dt, c.stream);
+                                    1, has_res ? c.arena + roff : nullptr, c.arena + y.off, Bc, x.H, x.W, cv.Cin,
+                                    cv.Cout, cv.k, cv.stride, 0, (float*)(c.arena + E->scr_cpartial), nullptr, nullptr, nullptr, 1, dt, c.stream);
         if (rc) return rc;
         return pwr_norm_finalize_partial((float*)(c.arena + E->scr_cpartial), chunks, c.params + on.gamma,
                                          c.params + on.beta, rm, rv, (float*)(c.arena + on.state), Bc, HWo, cv.Cout, mode, 1e-5f, 0.1f,
@@ -461,6 +469,29 @@ struct Engine {
 
   // ---- ResBlock (model.py:6-23)
   struct ResB { NormL na, nb, nc; ConvL ca, cb, cc; Tn t1, t2; };
+  // Weight gradients of the fused small-map ResBlocks: while `small_jobs` is set (hourglass(): the region below the 32x32 level),
+  // resblock_fused records its three conv layers here instead of pushing a launch + a split-K reduce for each; the region's owner
+  // issues them as ONE grouped launch (pwr_conv_wgrad_group) behind the last block's backward kernel.
+  struct SmallJob { size_t x_off, dy_off, state_off; long long w; int H, W, Cin, Cout, k; };
+  std::vector<SmallJob>* small_jobs = nullptr;
+  Op small_group_op(const std::vector<SmallJob>& jobs) {
+    const int Bc = B, dt = dtype;
+    Engine* E = this;
+    std::vector<pwr_wgrad_job> tmp;
+    for (auto& j : jobs) tmp.push_back(pwr_wgrad_job{nullptr, nullptr, nullptr, nullptr, j.H, j.W, j.Cin, j.Cin, j.Cout, j.Cout, j.k, 1});
+    const size_t bytes = pwr_conv_wgrad_group_slab_bytes(tmp.data(), (int)tmp.size(), B);
+    if (!bytes) err = "internal: grouped weight-gradient job list refused";
+    want_slab(bytes);
+    return [=](Ctx& c) {
+      return run_on_side(c, [=](Ctx& c2) {
+        std::vector<pwr_wgrad_job> arr;
+        for (auto& j : jobs)
+          arr.push_back(pwr_wgrad_job{c2.arena + j.x_off, c2.arena + j.dy_off, (const float*)(c2.arena + j.state_off), c2.grads + j.w, j.H, j.W,
+                                      j.Cin, j.Cin, j.Cout, j.Cout, j.k, 1});
+        return pwr_conv_wgrad_group(arr.data(), (int)arr.size(), (float*)(c2.arena + E->scr_slab + c2.slab_off), Bc, dt, c2.stream);
+      });
+    };
+  }
   Tn resblock(const Tn& x) {
     const bool tr = training;
     ResB r;
@@ -511,7 +542,13 @@ struct Engine {
       std::vector<Op> blk;
       std::swap(blk, bwd_cur);
       const size_t bsum = alloc((size_t)B * x.C * 4);           // per-sample column sums of out.g (bias gradient of conv c)
-      conv_bwd(r.t2, &r.nc, r.cc, out, false, false, false);    // side stream: dW_c (needs only out.g)
+      if (small_jobs) {
+        small_jobs->push_back(SmallJob{r.t2.off, out.goff, r.nc.state, r.cc.w, x.H, x.W, Fh, x.C, 1});
+        small_jobs->push_back(SmallJob{r.t1.off, r.t2.goff, r.nb.state, r.cb.w, x.H, x.W, Fh, Fh, 3});
+        small_jobs->push_back(SmallJob{x.off, r.t1.goff, r.na.state, r.ca.w, x.H, x.W, x.C, Fh, 1});
+      } else {
+        conv_bwd(r.t2, &r.nc, r.cc, out, false, false, false);    // side stream: dW_c (needs only out.g)
+      }
       bwd_cur.push_back([=](Ctx& c) {
         if (elim_mask() & 4) return 0;
         return pwr_resblock_bwd_small(c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
@@ -520,8 +557,10 @@ struct Engine {
                                       (float*)(c.arena + rb.nc.state), (float*)(c.arena + rb.na.sums), (float*)(c.arena + rb.nb.sums),
                                       (float*)(c.arena + rb.nc.sums), (float*)(c.arena + bsum), Bc, x.H, x.W, x.C, dt, c.stream);
       });
-      conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, false, false);   // side stream: dW_b from t2.g
-      conv_bwd(x, &r.na, r.ca, r.t1, false, false, false);      // side stream: dW_a from t1.g
+      if (!small_jobs) {
+        conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, false, false);   // side stream: dW_b from t2.g
+        conv_bwd(x, &r.na, r.ca, r.t1, false, false, false);      // side stream: dW_a from t1.g
+      }
       bwd_cur.push_back([=](Ctx& c) {
         return run_on_side(c, [=](Ctx& c2) {
           int rc = pwr_resblock_param_grads((float*)(c2.arena + rb.na.sums), (float*)(c2.arena + rb.nb.sums), (float*)(c2.arena + rb.nc.sums),
@@ -554,12 +593,18 @@ struct Engine {
     // the ops pushed by resblock(x) must run after everything below: take them out, put them back at the end
     std::vector<Op> after_a;
     std::swap(after_a, bwd_cur);
+    // everything between this level's pool and its up-sample lives on maps of 16x16 .. 2x2 (fused ResBlocks): their weight
+    // gradients go out as grouped launches
+    std::vector<SmallJob> jobs;
+    const bool own = tr && !small_jobs && PWR_DBG_ENV("PWR_WGRAD_GROUP", 1) != 0 && h0.H <= 16 && pwr_resblock_small_supported(h0.H, h0.W, h0.C, norm_mode, dtype);
+    if (own) small_jobs = &jobs;
     Tn h1 = lvl > 0 ? hourglass(h0, lvl - 1) : resblock(h0);
     std::vector<Op> after_inner;
     std::swap(after_inner, bwd_cur);
     Tn h2 = resblock(h1);
     std::vector<Op> after_h2;
     std::swap(after_h2, bwd_cur);
+    if (own) small_jobs = nullptr;
     Tn out = tensor(a.H, a.W, a.C, tr);
     fwd.push_back([=](Ctx& c) {
       return pwr_upsample_add_fwd(c.arena + h2.off, c.arena + a.off, c.arena + out.off, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream);
@@ -568,6 +613,8 @@ struct Engine {
       bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
       bwd_cur.insert(bwd_cur.end(), after_h2.begin(), after_h2.end());        // resblock h1 -> h2
       bwd_cur.insert(bwd_cur.end(), after_inner.begin(), after_inner.end());  // inner
+      for (size_t j0 = 0; own && j0 < jobs.size(); j0 += 24)                  // (<= 24 layers per grouped launch)
+        bwd_cur.push_back(small_group_op(std::vector<SmallJob>(jobs.begin() + j0, jobs.begin() + std::min(jobs.size(), j0 + 24))));
       bwd_cur.push_back([=](Ctx& c) {
         return pwr_maxpool_bwd(c.arena + a.off, c.arena + h0.goff, c.arena + out.goff, c.arena + a.goff, Bc, a.H, a.W, a.C, dt, c.stream);
       });

@@ -16,8 +16,17 @@ import torch
 import torch.distributed as dist
 
 
+MODES = ("segments", "end")
+
+
 class DataParallel:
-    def __init__(self, model, process_group=None, broadcast=True):
+    """mode 'segments' (default): one async all-reduce per finished backward segment, overlapped with the next segment.
+    mode 'end': ONE all-reduce of the whole flat gradient after the last segment (no overlap; the yardstick of tools/dist_overhead.py)."""
+
+    def __init__(self, model, process_group=None, broadcast=True, mode="segments"):
+        if mode not in MODES:
+            raise ValueError("mode must be one of %s" % (MODES,))
+        self.mode = mode
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.works = []
@@ -29,6 +38,10 @@ class DataParallel:
         model._ddp = self
 
     def segment_done(self, model, seg, nseg):
+        if self.mode == "end":
+            if seg == nseg - 1:
+                self.works.append(dist.all_reduce(model.flat_grad(), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         b, e = self.ranges[seg]
         self.works.append(dist.all_reduce(model.flat_grad()[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -6,6 +6,8 @@ same entry points from C++ without going through Python.  Activations are NHWC t
 """
 import struct
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -87,6 +89,33 @@ def conv_wgrad(x, dy, cout_real, ksize, stride=1, norm=None, relu_in=True, split
     _lib.check(l.pwr_conv_wgrad(_p(x), _p(dy), _p(norm), int(relu_in), _p(slab), _p(dw), int(acc), B, H, W, Cin, cin_real,
                                 Cout, cout_real, ksize, stride, splits, _dt(x), _s(x)), "pwr_conv_wgrad")
     return dw
+
+
+class _WgradJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("in_norm", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("cin_real", ctypes.c_int), ("Cout", ctypes.c_int), ("cout_real", ctypes.c_int),
+                ("ksize", ctypes.c_int), ("relu_in", ctypes.c_int)]
+
+
+def conv_wgrad_group(jobs):
+    """jobs: list of (x [B,H,W,Cin], dy [B,H,W,Cout], ksize, norm state or None): the weight gradients of all of them in one grouped
+    launch (pwr_conv_wgrad_group).  Returns the list of dw [Cout,Cin,k,k] fp32."""
+    l = _lib.lib()
+    B = jobs[0][0].shape[0]
+    arr = (_WgradJob * len(jobs))()
+    dws = []
+    for i, (x, dy, k, norm) in enumerate(jobs):
+        _, H, W, Cin = x.shape
+        Cout = dy.shape[-1]
+        dw = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=x.device)
+        dws.append(dw)
+        arr[i] = _WgradJob(_p(x), _p(dy), _p(norm), _p(dw), H, W, Cin, Cin, Cout, Cout, k, 1 if norm is not None else 0)
+    nbytes = l.pwr_conv_wgrad_group_slab_bytes(arr, len(jobs), B)
+    if not nbytes:
+        raise _lib.PwrError("pwr_conv_wgrad_group: unsupported job list")
+    slab = torch.empty(nbytes // 4, dtype=torch.float32, device=jobs[0][0].device)
+    _lib.check(l.pwr_conv_wgrad_group(arr, len(jobs), _p(slab), B, _dt(jobs[0][0]), _s(jobs[0][0])), "pwr_conv_wgrad_group")
+    return dws
 
 
 def stem_conv_fwd(img, w, bias, dtype):

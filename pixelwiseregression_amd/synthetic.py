@@ -150,6 +150,29 @@ def make_pose_batch(B, J, S=128, seed=0, device="cpu", dataset="NYU", cube_size=
             "cube_size": torch.full((B,), float(cube_size)), "com": com}
 
 
+def make_raw_frames(B, J, H=480, W=640, seed=0, device="cpu", dataset="NYU", cube_size=150.0):
+    """RAW depth frames as a depth camera delivers them (what datasets.py:182-199 loads from disk): [B,H,W] fp32 millimetres, 0 = no
+    measurement -- a hand-sized blob of smooth depth around the centre of mass, far clutter behind it -- with joints inside the blob
+    (uvd in pixels / mm) and the COM: the input of preprocess_batch.  Seeded, generated on the CPU, moved to `device`."""
+    from .metric import INTRINSICS
+    g = torch.Generator().manual_seed(int(seed))
+    fx, fy, hu, hv = INTRINSICS[dataset]
+    rnd = lambda *s_: torch.rand(*s_, generator=g)
+    cz = 550.0 + 300.0 * rnd(B)
+    cu, cv = 200 + 240 * rnd(B), 150 + 180 * rnd(B)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    rad = cube_size / cz * fx * (0.45 + 0.2 * rnd(B))
+    dx, dy = xx[None] - cu[:, None, None], yy[None] - cv[:, None, None]
+    blob = dx * dx + dy * dy < (rad * rad)[:, None, None]
+    depth = torch.where(blob, cz[:, None, None] + 60 * torch.sin(xx / 17.0)[None] * torch.cos(yy / 23.0)[None] + 0.1 * dx, torch.zeros(()))
+    clutter = (dx > 0.5 * rad[:, None, None]) & (dy > 0) & (~blob) & (dx < 1.4 * rad[:, None, None])
+    depth = torch.where(clutter, cz[:, None, None] + 400.0, depth)           # cut by the cube (datasets.py:251)
+    ang, rr = rnd(B, J) * 6.2831853, rad[:, None] * 0.5 * torch.sqrt(rnd(B, J))
+    joints = torch.stack([cu[:, None] + rr * torch.cos(ang), cv[:, None] + rr * torch.sin(ang), cz[:, None] + 50 * (rnd(B, J) - 0.5)], dim=2)
+    com = torch.stack([cu + 3 * (rnd(B) - 0.5), cv + 3 * (rnd(B) - 0.5), cz], dim=1)
+    return {"depth": depth.to(device), "joint_uvd": joints.double(), "com": com.double(), "cube_size": float(cube_size)}
+
+
 def joint_error_mm(uvd_pred, batch, dataset="NYU"):
     """Per-sample mean 3D joint error in mm of normalised predictions [B,J,3] against the batch's targets, exactly the
     validation metric of train.py:254-285: recover_uvd -> uvd2xyz -> mean over joints of the Euclidean distance."""

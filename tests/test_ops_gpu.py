@@ -202,6 +202,54 @@ def test_wgrad_split_k_reduce_is_repeatable_and_accumulates_exactly(case):
     assert torch.equal(K.conv_wgrad(x, dy, Cout, k, 1, splits=splits, dw=dw.clone()), dw + dw)
 
 
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 80), (3, 20, 96, 64, 64, 24), (2, 32, 32, 128, 64, 8), (2, 8, 32, 64, 128, 3), (5, 64, 64, 128, 128, 37)])
+def test_wgrad3_lds_dma_path(case):
+    """conv_wgrad_dma.hip: the 3x3 weight gradient with both operands staged by LDS-DMA (taken when the operand needs no norm).
+    (1) bit-identical to the register-staged kernel, which is reached with an IDENTITY norm state (mean 0, scale 1, beta 0, no ReLU:
+    fmaf(x - 0, 1, 0) == x) -- same accumulation order, same split-K slabs; (2) matches F.conv2d's float64 weight gradient, image
+    borders, ragged last split and all."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, splits = case
+    x, dy = rnd(B, Cin, H, W, seed=3), rnd(B, Cout, H, W, seed=4)
+    xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
+    ident = torch.zeros(4, B, Cin, device=DEV)
+    ident[1:3] = 1.0                                    # [mean, rstd, scale, beta] = [0, 1, 1, 0]
+    old = K.conv_wgrad(xd, dyd, Cout, 3, 1, norm=ident, relu_in=False, splits=splits)        # register-staged kernel
+    new = K.conv_wgrad(xd, dyd, Cout, 3, 1, norm=None, splits=splits)                        # LDS-DMA kernel
+    assert float(new.abs().max()) > 0 and torch.equal(old, new), float((old - new).abs().max())
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(q(x, torch.bfloat16), w, None, padding=1).backward(q(dy, torch.bfloat16))
+    assert_close(new.double().cpu(), w.grad, 1.5e-2, "LDS-DMA wgrad %s" % (case,))
+
+
+def test_grouped_weight_gradients_match_float64():
+    """pwr_conv_wgrad_group: the 24 conv layers of one stage's small-map ResBlocks (16x16 .. 2x2, 1x1 128->64, 3x3 64->64, 1x1 64->128,
+    norm + ReLU on the operand load) in ONE grouped launch, each against F.conv2d's float64 weight gradient; repeatable bit for bit."""
+    from pixelwiseregression_amd import kernels as K
+    B = 6
+    jobs, refs = [], []
+    seed = 0
+    for W in (16, 16, 8, 8, 4, 4, 2, 2):
+        for (cin, cout, k) in ((128, 64, 1), (64, 64, 3), (64, 128, 1)):
+            seed += 1
+            x, dy = rnd(B, cin, W, W, seed=seed), rnd(B, cout, W, W, seed=100 + seed)
+            gamma, beta = (1 + 0.2 * rnd(cin, seed=200 + seed)).float().to(DEV), (0.2 * rnd(cin, seed=300 + seed)).float().to(DEV)
+            xd = nhwc(x, torch.bfloat16)
+            st = K.norm_stats(xd, gamma, beta, mode=0)
+            xq = q(x, torch.bfloat16)
+            mean, scale, shift = (st[i].double().cpu()[:, :, None, None] for i in (0, 2, 3))
+            xin = q(torch.relu((xq - mean) * scale + shift), torch.bfloat16)
+            w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+            F.conv2d(xin, w, None, padding=k // 2).backward(q(dy, torch.bfloat16))
+            jobs.append((xd, nhwc(dy, torch.bfloat16), k, st))
+            refs.append(w.grad)
+    dws = K.conv_wgrad_group(jobs)
+    for i, (dw, ref) in enumerate(zip(dws, refs)):
+        assert_close(dw.double().cpu(), ref, 1.5e-2, "grouped wgrad job %d %s" % (i, tuple(ref.shape)))
+    again = K.conv_wgrad_group(jobs)
+    assert all(torch.equal(a, b_) for a, b_ in zip(dws, again))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_wgrad_padded_dy(dtype):
     """head's last conv: dy arrives as [B,P,P,Jp] with Jp > J zero-padded channels"""

@@ -63,6 +63,8 @@ VARIANTS = [
     ("neither", {"PWR_ELIM": "3"}),
     ("no data-gradient convs / fused ResBlock backwards", {"PWR_ELIM": "4"}),
     ("forward + loss + AdamW only (no backward kernels at all)", {"PWR_ELIM": "7"}),
+    ("no fork events: side launches NOT ordered behind the chain (what the event records cost the chain)", {"PWR_ELIM": "8"}),
+    ("no chain backward kernels, side work only (forward + parameter gradients)", {"PWR_ELIM": "6"}),
     ("everything on the caller's stream (no side streams): the serial sum", {"PWR_SIDE_STREAM": "0"}),
     ("one side stream", {"PWR_SIDE_STREAM": "1"}),
     ("side streams on 64 CUs (first 64 mask bits), chain unmasked", {"PWR_SIDE_CUS": "64"}),
@@ -82,7 +84,9 @@ if __name__ == "__main__":
     steps = sys.argv[1] if len(sys.argv) > 1 else "100"
     out = {"what": "train step, BASELINE configs[1] (B=32, bf16, AdamW), debug build, %s timed steps per variant after 20 warm-up; "
                    "results of the elimination variants are wrong by construction" % steps, "variants": []}
-    for name, env in VARIANTS:
+    only = os.environ.get("ELIM_ONLY")          # e.g. "0,6,7": a subset of the variants by index
+    sel = [int(i) for i in only.split(",")] if only else range(len(VARIANTS))
+    for name, env in [VARIANTS[i] for i in sel]:
         e = dict(os.environ, ELIM_CHILD="1", ELIM_STEPS=steps, **env)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=e, capture_output=True, text=True, timeout=600)
         ms = None
