@@ -211,7 +211,9 @@ def cpu_baseline(Bc=B_PER_GPU, warmup=3, iters=10, budget_s=60.0):
             "os_cpu_count": os.cpu_count(), "usable_cpus": usable, "thread_scan_s_per_forward": {str(k): round(v, 3) for k, v in scan.items()},
             "infer_value": Bc / ti,
             "sample": "median of %d timed train steps (fwd+loss+bwd+AdamW) after %d warm-up of the CPU oracle at batch %d (the config's), "
-                      "same architecture and 128x128 crops, fp32, %d threads (fastest of a scan over the usable CPUs); inference = median of 3 no_grad forwards"
+                      "same architecture and 128x128 crops, fp32, %d threads (fastest of a scan over the usable CPUs); inference = median of 3 no_grad forwards. "
+                      "Oracle vs the reference itself (build container, 8 threads, B=8, profiles/r3_ref_vs_oracle_cpu.json): train 0.88-0.99x, inference "
+                      "0.78-0.79x of the reference's speed -- `infer_value` understates the reference by about a fifth"
                       % (iters, warmup, Bc, cores)}
 
 

@@ -52,7 +52,9 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
             raise ValueError("extra_flags only with debug=True: the product library has one configuration")
         saved = (FLAGS, LIB, OBJ)
         bdir = os.path.join(ROOT, "tools", "_build")
-        FLAGS, LIB, OBJ = FLAGS + ["-DPWR_DEBUG_BUILD"] + list(extra_flags), os.path.join(bdir, "libpwr_hip_dbg.so"), os.path.join(bdir, "obj")
+        tag = "".join(c if c.isalnum() else "_" for c in "".join(extra_flags))        # a variant per set of extra flags
+        FLAGS, LIB, OBJ = (FLAGS + ["-DPWR_DEBUG_BUILD"] + list(extra_flags), os.path.join(bdir, "libpwr_hip_dbg%s.so" % tag),
+                           os.path.join(bdir, "obj" + tag))
         try:
             return build(force, verbose)
         finally:

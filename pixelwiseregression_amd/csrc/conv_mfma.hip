@@ -21,8 +21,16 @@ namespace pwr {
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------------------
+// PWR_OCC2(cond): second argument of __launch_bounds__ (minimum waves per SIMD) for the kernels meant to run two workgroups per CU.
+// Without it hipcc budgets a 256-thread kernel 512 registers and splits accumulators into AGPRs; told "2" it keeps everything within
+// 256 VGPRs.  Round 3, the patch conv: 6.62 -> 6.49 ms per train step from this hint alone (profiles/r3_experiments.md section 8).
+#ifndef PWR_OCC_HINT
+#define PWR_OCC_HINT 1
+#endif
+#define PWR_OCC2(cond) ((PWR_OCC_HINT && (cond)) ? 2 : 1)
+
 template <typename T, int WM, int WN, int MR, int NR>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, PWR_OCC2(sizeof(T) == 2)) void conv_fwd_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
   constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -625,7 +633,7 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradParams& p, int tap, int
 }
 
 template <int WM, int WN, int MR, int NR>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, PWR_OCC2(true)) void conv_wgrad_tr_kernel(WgradParams p) {
   __shared__ __attribute__((aligned(16))) char smem[WgradTrGeom<WM, WN, MR, NR>::LDS];
   wgrad_tr_body<WM, WN, MR, NR>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
@@ -644,7 +652,7 @@ struct WgradGroup {
   int n;
 };
 template <int WM, int WN, int MR, int NR>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_group_kernel(WgradGroup g) {
+__global__ __launch_bounds__(256, PWR_OCC2(true)) void conv_wgrad_tr_group_kernel(WgradGroup g) {
   __shared__ __attribute__((aligned(16))) char smem[WgradTrGeom<WM, WN, MR, NR>::LDS];
   const int b = blockIdx.x;
   int j = 0;
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_group_kernel(WgradGroup g) 
 // DBG (only instantiated in the debug build, tools/build_debug.py; PWR_WGRAD3_DBG selects): timing by elimination, results are WRONG --
 // 1 no MFMAs, 2 no fragment reads, 4 no norm / ReLU math in the staging, 16 no staging stores, 32 no global loads in the loop
 template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0>
-__global__ __launch_bounds__(256) void conv_wgrad3_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wgrad3_kernel(WgradParams p) {
   static_assert(DEPTH >= 2 && DEPTH % 2 == 0, "register stages: even, so that the LDS buffer parity follows the step parity");
   typedef bf16_t T;
   typedef bf16x8 V;

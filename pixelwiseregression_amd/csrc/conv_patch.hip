@@ -40,9 +40,18 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 // dy[a + oy, c + ox] for 1, 2, 2 or 4 taps (py = 0: ky = 1; py = 1: ky = 2 at oy = 0 and ky = 0 at oy = 1; same in x) -- a stride-1
 // patch conv over dy with a (1+py) x (1+px) window whose output is scattered to every second pixel.  Four launches (one per class)
 // replace the gather form of the universal kernel (180 us isolated for the stem's 128 <- 128 layer at 128x128).
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams p) {
+// MF = 16: the K loop issues v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same cycles per FLOP, same LDS reads per FLOP, same 64
+// accumulator registers for a 64 x 64 wave tile: 16 tiles of 4).  The chip holds its clock down under this kernel (all-zero operands:
+// 38.8 vs 47 - 49 us, profiles/r3_experiments.md section 6), and the clock it holds depends on the MFMA shape (MI355X_MICROARCH.md,
+// DVFS give-back item 7: build both at the same tile, keep the faster by wall on random data).
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32>
+#ifndef PWR_OCC_HINT
+#define PWR_OCC_HINT 1
+#endif
+__global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void conv3x3_patch_kernel(ConvParams p) {
   typedef typename Vec16<T>::type V;
+  static_assert(MF == 32 || (MF == 16 && sizeof(T) == 2 && DMA), "the 16x16x32 form exists for the bf16 LDS-DMA kernel");
+  constexpr int MR4 = MR * 2, NR4 = NR * 2;     // 16-row / 16-column blocks of the wave tile (MF == 16)
   constexpr int KE = Mma<T>::KE, EP = Mma<T>::EP;
   constexpr int NT = WM * WN * 64;                // threads per workgroup (256 or 512)
   constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
@@ -204,13 +213,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
   __syncthreads();     // (drains the two DMA stages in flight as well)
   stamp(p, 2);
 
-  f32x16 acc[MR][NR];
+  f32x16 acc[MF == 32 ? MR : 1][MF == 32 ? NR : 1];
+  f32x4 acc4[MF == 16 ? MR4 : 1][MF == 16 ? NR4 : 1];
+  if constexpr (MF == 32) {
 #pragma unroll
-  for (int i = 0; i < MR; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
-    for (int j = 0; j < NR; ++j)
+      for (int j = 0; j < NR; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MR4; ++i)
+#pragma unroll
+      for (int j = 0; j < NR4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   constexpr bool kTwoLevel = sizeof(T) == 4;
   f32x16 acc2[kTwoLevel ? MR : 1][kTwoLevel ? NR : 1];
   if constexpr (kTwoLevel) {
@@ -237,6 +254,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     bOff[j][0] = lds_off(wn * NR * 32 + j * 32 + r, h);
     bOff[j][1] = lds_off(wn * NR * 32 + j * 32 + r, 2 + h);
   }
+  // 16x16x32 operands: lane = row (pixel / output channel) % 16 + 16 * (K / 8): one fragment covers the whole 32-channel K chunk
+  const char* aBase4[MF == 16 ? MR4 : 1];
+  int bOff4[MF == 16 ? NR4 : 1];
+  if constexpr (MF == 16) {
+    const int r16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MR4; ++i) {
+      const int R = wm * MR * 32 + i * 16 + r16;
+      const int fs = R / SUBPIX, rr = R - fs * SUBPIX;
+      aBase4[i] = patch + (fs * PP + (rr / TW) * PW + rr % TW) * PITCH + kg * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < NR4; ++j) bOff4[j] = lds_off(wn * NR * 32 + j * 16 + r16, kg);
+  }
   // fully unrolled over (ky, kx, K chunk): every LDS offset, ring stage and wait count is a compile-time constant
   if constexpr (DMA) {
     // Weight ring of three LDS stages filled by LDS-DMA, fragments one K step AHEAD in registers:
@@ -252,6 +283,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       const int tap = it / KCH, kch = it - tap * KCH;
       const int ky = tap / NTX, kx = tap - ky * NTX;     // window offset of the tap inside the patch
       const char* lB = wbuf + (GEO == 1 ? it : it % 3) * WBUF_BYTES;
+      if constexpr (MF == 16) {       // (the [2][MR] / [2][NR] arrays hold the MR4 / NR4 fragments: same registers)
+#pragma unroll
+        for (int i = 0; i < MR4; ++i) a[i / MR][i % MR] = *reinterpret_cast<const V*>(aBase4[i] + (ky * PW + kx) * PITCH + kch * 64);
+#pragma unroll
+        for (int j = 0; j < NR4; ++j) bq[j / NR][j % NR] = *reinterpret_cast<const V*>(lB + bOff4[j]);
+        return;
+      }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
 #pragma unroll
@@ -287,6 +325,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
       // MFMAs (sched_group_barrier pipeline below); issuing all ten memory instructions first left the matrix pipe idle for
       // ~150 cycles per step.
       if constexpr (sizeof(T) != 2) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MF == 16) {
+#pragma unroll
+        for (int i = 0; i < MR4; ++i)
+#pragma unroll
+          for (int j = 0; j < NR4; ++j)
+            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it & 1][i / MR][i % MR], fb[it & 1][j / NR][j % NR], acc4[i][j], 0, 0, 0);
+      } else
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -302,7 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
             }
           }
       if constexpr (sizeof(T) == 2) {
-        constexpr int NMFMA = 2 * MR * NR, NREAD = 2 * (MR + NR);
+        constexpr int NMFMA = MF == 16 ? MR4 * NR4 : 2 * MR * NR, NREAD = 2 * (MR + NR);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
         if (GEO != 1 && it + 3 < ITERS) __builtin_amdgcn_sched_group_barrier(0x010, NBW, 0);   // the LDS-DMA of stage it+3
         if (it + 1 < ITERS) {
@@ -416,6 +461,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_patch_kernel(ConvParams 
     const int wrow0 = wm * MR * 32;
     if (wrow0 / EROWS == ps) {
       const int er0 = wrow0 - ps * EROWS;
+      if constexpr (MF == 16) {       // D[i][j] of a 16x16 tile: lane = j + 16 * (i / 4), element i % 4
+#pragma unroll
+        for (int i = 0; i < MR4; ++i)
+#pragma unroll
+          for (int j = 0; j < NR4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              E[(er0 + i * 16 + 4 * (lane >> 4) + e) * EPITCH + wn * NR * 32 + j * 16 + (lane & 15)] = acc4[i][j][e];
+      } else
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -583,6 +637,15 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
       if (big64(p, PWR_BF16)) {
         dim3 g8(p.B * (p.H / 8) * (p.W / 32), p.CoutPad / bn);
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 4, 2, 2, 1, true>), g8, dim3(512), 0, s, p);
+        return (int)hipGetLastError();
+      }
+    }
+    // the 128 -> 128 tile (the heads' convs and their data gradients: 72 % of the FLOPs) issues 16x16x32 MFMAs: bit-identical
+    // results, 2 - 9 % less time isolated, 0.04 ms per train step (PWR_PATCH_MF16=0 in the debug build: the 32x32x16 form; extending
+    // it to the other tiles, the 1x1 form and the stride-2 classes gave nothing more: profiles/r3_experiments.md section 8)
+    if constexpr (sizeof(T) == 2 && CIN == 128) {
+      if (bn == 128 && PWR_DBG_ENV("PWR_PATCH_MF16", 1) != 0) {
+        hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, p);
         return (int)hipGetLastError();
       }
     }

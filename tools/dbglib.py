@@ -9,7 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 from pixelwiseregression_amd import _lib
 
-DBG = os.path.join(ROOT, "tools", "_build", "libpwr_hip_dbg.so")
+DBG = os.path.join(ROOT, "tools", "_build", os.environ.get("PWR_DBGLIB", "libpwr_hip_dbg.so"))    # PWR_DBGLIB: a variant built with extra flags
 if _lib._lib is not None:
     raise RuntimeError("dbglib must be imported before the product library is loaded")
 if not os.path.exists(DBG):
