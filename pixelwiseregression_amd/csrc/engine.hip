@@ -623,6 +623,15 @@ struct Engine {
     return out;
   }
 
+  // Channel padding of the two narrow NHWC tensors of the network -- the heads' output gradient (J channels) and the stage-input
+  // concat (2J + 1 channels).  bf16: up to the 32 / 64 channels of a whole K chunk, so that the convs reading them are served by the
+  // LDS-patch kernels (Cin in {32, 64, 128}) instead of the universal implicit-GEMM kernel: at C2 the heads' last data gradient
+  // (16 -> 128 channels, 4.8 GFLOP) took 50 - 70 us there, four times per step on the chain.  The weight packs already span whole
+  // K chunks (zero-filled), so nothing else changes.  fp32 (K chunks of 16) and wider tensors keep the multiple of 8.
+  int pad_narrow(int c) const {
+    if (dtype == PWR_BF16 && c <= 64 && PWR_DBG_ENV("PWR_PAD_NARROW", 1)) return c <= 32 ? 32 : 64;
+    return (c + 7) / 8 * 8;
+  }
   // ---- one regression head (model.py:54-65 / 103-114) ending in an NCHW fp32 map
   struct Head { ConvL c0, c1, c2, c3; NormL n0, n1, n2; Tn h1, h2, h3; size_t gT; };
   // out_sel: 0 -> logits z in the arena (z_off), 1 -> external depthmaps output
@@ -644,7 +653,7 @@ struct Engine {
       return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.state),
                           1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
     });
-    const int Jp = (J + 7) / 8 * 8;
+    const int Jp = pad_narrow(J);
     h.gT = tr ? alloc((size_t)B * P * P * Jp * esz, "gT") : 0;
     return h;
   }
@@ -652,7 +661,7 @@ struct Engine {
   void head_bwd(const Tn& f, const Head& h, size_t g_nchw_off, bool accumulate_df) {
     const int Bc = B, dt = dtype, Jc = J, Pc = P;
     scope = "s" + std::to_string(cur_stage) + (accumulate_df ? ".depth.bwd" : ".plane.bwd");
-    const int Jp = (J + 7) / 8 * 8;
+    const int Jp = pad_narrow(J);
     const int M = B * P * P;
     const int splits = splits_for(M, F, Jp, ks);
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits));
@@ -735,7 +744,7 @@ struct Engine {
       scope = "s" + std::to_string(s) + ".in";
       Tn x0;
       ConvL cin;
-      const int Cp = (2 * J + 1 + 7) / 8 * 8;
+      const int Cp = pad_narrow(2 * J + 1);
       Tn xc;  // NHWC concat [B,P,P,Cp] for stages >= 1
       if (s == 0) {
         cin = conv_params(F, F, 1, 1, true, true);
