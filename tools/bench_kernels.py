@@ -31,6 +31,11 @@ if which in ("all", "fwd"):
     t = timeit(lambda: K.conv_fwd(x, pack, F_, 3, 1))
     print(json.dumps({"kernel": "conv3x3_patch (no prologue: dgrad form)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
 if which in ("all", "wgrad"):
-    for splits in (40, 57, 80, 85, 86, 96, 120, 160):
+    # the engine's split count for this layer (80) only, so that the rocprofv3 average of these launches is the number quoted in
+    # DESIGN.md; `sweep` as third argument walks the split counts (round 2's 81 us "average" was over such a sweep)
+    sweep = len(sys.argv) > 3 and sys.argv[3] == "sweep"
+    for splits in ((40, 57, 80, 85, 86, 96, 120, 160) if sweep else (80,)):
         t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=st, splits=splits))
-        print(json.dumps({"kernel": "conv_wgrad_tr + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+        print(json.dumps({"kernel": "conv_wgrad3 (norm on load, register-staged) + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+        t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=None, splits=splits))
+        print(json.dumps({"kernel": "conv_wgrad3d (no norm, LDS-DMA) + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
