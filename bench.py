@@ -453,7 +453,7 @@ def main():
             # HBM bytes per launch: NOT measured in this run -- replayed from the committed rocprofv3 PMC passes of the same kernel
             # and shape (PMC collection needs its own rocprofv3 runs); `traffic_source` names the file
             traffic, traffic_source = None, None
-            for tj in ("r2_traffic.json", "r1_traffic.json"):
+            for tj in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 fp = os.path.join(ROOT, "profiles", tj)
                 if os.path.exists(fp):
                     traffic = None if args.precision != "bf16" else json.load(open(fp)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
@@ -468,13 +468,17 @@ def main():
                 out["roofline"]["vendor_gemm_same_shape"] = vendor_gemm_yardstick(dev, B_PER_GPU)
             td, nb = time_decoder(dev, B_PER_GPU)
             dtraffic = None
-            fp = os.path.join(ROOT, "profiles", "r2_traffic.json")
-            if os.path.exists(fp):
-                dtraffic = json.load(open(fp)).get("decode_fwd B=%d J=%d P=%d" % (B_PER_GPU, J, P), {}).get("hbm_bytes_corrected")
+            dsrc = None
+            for tj in ("r3_traffic.json", "r2_traffic.json"):
+                fp = os.path.join(ROOT, "profiles", tj)
+                if os.path.exists(fp) and dtraffic is None:
+                    dtraffic = json.load(open(fp)).get("decode_fwd B=%d J=%d P=%d" % (B_PER_GPU, J, P), {}).get("hbm_bytes_corrected")
+                    dsrc = "profiles/" + tj
             out["roofline_decoder"] = {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": dtraffic, "traffic_source": "profiles/r2_traffic.json",
+                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": dtraffic, "traffic_source": dsrc,
                                        "us_per_launch": td * 1e6,
-                                       "note": "23 MB per launch: launch / latency bound at this shape; HBM bound at the C5 shape (profiles/r2_dec_bench.jsonl: 4.3 / 4.7 TB/s)"}
+                                       "note": "23 MB per launch: launch / latency bound at this shape (the rocprofv3 average of the same probe is ~1 us longer than this "
+                                               "HIP-event figure: profiles/r3_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r3_dec_bench.jsonl)"}
         if world == 1 and args.with_pipeline and native:
             model.train()
             out["pipeline"] = pipeline_block(model, trainer, dev, max(10, min(args.steps, 100)))
