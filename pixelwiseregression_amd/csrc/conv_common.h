@@ -27,6 +27,7 @@ struct ConvParams {
   const float* nb_state = nullptr;
   float* nb_partial = nullptr;
   int nb_relu = 1;
+  int epi16 = 1;            // (debug build: 0 = the two-pass fp32 epilogue also for the 16x16x32 tile)
 };
 
 struct WgradParams {

@@ -422,6 +422,83 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
     else return (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
   };
   stamp(p, 3);
+  // ---- epilogue of the 16x16x32 form (128 x 128 tile, bf16 NHWC output, no residual): ONE pass through a bf16 image.
+  // A lane holds 4 consecutive pixels of one channel per 16x16 tile, so it writes them (+ bias, rounded) as ONE 8-byte store into a
+  // CHANNEL-major image [128 channels][128 pixels] whose 16-byte chunks are XOR-swizzled (cdna_hip_programming.md T10, image (b));
+  // ds_read_b64_tr_b16 hands them back pixel-major: lane i of a 16-lane group gets pixel 16 it + i, 4 channels per read, 2 reads =
+  // the 16-byte NHWC vector it stores.  32 LDS instructions and 64 KB of LDS traffic per thread-tile instead of 80 and 128 KB for
+  // the two fp32 passes below, two barriers instead of four; same values (fp32 accumulator + bias, one rounding), same statistics
+  // up to the order of their fixed-order sums.
+  if constexpr (MF == 16 && TW == 32 && GEO == 0 && MR4 == 4 && NR4 == 4) {
+    if (p.y && !p.y_nchw && !p.residual && p.Cout % BN == 0 && p.epi16) {
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
+      char* E16 = smem;
+      auto eoff = [](int ch, int chunk) { return 256 * ch + 16 * (chunk ^ (((ch & 3) << 2) | ((ch >> 2) & 3))); };
+      {
+        const int c15 = lane & 15, rg = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < NR4; ++j) {
+          const int col = wn * NR * 32 + j * 16 + c15;
+          const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < MR4; ++i) {
+            const int r0 = wm * MR * 32 + i * 16 + 4 * rg;
+            bf16x4_e v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc4[i][j][e] + bv);
+            *reinterpret_cast<bf16x4_e*>(E16 + eoff(col, r0 >> 3) + 8 * ((r0 >> 2) & 1)) = v;
+          }
+        }
+      }
+      __syncthreads();
+      const int slot = 4 * wid + (lane >> 4), cb = slot * EP, n = n0 + cb;     // this thread's 8 channels, all its vectors
+      const int li = lane & 15, q4 = li >> 2, p4 = li & 3;
+      EpiStats<T> est;
+      est.init(p, b, n);
+      if (est.kind == 1) {      // shift of the forward statistics: the tile's first pixel (uniform over the threads of a slot)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) est.a0[e] = (float)*reinterpret_cast<const bf16_t*>(E16 + eoff(cb + e, 0));
+      }
+      const T* __restrict__ nby = est.kind == 2 ? reinterpret_cast<const T*>(p.nb_y) : reinterpret_cast<const T*>(p.w);
+      T* __restrict__ y = reinterpret_cast<T*>(p.y);
+      V ypre[8];
+      size_t mrow[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        mrow[it] = out_m(16 * it + li);
+        ypre[it] = *reinterpret_cast<const V*>(nby + (est.kind == 2 ? mrow[it] * p.Cout + n : 0));
+      }
+      typedef __attribute__((address_space(3))) bf16x4_e* lptr;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int px = 16 * it + 4 * p4;                     // first of the 4 pixels whose address this lane supplies
+        const int ck = px >> 3, hf = 8 * ((px >> 2) & 1);
+        const bf16x4_e lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(E16 + eoff(cb + q4, ck) + hf));
+        const bf16x4_e hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(E16 + eoff(cb + 4 + q4, ck) + hf));
+        V o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3]; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        *reinterpret_cast<V*>(y + mrow[it] * p.Cout + n) = o;
+        est.add_pre(p, o, ypre[it]);
+      }
+      if (est.kind) {           // the 16 lanes of a group share the slot: fixed-order butterfly, lane 0 of the group writes
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < EP; ++e) { est.s1[e] += __shfl_xor(est.s1[e], o, 64); est.s2[e] += __shfl_xor(est.s2[e], o, 64); }
+        if (li == 0) {
+          float* out = est.kind == 1 ? p.st_partial + ((size_t)(b * tiles_img + tr) * 3) * p.Cout : p.nb_partial + ((size_t)(b * tiles_img + tr) * 2) * p.Cout;
+#pragma unroll
+          for (int e = 0; e < EP; ++e) {
+            out[n + e] = est.s1[e];
+            out[(size_t)p.Cout + n + e] = est.s2[e];
+            if (est.kind == 1) out[(size_t)2 * p.Cout + n + e] = est.a0[e];
+          }
+        }
+      }
+      stamp(p, 4);
+      return;
+    }
+  }
   // ---- epilogue: accumulators -> LDS (fp32, 64 tile pixels at a time) -> coalesced 16-byte stores
   float* E = reinterpret_cast<float*>(smem);
   constexpr int PASSES = BM / EROWS;
@@ -645,6 +722,7 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
     // it to the other tiles, the 1x1 form and the stride-2 classes gave nothing more: profiles/r3_experiments.md section 8)
     if constexpr (sizeof(T) == 2 && CIN == 128) {
       if (bn == 128 && PWR_DBG_ENV("PWR_PATCH_MF16", 1) != 0) {
+        const_cast<ConvParams&>(p).epi16 = PWR_DBG_ENV("PWR_PATCH_EPI16", 1);
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, p);
         return (int)hipGetLastError();
       }
