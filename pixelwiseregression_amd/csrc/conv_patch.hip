@@ -720,8 +720,9 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
     // the 128 -> 128 tile (the heads' convs and their data gradients: 72 % of the FLOPs) issues 16x16x32 MFMAs: bit-identical
     // results, 2 - 9 % less time isolated, 0.04 ms per train step (PWR_PATCH_MF16=0 in the debug build: the 32x32x16 form; extending
     // it to the other tiles, the 1x1 form and the stride-2 classes gave nothing more: profiles/r3_experiments.md section 8)
-    if constexpr (sizeof(T) == 2 && CIN == 128) {
-      if (bn == 128 && PWR_DBG_ENV("PWR_PATCH_MF16", 1) != 0) {
+    if constexpr (sizeof(T) == 2) {
+      const int mf16 = PWR_DBG_ENV("PWR_PATCH_MF16", 1);      // 0: 32x32x16 everywhere, 1: 16x16x32 for 128 -> 128 only, 2: for every Cin at 128 output channels (measured: train step +1.3 %, inference -1 %)
+      if (bn == 128 && (mf16 == 2 || (mf16 == 1 && CIN == 128))) {
         const_cast<ConvParams&>(p).epi16 = PWR_DBG_ENV("PWR_PATCH_EPI16", 1);
         hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, p);
         return (int)hipGetLastError();
