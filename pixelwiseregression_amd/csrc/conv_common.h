@@ -37,6 +37,7 @@ struct WgradParams {
   float* slab;            // [S][taps][CinPad128][CoutPad] fp32 partials
   int B, H, W, Cin, Ho, Wo, Cout, CoutPad, CinPad;
   int ksize, stride, pad, relu_in, M, S, steps_per_split;
+  int dbg = 0;            // debug build only: elimination bits of conv_wgrad3d_kernel (1 no MFMA, 2 no fragment reads, 4 no DMA after the prologue, 8 no slab stores)
 };
 
 template <typename T> struct Mma;

@@ -170,8 +170,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3d_kernel(WgradParams p) {
     }
     __builtin_amdgcn_s_barrier();
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#ifdef PWR_DEBUG_BUILD
+    if (st + 3 < nsteps && !(p.dbg & 4)) issue((stage + 3) & (NS - 1));
+    if (rowok && !(p.dbg & 2)) {
+#else
     if (st + 3 < nsteps) issue((stage + 3) & (NS - 1));     // into the stage that was read during step st - 1
     if (rowok) {
+#endif
       V bf[2][NR], af[2][3][MR];
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -192,6 +197,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3d_kernel(WgradParams p) {
 #pragma unroll
           for (int i = 0; i < MR; ++i) asm volatile("" : "+v"(af[ss][t][i]));
       }
+#ifdef PWR_DEBUG_BUILD
+      if (!(p.dbg & 1))
+#endif
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -219,6 +227,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3d_kernel(WgradParams p) {
   // (no DMA may still be in flight when the workgroup's LDS is released)
   __builtin_amdgcn_s_waitcnt(0x0070);
   const int r = lane & 31, h = lane >> 5;
+#ifdef PWR_DEBUG_BUILD
+  if (p.dbg & 8) return;
+#endif
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     float* __restrict__ out = p.slab + ((size_t)(split * 9 + ky * 3 + t) * p.CinPad) * p.CoutPad;
@@ -242,7 +253,9 @@ bool wgrad3d_applicable(const WgradParams& p) {
          p.CoutPad == p.Cout;
 }
 
-int launch_wgrad3d(const WgradParams& p, hipStream_t s) {
+int launch_wgrad3d(const WgradParams& p0, hipStream_t s) {
+  WgradParams p = p0;
+  p.dbg = PWR_DBG_ENV("PWR_WGRAD3D_DBG", 0);
   const int bn = p.Cout % 128 == 0 ? 128 : 64;
   dim3 grid(24 * ((p.S + 7) / 8), (p.Cin / 64) * (p.CoutPad / bn), 1), block(256);
   if (bn == 128) hipLaunchKernelGGL((conv_wgrad3d_kernel<64, 128>), grid, block, 0, s, p);
