@@ -100,7 +100,8 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
 
 
 def _scan_gate(lib, verbose=True):
-    """No packed f32 instruction with a cross-half op_sel may ship: checked on every link."""
+    """No packed f32 instruction with a cross-half op_sel may ship, and no instruction may touch the
+    destination of an inline-asm LDS read before its wait (conv_wgrad_dma.hip): checked on every link."""
     from . import codeobj_scan
     if not codeobj_scan.available():
         if verbose:
@@ -112,8 +113,13 @@ def _scan_gate(lib, verbose=True):
         raise RuntimeError("%s contains %d packed f32 instructions with a cross-half op_sel (e.g. %s): the build flags lost "
                            "-fno-slp-vectorize or hand-written packed math was added -- see DESIGN.md section 2"
                            % (lib, r["packed_f32_cross_half_op_sel"], r["examples"][:2]))
+    if r["async_lds_hazards"]:
+        os.remove(lib)
+        raise RuntimeError("%s: %d instructions touch the destination of an inline-asm LDS read before the s_waitcnt that covers it "
+                           "(e.g. %s) -- see codeobj_scan.async_lds_hazards" % (lib, r["async_lds_hazards"], r["async_lds_examples"][:2]))
     if verbose:
-        print("[pwr build] code-object scan ok: %d functions, %d packed f32, 0 with cross-half op_sel" % (r["functions"], r["packed_f32"]), flush=True)
+        print("[pwr build] code-object scan ok: %d functions, %d packed f32, 0 with cross-half op_sel, 0 uses of an LDS read in flight"
+              % (r["functions"], r["packed_f32"]), flush=True)
 
 
 if __name__ == "__main__":

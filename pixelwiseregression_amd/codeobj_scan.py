@@ -59,8 +59,58 @@ def scan(lib):
     n_kernels = len(re.findall(r"^[0-9a-f]+ <[^>]+>:", txt, flags=re.M))
     pk = [l for l in txt.splitlines() if PK.search(l)]
     cross = [l for l in pk if CROSS.search(l)]
+    hz = async_lds_hazards(txt)
     return {"functions": n_kernels, "instructions": txt.count("\n"), "packed_f32": len(pk), "packed_f32_cross_half_op_sel": len(cross),
-            "examples": [c.split("//")[0].strip() for c in cross[:5]]}
+            "examples": [c.split("//")[0].strip() for c in cross[:5]], "async_lds_hazards": len(hz), "async_lds_examples": hz[:5]}
+
+
+def _vregs(text):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def async_lds_hazards(txt, name_filter="wgrad3d"):
+    """The kernels of csrc/conv_wgrad_dma.hip read LDS through inline asm (so that the compiler's wait-count pass does not fence the
+    LDS-DMA prefetches).  The compiler then believes an asm's output register is defined when the statement ends, while the data of
+    a ds_read arrives later: any instruction that touches such a register between the read and the `s_waitcnt lgkmcnt` covering it
+    copies or clobbers stale data -- round 3 shipped-candidate build had exactly that (a v_mov the register allocator put in front
+    of a wait where two paths merged; wrong weight gradients in roughly one launch of ten).  Linear scan per kernel, LDS operations
+    retire in order.  Returns the list of offending instruction lines."""
+    bad, cur, pending = [], None, []
+    for ln in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
+        if m:
+            cur, pending = (m.group(1) if name_filter in m.group(1) else None), []
+            continue
+        if cur is None:
+            continue
+        t = ln.split("//")[0].strip()
+        if not t:
+            continue
+        op = t.split()[0]
+        rest = t[len(op):]
+        busy = set().union(*[d for d in pending]) if pending else set()
+        if op.startswith("ds_"):
+            if busy & _vregs(rest):
+                bad.append(cur[:48] + ": " + t)
+            pending.append(_vregs(rest.split(",")[0]) if op.startswith("ds_read") else set())
+            continue
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                while len(pending) > int(m.group(1)):
+                    pending.pop(0)
+            continue
+        if op.startswith("s_"):
+            continue
+        if busy & _vregs(rest):
+            bad.append(cur[:48] + ": " + t)
+    return bad
 
 
 if __name__ == "__main__":

@@ -205,9 +205,9 @@ def test_wgrad_split_k_reduce_is_repeatable_and_accumulates_exactly(case):
 @pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 80), (3, 20, 96, 64, 64, 24), (2, 32, 32, 128, 64, 8), (2, 8, 32, 64, 128, 3), (5, 64, 64, 128, 128, 37)])
 def test_wgrad3_lds_dma_path(case):
     """conv_wgrad_dma.hip: the 3x3 weight gradient with both operands staged by LDS-DMA (taken when the operand needs no norm).
-    (1) bit-identical to the register-staged kernel, which is reached with an IDENTITY norm state (mean 0, scale 1, beta 0, no ReLU:
-    fmaf(x - 0, 1, 0) == x) -- same accumulation order, same split-K slabs; (2) matches F.conv2d's float64 weight gradient, image
-    borders, ragged last split and all."""
+    (1) bit-identical to the kernel that applies a norm on the way -- the register-staged one for 128-wide output tiles, the in-LDS
+    variant for 64-wide ones -- run with an IDENTITY norm state (mean 0, scale 1, beta 0, no ReLU: fmaf(x - 0, 1, 0) == x): same
+    accumulation order, same split-K slabs; (2) matches F.conv2d's float64 weight gradient, image borders, ragged last split and all."""
     from pixelwiseregression_amd import kernels as K
     B, H, W, Cin, Cout, splits = case
     x, dy = rnd(B, Cin, H, W, seed=3), rnd(B, Cout, H, W, seed=4)
@@ -220,6 +220,30 @@ def test_wgrad3_lds_dma_path(case):
     w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(q(x, torch.bfloat16), w, None, padding=1).backward(q(dy, torch.bfloat16))
     assert_close(new.double().cpu(), w.grad, 1.5e-2, "LDS-DMA wgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(6, 64, 64, 64, 64, 37), (3, 20, 96, 64, 64, 24), (2, 32, 32, 128, 64, 8), (9, 32, 32, 64, 64, 5), (4, 128, 128, 64, 64, 40)])
+def test_wgrad3_lds_dma_norm_in_lds(case):
+    """conv_wgrad_dma.hip, NRM variant (taken for 64-wide output tiles): the operand's pending norm + ReLU applied IN LDS to the tile
+    the LDS-DMA landed, one step ahead of the MFMAs.  Against F.conv2d's float64 weight gradient of the normalised, bf16-rounded
+    operand -- splits that straddle a sample (the per-sample norm state changes inside the split), image borders, ragged last split --
+    and bit-identical over repeated launches: the first build of this variant used a register the LDS read had not filled yet in
+    about one launch of ten (pixelwiseregression_amd/codeobj_scan.py: async_lds_hazards is the static gate for that)."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, splits = case
+    x, dy = rnd(B, Cin, H, W, seed=13), rnd(B, Cout, H, W, seed=14)
+    gamma, beta = (1 + 0.3 * rnd(Cin, seed=15)).float().to(DEV), (0.3 * rnd(Cin, seed=16)).float().to(DEV)
+    xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
+    st = K.norm_stats(xd, gamma, beta, mode=0)
+    outs = [K.conv_wgrad(xd, dyd, Cout, 3, 1, norm=st, relu_in=True, splits=splits).clone() for _ in range(12)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), float((outs[0] - o).abs().max())
+    xq = q(x, torch.bfloat16)
+    mean, scale, shift = (st[i].double().cpu()[:, :, None, None] for i in (0, 2, 3))
+    xin = q(torch.relu((xq - mean) * scale + shift), torch.bfloat16)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w, None, padding=1).backward(q(dy, torch.bfloat16))
+    assert_close(outs[0].double().cpu(), w.grad, 1.5e-2, "LDS-DMA wgrad with the norm in LDS %s" % (case,))
 
 
 def test_grouped_weight_gradients_match_float64():
