@@ -40,10 +40,18 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 // dy[a + oy, c + ox] for 1, 2, 2 or 4 taps (py = 0: ky = 1; py = 1: ky = 2 at oy = 0 and ky = 0 at oy = 1; same in x) -- a stride-1
 // patch conv over dy with a (1+py) x (1+px) window whose output is scattered to every second pixel.  Four launches (one per class)
 // replace the gather form of the universal kernel (180 us isolated for the stem's 128 <- 128 layer at 128x128).
+// GEO = 6: the FORWARD of a stride-2 3x3 conv (the stem's last layer, model.py:182): y[oy, ox] reads x[2 oy + ky - 1, 2 ox + kx - 1], i.e.
+// tap (ky, kx) reads the input pixels of parity class (ky != 1, kx != 1), which form a stride-1 image of their own.  The workgroup walks
+// the four classes one after the other -- stage the class's (TH+1) x 33 window of the tile (every second pixel of the input, norm +
+// ReLU on the way), run its 1, 2, 2 or 4 taps out of LDS, next class -- into ONE set of accumulators; the weight ring runs through.
+// 9 taps x KCH K steps like the stride-1 conv, 4 x 165 staged pixels per 128 outputs (the universal implicit-GEMM kernel, which
+// gathered 9 x 128 pixels per tile with a global-load round trip per K step, took 138 us for the FLOPs of a 43-us head conv).
 // MF = 16: the K loop issues v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same cycles per FLOP, same LDS reads per FLOP, same 64
 // accumulator registers for a 64 x 64 wave tile: 16 tiles of 4).  The chip holds its clock down under this kernel (all-zero operands:
 // 38.8 vs 47 - 49 us, profiles/r3_experiments.md section 6), and the clock it holds depends on the MFMA shape (MI355X_MICROARCH.md,
 // DVFS give-back item 7: build both at the same tile, keep the faster by wall on random data).
+__host__ __device__ constexpr int s2_tap(int q) { return q == 0 ? 4 : q == 1 ? 3 : q == 2 ? 5 : q == 3 ? 1 : q == 4 ? 7 : q == 5 ? 0 : q == 6 ? 2 : q == 7 ? 6 : 8; }
+__host__ __device__ constexpr bool s2_first(int q) { return q == 0 || q == 1 || q == 3 || q == 5; }       // first tap position of a class
 template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32>
 #ifndef PWR_OCC_HINT
 #define PWR_OCC_HINT 1
@@ -58,12 +66,16 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   constexpr int TH = WM * MR;                     // tile rows of the TW == 32 form
   constexpr int RH = TW == 32 ? TH : (TW * TW < BM ? TW : BM / TW);   // rows of one sub-block
   constexpr int SUBPIX = RH * TW, SUB = BM / SUBPIX;                  // 128-pixel tile = SUB sub-blocks of RH x TW pixels
-  constexpr bool TR = GEO >= 2;
+  constexpr bool TR = GEO >= 2 && GEO <= 5;
+  constexpr bool S2 = GEO == 6;
+  static_assert(!S2 || (DMA && TW == 32 && MF == 32), "the stride-2 forward form: bf16 LDS-DMA kernel, 4 x 32 tile");
   constexpr int CPY = TR ? ((GEO - 2) >> 1) : 0, CPX = TR ? ((GEO - 2) & 1) : 0;
   constexpr int HALO = GEO == 0 ? 1 : 0;
-  constexpr int NTY = TR ? CPY + 1 : (GEO == 0 ? 3 : 1), NTX = TR ? CPX + 1 : (GEO == 0 ? 3 : 1);     // taps per axis
-  constexpr int PH = RH + (TR ? CPY : 2 * HALO), PW = TW + (TR ? CPX : 2 * HALO), PP = PH * PW, NPIX = SUB * PP;
+  constexpr int NTY = TR ? CPY + 1 : ((GEO == 0 || S2) ? 3 : 1), NTX = TR ? CPX + 1 : ((GEO == 0 || S2) ? 3 : 1);     // taps per axis
+  constexpr int PH = RH + (TR ? CPY : (S2 ? 1 : 2 * HALO)), PW = TW + (TR ? CPX : (S2 ? 1 : 2 * HALO)), PP = PH * PW, NPIX = SUB * PP;
   static_assert(!TR || TW == 32, "the transposed classes use the 4 x 32 tile");
+  // S2: K steps in class order -- tap position q -> kernel tap ky * 3 + kx; class 0: (1,1); 1: (1,0) (1,2); 2: (0,1) (2,1); 3: the corners
+  // (s2_tap / s2_first above the kernel)
   constexpr int NSLOT = CIN / EP;                 // 16-byte slots per pixel
   constexpr int KCH = CIN / KE;                   // 64-byte K chunks per tap
   // weight stage (tap-major index into the pack) of K step `it`; the window offset of its tap inside the patch is (it's ty, tx)
@@ -73,6 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
     int wt;
     if (GEO == 0) wt = ty * 3 + tx;
     else if (GEO == 1) wt = 0;
+    else if (S2) wt = s2_tap(tap);
     else wt = (CPY ? (ty == 0 ? 2 : 0) : 1) * 3 + (CPX ? (tx == 0 ? 2 : 0) : 1);
     return wt * KCH + kch;
   };
@@ -92,9 +105,10 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   const int wm = wid / WN, wn = wid % WN;
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int HW = p.H * p.W;
+  const int OW = S2 ? p.Wo : p.W, OH = S2 ? p.Ho : p.H, OHW = OW * OH;      // the image the tiles cover (S2: the output, half the input)
   int b = 0, ty0 = 0, tx0 = 0, tr = 0, tiles_img = 1;
   if constexpr (TW == 32) {
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH;   // requires H % TH == 0
+    const int tiles_x = OW / TW, tiles_y = OH / TH;   // requires H % TH == 0
     tiles_img = tiles_x * tiles_y;
     b = t / tiles_img;
     tr = t - b * tiles_img;
@@ -155,59 +169,76 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   }
 
   // ---- stage the patch: thread -> fixed sub-block and 16-byte channel slot, pixels pl + k*PL of that sub-block
-  {
-    constexpr int TPS = NT / SUB, PL = TPS / NSLOT;
-    static_assert(TPS % NSLOT == 0 && PL >= 1, "sub-block needs at least one thread per channel slot");
-    constexpr int NIT = (PP + PL - 1) / PL;
-    const int sub = tid / TPS, pl = (tid % TPS) / NSLOT, slot = tid % NSLOT;
-    int sb = b, sy0 = ty0, sx0 = tx0;
-    bool sv = true;
-    if constexpr (TW != 32) {
-      const long long Ls = L0 + sub * SUBPIX;
-      sv = Ls < Mtot;
-      sb = sv ? (int)(Ls / HW) : 0;
-      sy0 = ((int)(Ls - (long long)sb * HW)) / TW; sx0 = 0;
-    }
-    const T* __restrict__ xs = x + (size_t)sb * HW * CIN;
-    float mu[EP], sc[EP], be[EP];
-    const bool nr = p.in_norm != nullptr;
+  constexpr int TPS = NT / SUB, PL = TPS / NSLOT;
+  static_assert(TPS % NSLOT == 0 && PL >= 1, "sub-block needs at least one thread per channel slot");
+  constexpr int NITP = (PP + PL - 1) / PL;
+  const int st_sub = tid / TPS, st_pl = (tid % TPS) / NSLOT, st_slot = tid % NSLOT;
+  int sb = b, sy0 = ty0, sx0 = tx0;
+  bool sv = true;
+  if constexpr (TW != 32) {
+    const long long Ls = L0 + st_sub * SUBPIX;
+    sv = Ls < Mtot;
+    sb = sv ? (int)(Ls / HW) : 0;
+    sy0 = ((int)(Ls - (long long)sb * HW)) / TW; sx0 = 0;
+  }
+  const T* __restrict__ xs = x + (size_t)sb * HW * CIN;
+  const bool nr = p.in_norm != nullptr;
+  // cls (S2 only): parity class 2 * py + px of the input pixels to stage -- patch pixel (ry, rx) = input (2 (ty0 - 1 + ry) + py,
+  // 2 (tx0 - 1 + rx) + px); row / column -1 of the class image is the conv's zero padding
+  auto stage_patch = [&](int cls) {
+    float mu[EP], sc[EP], be[EP];          // (S2: re-read per class rather than kept alive through the K loop)
     {
       // (branch-free as well: without a norm the three vectors come from the weight pack and are not used)
       const size_t plane = nr ? (size_t)p.B * CIN : 0;
-      const float* st = nr ? p.in_norm + (size_t)sb * CIN + slot * EP : reinterpret_cast<const float*>(p.w);
+      const float* st = nr ? p.in_norm + (size_t)sb * CIN + st_slot * EP : reinterpret_cast<const float*>(p.w);
 #pragma unroll
       for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
     }
-    V v[NIT];
-    bool ok[NIT];
+    // (S2 restages inside the K loop with the accumulators live: two rounds of loads instead of one, half the staging registers)
+    constexpr int CH = S2 ? (NITP + 1) / 2 : NITP;
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int pix = pl + k * PL;
-      const int py = pix / PW, px = pix - py * PW;
-      const int iy = sy0 + py - HALO, ix = sx0 + px - HALO;
-      ok[k] = sv && pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      // branch-free: an out-of-image pixel reads a clamped (valid) address and is zeroed below -- all loads issue back to back
-      const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-      v[k] = *reinterpret_cast<const V*>(xs + ((size_t)cy * p.W + cx) * CIN + slot * EP);
-    }
+    for (int k0 = 0; k0 < NITP; k0 += CH) {
+      V v[CH];
+      bool ok[CH];
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int pix = pl + k * PL;
-      if (pix < PP) {
-        V o = v[k];
-        if (nr) {
-#pragma unroll
-          for (int e = 0; e < EP; ++e) {
-            float f = fmaf(Elem<T>::to_f(v[k][e]) - mu[e], sc[e], be[e]);
-            if (p.relu_in) f = fmaxf(f, 0.f);
-            o[e] = Elem<T>::from_f(f);
-          }
+      for (int kk = 0; kk < CH; ++kk) {
+        const int k = k0 + kk;
+        const int pix = st_pl + k * PL;
+        const int py = pix / PW, px = pix - py * PW;
+        int iy, ix;
+        if constexpr (S2) {
+          const int a = sy0 - 1 + py, c = sx0 - 1 + px;
+          iy = 2 * a + (cls >> 1); ix = 2 * c + (cls & 1);
+          ok[kk] = k < NITP && pix < PP && a >= 0 && c >= 0;
+        } else {
+          iy = sy0 + py - HALO; ix = sx0 + px - HALO;
+          ok[kk] = sv && pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         }
-        if (!ok[k]) o = V{};
-        *reinterpret_cast<V*>(patch + (sub * PP + pix) * PITCH + slot * 16) = o;
+        // branch-free: an out-of-image pixel reads a clamped (valid) address and is zeroed below -- all loads issue back to back
+        const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        v[kk] = *reinterpret_cast<const V*>(xs + ((size_t)cy * p.W + cx) * CIN + st_slot * EP);
+      }
+#pragma unroll
+      for (int kk = 0; kk < CH; ++kk) {
+        const int k = k0 + kk;
+        const int pix = st_pl + k * PL;
+        if (k < NITP && pix < PP) {
+          V o = v[kk];
+          if (nr) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+              float f = fmaf(Elem<T>::to_f(v[kk][e]) - mu[e], sc[e], be[e]);
+              if (p.relu_in) f = fmaxf(f, 0.f);
+              o[e] = Elem<T>::from_f(f);
+            }
+          }
+          if (!ok[kk]) o = V{};
+          *reinterpret_cast<V*>(patch + (st_sub * PP + pix) * PITCH + st_slot * 16) = o;
+        }
       }
     }
-  }
+  };
+  stage_patch(0);
   if constexpr (!DMA) store_w(0);
   stamp(p, 1);
   __syncthreads();     // (drains the two DMA stages in flight as well)
@@ -281,7 +312,8 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
     V fa[2][2][MR], fb[2][2][NR];
     auto frag_load = [&](int it, V (&a)[2][MR], V (&bq)[2][NR]) {
       const int tap = it / KCH, kch = it - tap * KCH;
-      const int ky = tap / NTX, kx = tap - ky * NTX;     // window offset of the tap inside the patch
+      int ky = tap / NTX, kx = tap - ky * NTX;     // window offset of the tap inside the patch
+      if constexpr (S2) { ky = s2_tap(tap) / 3 == 0 ? 0 : 1; kx = s2_tap(tap) % 3 == 0 ? 0 : 1; }     // (tap 0 of an axis reads class pixel -1)
       const char* lB = wbuf + (GEO == 1 ? it : it % 3) * WBUF_BYTES;
       if constexpr (MF == 16) {       // (the [2][MR] / [2][NR] arrays hold the MR4 / NR4 fragments: same registers)
 #pragma unroll
@@ -301,8 +333,8 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
     };
     if constexpr (GEO != 1) { if (2 < ITERS) dma_w(wstage(2), 2); }
     frag_load(0, fa[0], fb[0]);
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
+    // one K step; `it` is a constant once the loops below are unrolled (ring stage, wait count, tap offset)
+    auto kstep = [&](const int it, const bool prefetch) __attribute__((always_inline)) {
       // s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (simm16: vmcnt[3:0], expcnt[6:4] = 7 (no wait), lgkmcnt[11:8]): the
       // compiler's own wait-count pass sees it and does not add an lgkmcnt(0) in front of this step's MFMAs, which would
       // wait for the reads just issued for the NEXT step (it cannot see through an inline-asm wait).
@@ -318,7 +350,8 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (it + 3 < ITERS) dma_w(wstage(it + 3), it % 3);
       }
-      if (it + 1 < ITERS) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
+      // (S2: no prefetch across a class boundary -- the next class's patch is staged after this step)
+      if (prefetch) frag_load(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
       // pin the order: left alone, the scheduler sinks these reads to just before their first use (shortest live range),
       // i.e. back into the next step, and hoists that step's MFMAs above the barrier -- the read-then-wait form again.
       // bf16: the first MFMA goes out right behind the barrier and the DMA / fragment reads are issued in the shadow of the
@@ -350,7 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
         constexpr int NMFMA = MF == 16 ? MR4 * NR4 : 2 * MR * NR, NREAD = 2 * (MR + NR);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
         if (GEO != 1 && it + 3 < ITERS) __builtin_amdgcn_sched_group_barrier(0x010, NBW, 0);   // the LDS-DMA of stage it+3
-        if (it + 1 < ITERS) {
+        if (prefetch) {
 #pragma unroll
           for (int k = 1; k < NMFMA; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x100, (NREAD + NMFMA - 2) / (NMFMA - 1), 0);   // DS reads (as many groups as it takes)
@@ -367,6 +400,25 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
             for (int j = 0; j < NR; ++j) { acc2[i][j] += acc[i][j]; acc[i][j] = f32x16{}; }
         }
       }
+    };
+    if constexpr (!S2) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) kstep(it, it + 1 < ITERS);
+    } else {
+      // four parity classes of 1, 2, 2 and 4 taps: run a class out of LDS, stage the next one (every wave passed the last step's
+      // barrier with its fragment reads retired: nobody reads the old patch any more), barrier, first fragments, go on
+      constexpr int B1 = KCH, B2 = 3 * KCH, B3 = 5 * KCH;
+#pragma unroll
+      for (int it = 0; it < B1; ++it) kstep(it, it + 1 < B1);
+      stage_patch(1); __syncthreads(); frag_load(B1, fa[B1 & 1], fb[B1 & 1]);
+#pragma unroll
+      for (int it = B1; it < B2; ++it) kstep(it, it + 1 < B2);
+      stage_patch(2); __syncthreads(); frag_load(B2, fa[B2 & 1], fb[B2 & 1]);
+#pragma unroll
+      for (int it = B2; it < B3; ++it) kstep(it, it + 1 < B3);
+      stage_patch(3); __syncthreads(); frag_load(B3, fa[B3 & 1], fb[B3 & 1]);
+#pragma unroll
+      for (int it = B3; it < ITERS; ++it) kstep(it, it + 1 < ITERS);
     }
     __syncthreads();
   } else {
@@ -419,7 +471,7 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   // NHWC pixel index of tile pixel ml in the output (TW == 32 forms)
   auto out_m = [&](int ml) -> size_t {
     if constexpr (TR) return (size_t)b * 4 * HW + (size_t)(2 * (ty0 + ml / TW) + CPY) * (2 * p.W) + 2 * (tx0 + ml % TW) + CPX;
-    else return (size_t)b * HW + (size_t)(ty0 + ml / TW) * p.W + tx0 + ml % TW;
+    else return (size_t)b * OHW + (size_t)(ty0 + ml / TW) * OW + tx0 + ml % TW;
   };
   stamp(p, 3);
   // ---- epilogue of the 16x16x32 form (128 x 128 tile, bf16 NHWC output, no residual): ONE pass through a bf16 image.
@@ -627,12 +679,12 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
         const int ml = ps * EROWS + row, n = n0 + col;
         int ob = b, opix;
         bool mvalid = true;
-        if constexpr (TW == 32) opix = (ty0 + ml / TW) * p.W + tx0 + ml % TW;
+        if constexpr (TW == 32) opix = (ty0 + ml / TW) * OW + tx0 + ml % TW;
         else { mvalid = L0 + ml < Mtot; ob = (int)((L0 + ml) / HW); opix = (int)(L0 + ml - (long long)ob * HW); }
         if (n < p.Cout && mvalid) {
           float v = E[row * EPITCH + col];
           if (p.bias) v += p.bias[n];
-          p.y_nchw[((size_t)ob * p.Cout + n) * HW + opix] = v;
+          p.y_nchw[((size_t)ob * p.Cout + n) * (TW == 32 ? OHW : HW) + opix] = v;
         }
       }
     }
@@ -656,8 +708,16 @@ static bool conv1x1_applicable(const ConvParams& p, int dtype) {
          (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && p.y != nullptr;
 }
 
+// forward of a stride-2 3x3 conv (GEO 6): bf16, tiles of 4 x 32 OUTPUT pixels
+static bool conv_s2_applicable(const ConvParams& p, int dtype) {
+  static const bool on = (PWR_DBG_ENV("PWR_PATCH_S2", 1) != 0);
+  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 2 && p.pad == 1 && p.H % 2 == 0 && p.W % 2 == 0 &&
+         p.Wo % 32 == 0 && p.Ho % 4 == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && p.y != nullptr && !p.y_nchw;
+}
+
 bool conv_patch_applicable(const ConvParams& p, int dtype) {
   if (conv1x1_applicable(p, dtype)) return true;
+  if (conv_s2_applicable(p, dtype)) return true;
   if (!(p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1)) return false;
   if (small_map(p, dtype)) return true;
   return p.W % 32 == 0 && p.H % 4 == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128);
@@ -674,6 +734,7 @@ static bool big64(const ConvParams& p, int dtype) {
 
 int conv_patch_stats_chunks(const ConvParams& p, int dtype) {
   if (conv1x1_applicable(p, dtype)) return (p.H / 4) * (p.W / 32);
+  if (conv_s2_applicable(p, dtype)) return (p.Ho / 4) * (p.Wo / 32);
   if (big64(p, dtype)) return (p.H / 8) * (p.W / 32);
   if (!conv_patch_applicable(p, dtype) || small_map(p, dtype)) return 0;
   return (p.H / 4) * (p.W / 32);
@@ -784,7 +845,23 @@ int launch_conv_tr2(const ConvParams& p0, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <int CIN>
+static int launch_patch_s2(const ConvParams& p, hipStream_t s) {
+  const int bn = pick_bn(p.Cout);
+  dim3 grid(p.B * (p.Ho / 4) * (p.Wo / 32), p.CoutPad / bn), block(256);
+  if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 2, true, 32, 6>), grid, block, 0, s, p);
+  else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 1, true, 32, 6>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 4, 1, 1, 1, true, 32, 6>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
+  if (conv_s2_applicable(p, dtype)) {
+    const_cast<ConvParams&>(p).stamps = g_stamps;
+    if (p.Cin == 128) return launch_patch_s2<128>(p, s);
+    if (p.Cin == 64) return launch_patch_s2<64>(p, s);
+    return launch_patch_s2<32>(p, s);
+  }
   if (conv1x1_applicable(p, dtype)) {
     const_cast<ConvParams&>(p).stamps = g_stamps;
     if (p.Cin == 128) return launch_patch_1x1<128>(p, s);

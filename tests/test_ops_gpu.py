@@ -94,6 +94,12 @@ CONV_CASES = [
     (3, 5, 9, 64, 16, 7, 1),
     (2, 32, 32, 128, 128, 5, 2),
     (2, 20, 20, 64, 128, 7, 2),
+    # stride-2 3x3 on maps whose OUTPUT has W % 32 == 0, H % 4 == 0 (bf16: the LDS-patch kernel's parity-class form, the stem's last conv)
+    (2, 64, 64, 128, 128, 3, 2),
+    (1, 128, 128, 128, 128, 3, 2),
+    (3, 64, 64, 64, 64, 3, 2),
+    (2, 8, 64, 32, 16, 3, 2),
+    (2, 16, 128, 128, 40, 3, 2),
 ]
 
 
