@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   // the 16-byte NHWC vector it stores.  32 LDS instructions and 64 KB of LDS traffic per thread-tile instead of 80 and 128 KB for
   // the two fp32 passes below, two barriers instead of four; same values (fp32 accumulator + bias, one rounding), same statistics
   // up to the order of their fixed-order sums.
-  if constexpr (MF == 16 && TW == 32 && GEO == 0 && MR4 == 4 && NR4 == 4) {
+  if constexpr (MF == 16 && TW == 32 && (GEO == 0 || TR) && MR4 == 4 && NR4 == 4) {
     if (p.y && !p.y_nchw && !p.residual && p.Cout % BN == 0 && p.epi16) {
       typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
       char* E16 = smem;
@@ -830,6 +830,13 @@ template <int GEO>
 static void launch_tr2_class(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
+  // 128 output channels: the 16x16x32 form with the one-pass bf16 epilogue -- a class has 1 - 4 taps only, so the epilogue is a large
+  // part of its launch
+  static const bool mf16 = PWR_DBG_ENV("PWR_TR2_MF16", 1) != 0;
+  if (bn == 128 && mf16 && !p.residual && p.Cout % 128 == 0) {
+    hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, GEO, 16>), grid, block, 0, s, p);
+    return;
+  }
   if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, GEO>), grid, block, 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 2, 2, 2, 1, true, 32, GEO>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, 128, 4, 1, 1, 1, true, 32, GEO>), grid, block, 0, s, p);
