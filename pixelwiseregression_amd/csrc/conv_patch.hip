@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   constexpr int SUBPIX = RH * TW, SUB = BM / SUBPIX;                  // 128-pixel tile = SUB sub-blocks of RH x TW pixels
   constexpr bool TR = GEO >= 2 && GEO <= 5;
   constexpr bool S2 = GEO == 6;
-  static_assert(!S2 || (DMA && TW == 32 && MF == 32), "the stride-2 forward form: bf16 LDS-DMA kernel, 4 x 32 tile");
+  static_assert(!S2 || (DMA && TW == 32), "the stride-2 forward form: bf16 LDS-DMA kernel, 4 x 32 tile");
   constexpr int CPY = TR ? ((GEO - 2) >> 1) : 0, CPX = TR ? ((GEO - 2) & 1) : 0;
   constexpr int HALO = GEO == 0 ? 1 : 0;
   constexpr int NTY = TR ? CPY + 1 : ((GEO == 0 || S2) ? 3 : 1), NTX = TR ? CPX + 1 : ((GEO == 0 || S2) ? 3 : 1);     // taps per axis
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   // the 16-byte NHWC vector it stores.  32 LDS instructions and 64 KB of LDS traffic per thread-tile instead of 80 and 128 KB for
   // the two fp32 passes below, two barriers instead of four; same values (fp32 accumulator + bias, one rounding), same statistics
   // up to the order of their fixed-order sums.
-  if constexpr (MF == 16 && TW == 32 && (GEO == 0 || TR) && MR4 == 4 && NR4 == 4) {
+  if constexpr (MF == 16 && TW == 32 && (GEO == 0 || TR || S2) && MR4 == 4 && NR4 == 4) {
     if (p.y && !p.y_nchw && !p.residual && p.Cout % BN == 0 && p.epi16) {
       typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
       char* E16 = smem;
@@ -856,6 +856,14 @@ template <int CIN>
 static int launch_patch_s2(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   dim3 grid(p.B * (p.Ho / 4) * (p.Wo / 32), p.CoutPad / bn), block(256);
+  if constexpr (CIN == 128) {
+    static const bool mf16 = PWR_DBG_ENV("PWR_S2_MF16", 1) != 0;       // (the 128 -> 128 tile: 16x16x32 MFMAs and the one-pass epilogue, as the heads' convs)
+    if (bn == 128 && mf16) {
+      const_cast<ConvParams&>(p).epi16 = 1;
+      hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 2, true, 32, 6, 16>), grid, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
+  }
   if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 2, true, 32, 6>), grid, block, 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 1, true, 32, 6>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 4, 1, 1, 1, true, 32, 6>), grid, block, 0, s, p);
