@@ -1,22 +1,32 @@
 // bf16 weight gradient of a 3x3 stride-1 conv with BOTH operands brought into LDS by LDS-DMA (global_load_lds): no register staging,
-// no ds_write, no VALU work in the K loop.
+// no per-step address arithmetic; the K loop is waits, one barrier, DMA issues, transposing fragment reads and MFMAs.
 //
 //   dW[co][ci][ky][kx] = sum_{b, y, x} a[b][y + ky - 1][x + kx - 1][ci] * dy[b][y][x][co]          (/root/reference/model.py: every
 //   3x3 Conv2d's weight under autograd; a = the conv's input AFTER its norm + ReLU)
 //
-// For the layers whose operand needs NO norm on the way (in_norm == NULL: the heads' first convs read the hourglass output f as it
-// is, model.py:55 / :104): global_load_lds cannot transform what it moves.  Round 3 also built the other half -- the forward conv
-// storing its normalised operand so that EVERY 3x3 layer could take this path -- and dropped it: the extra write cost the chain what
-// the side streams gained (6.51 vs 6.48 ms per step; profiles/r3_experiments.md section 5, where the isolated numbers are: 67.9 us
-// against 72.0 us for the register-staged conv_wgrad3_kernel incl. the reduce, bit-identical results).
+// global_load_lds cannot transform what it moves, so there are two forms:
+//   NRM = false  the operand needs NO norm on the way (in_norm == NULL: the heads' first convs read the hourglass output f as it is,
+//                model.py:55 / :104).  Bit-identical to the register-staged conv_wgrad3_kernel, 57 against 70 us at the C2 heads shape.
+//   NRM = true   the landed raw input tile of step st + 1 is read back from LDS, normalised + ReLU'd with conv_wgrad3_kernel's
+//                arithmetic (bit-identical again) and stored in place while step st's MFMAs issue.  Pays for 64-wide output tiles
+//                (48 -> 27 us per launch in the step's serial profile), not for 128-wide ones (86 against 76 us: 78 VALU instructions
+//                per wave and step that the MFMAs of the bigger tile do not hide) -- wgrad3d_applicable() picks accordingly.
+//   (Round 3 also built the third way -- the forward conv storing its normalised operand -- and dropped it: the extra write cost the
+//   chain what the side streams gained, profiles/r3_experiments.md section 5.)
 //
-// Workgroup = 256 threads (2 x 2 waves), one kernel row ky, a BM (ci) x BN (co) tile, 3 taps kx from one staged input row segment
-// with halo (as conv_wgrad3_kernel: same accumulation order, same slabs, same reduce -> bit-identical results).  K step = 32 output
-// pixels of one image row.  LDS: a ring of NS stages, each [34 input pixels][BM ch] + [32 pixels][BN ch] as plain rows whose 16-byte
-// slots are XOR-swizzled so that the four pixel rows of a ds_read_b64_tr_b16 group fall on four different 64-byte bank quarters
+// Workgroup = 256 threads (2 x 2 waves), one kernel row ky, a 64 (ci) x BN (co) tile, 3 taps kx from one staged input row segment
+// with halo (as conv_wgrad3_kernel: same accumulation order, same slabs, same reduce).  K step = 32 output pixels of one image row.
+// LDS: a ring of NS = 4 (NRM: 5) stages, each [34 input pixels][64 ch] + [32 pixels][BN ch] as plain rows whose 16-byte slots are
+// XOR-swizzled so that the four pixel rows of a ds_read_b64_tr_b16 group fall on four different 64-byte bank quarters
 // (cdna_hip_programming.md T10).  A DMA piece is 1 KiB = 64 lanes x 16 B, linear in LDS; the swizzle and the halo go into the per-lane
-// SOURCE address.  Out-of-image halo pixels (left / right border) are loaded from a clamped address and zeroed in LDS by the wave
-// that issued the piece, behind its own vmcnt wait; an out-of-image input ROW (ky = 0 / 2 at the top / bottom) skips the step's MFMAs.
+// SOURCE address.  Out-of-image halo pixels (left / right border) are loaded from a clamped address and zeroed in LDS (wave 0 behind
+// its own vmcnt wait; NRM: by the norm pass); an out-of-image input ROW (ky = 0 / 2 at the top / bottom) skips the step's MFMAs.
+//
+// LDS reads and the norm pass's stores are INLINE ASM: the compiler's wait-count pass would put vmcnt(0) -- a wait for every prefetch
+// in flight -- in front of any LDS access it knows about behind an LDS-DMA.  The price: the compiler believes an asm's output is
+// defined when the statement ends, while the data arrives later.  Rules kept here: one definition and one tied wait per asynchronous
+// register, straight-line code between a read and its wait, and pixelwiseregression_amd/codeobj_scan.py::async_lds_hazards checks the
+// linked code object for any instruction that touches such a register too early (profiles/r3_experiments.md section 14).
 #include <type_traits>
 
 #include "conv_common.h"
