@@ -179,6 +179,15 @@ int pwr_make_targets(const float* uvd, const float* label_img, const float* mask
  * (skip connection included), the per-sample norm sums [B][2][C] and (bias_sums != NULL) the per-sample column sums of g_out
  * [B][C], all reduced over the batch by pwr_resblock_param_grads; w*_d: kind-1 packs.
  * ------------------------------------------------------------------------------------------- */
+/* pwr_resblock_fwd_small with the producer of its input fused into the load: xmode 1: x = maxpool2x2(xa), xa [B,2H,2W,C] (model.py:40);
+ * xmode 2: x = nearest-upsample(xh) + xa, xh [B,H/2,W/2,C], xa [B,H,W,C] (model.py:45-47), H >= 4.  x is WRITTEN (the backward pass and the
+ * weight gradients read it), bit-identical to pwr_maxpool_fwd / pwr_upsample_add_fwd followed by pwr_resblock_fwd_small.  xmode 0: as
+ * pwr_resblock_fwd_small. */
+int pwr_resblock_fwd_small_x(int xmode, const void* xa, const void* xh, void* x, void* t1, void* t2, void* out, const void* wa,
+                             const void* wb, const void* wc, const float* bias_a, const float* bias_b, const float* bias_c,
+                             const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                             const float* gamma_c, const float* beta_c, float* state_a, float* state_b, float* state_c, int B,
+                             int H, int W, int C, float eps, int dtype, void* stream);
 int pwr_resblock_small_supported(int H, int W, int C, int norm_mode, int dtype);
 int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* out, const void* wa, const void* wb, const void* wc,
                            const float* bias_a, const float* bias_b, const float* bias_c, const float* gamma_a,

@@ -203,6 +203,10 @@ struct Engine {
   size_t scr_partial = 0, scr_S1 = 0, scr_S2 = 0, scr_slab = 0, scr_slab_bytes = 0;
   size_t need_partial = 0, need_sc = 0;
   size_t scr_cpartial = 0, need_cpartial = 0;   // column statistics written by conv epilogues (pwr_conv_fwd_stats)
+  // a tensor whose producer (max-pool / up-sample + add) was left to the one-launch ResBlock that consumes it (resblock_fused)
+  struct LazyX { bool valid = false; int mode = 0; size_t x_off = 0, a_off = 0, h_off = 0; };
+  LazyX lazy_x;
+  int hg_depth = 0;
   // The ONE producer/consumer pair of such statistics that spans two backward segments (two C ABI calls, with the all-reduce and
   // Python in between): stage 0's input-conv data gradient writes the norm-backward reductions of the stem's last norm, the stem
   // segment's first op reads them.  It has a buffer of its own so that nothing else can ever touch it in between.
@@ -530,8 +534,13 @@ struct Engine {
     if (tr) { r.t1 = tensor(x.H, x.W, Fh, true); r.t2 = tensor(x.H, x.W, Fh, true); }
     Tn out = tensor(x.H, x.W, x.C, tr);
     const ResB rb = r;
+    // the producer of x, if it was left to this launch (hourglass(): the level's max-pool, the inner level's up-sample + add)
+    int xmode = 0;
+    size_t xa_off = 0, xh_off = 0;
+    if (lazy_x.valid && lazy_x.x_off == x.off) { xmode = lazy_x.mode; xa_off = lazy_x.a_off; xh_off = lazy_x.h_off; lazy_x.valid = false; }
     fwd.push_back([=](Ctx& c) {
-      return pwr_resblock_fwd_small(c.arena + x.off, tr ? c.arena + rb.t1.off : nullptr, tr ? c.arena + rb.t2.off : nullptr, c.arena + out.off,
+      return pwr_resblock_fwd_small_x(xmode, xmode ? c.arena + xa_off : nullptr, xmode == 2 ? c.arena + xh_off : nullptr,
+                                    c.arena + x.off, tr ? c.arena + rb.t1.off : nullptr, tr ? c.arena + rb.t2.off : nullptr, c.arena + out.off,
                                     c.packs + rb.ca.pack_f, c.packs + rb.cb.pack_f, c.packs + rb.cc.pack_f, c.params + rb.ca.b,
                                     c.params + rb.cb.b, c.params + rb.cc.b, c.params + rb.na.gamma, c.params + rb.na.beta,
                                     c.params + rb.nb.gamma, c.params + rb.nb.beta, c.params + rb.nc.gamma, c.params + rb.nc.beta,
@@ -584,12 +593,21 @@ struct Engine {
   // (One launch per direction for the whole region below the 32x32 level was built and measured in round 2: bit-identical, not
   // faster -- DESIGN.md section 4 -- and removed in round 3.)
   Tn hourglass(const Tn& x, int lvl) {
+    struct Depth { int& d; Depth(int& r) : d(r) { ++d; } ~Depth() { --d; } } depth_guard(hg_depth);
     const bool tr = training;
     scope = "s" + std::to_string(cur_stage) + ".hg" + std::to_string(lvl);
     const int Bc = B, dt = dtype;
     Tn a = resblock(x);
     Tn h0 = tensor(a.H / 2, a.W / 2, a.C, tr);
-    fwd.push_back([=](Ctx& c) { return pwr_maxpool_fwd(c.arena + a.off, c.arena + h0.off, Bc, a.H, a.W, a.C, dt, c.stream); });
+    // the pooled map's only forward consumer is the next ResBlock: when that is the one-launch kernel of the small maps, it pools on
+    // the fly (and writes h0 for the backward pass) instead of a launch of its own
+    static const bool fuse_in = PWR_DBG_ENV("PWR_RESBLOCK_FUSE_IN", 1) != 0;
+    if (fuse_in && pwr_resblock_small_supported(h0.H, h0.W, h0.C, norm_mode, dtype)) {
+      if (lazy_x.valid) { err = "unconsumed fused producer"; }
+      lazy_x = LazyX{true, 1, h0.off, a.off, 0};
+    } else {
+      fwd.push_back([=](Ctx& c) { return pwr_maxpool_fwd(c.arena + a.off, c.arena + h0.off, Bc, a.H, a.W, a.C, dt, c.stream); });
+    }
     // the ops pushed by resblock(x) must run after everything below: take them out, put them back at the end
     std::vector<Op> after_a;
     std::swap(after_a, bwd_cur);
@@ -606,9 +624,16 @@ struct Engine {
     std::swap(after_h2, bwd_cur);
     if (own) small_jobs = nullptr;
     Tn out = tensor(a.H, a.W, a.C, tr);
-    fwd.push_back([=](Ctx& c) {
-      return pwr_upsample_add_fwd(c.arena + h2.off, c.arena + a.off, c.arena + out.off, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream);
-    });
+    // `out` of an inner level is consumed by the outer level's output ResBlock only: the same fusion (not for the outermost level --
+    // hg_depth == 1 here -- whose result goes to the heads, nor for the big maps)
+    if (fuse_in && hg_depth > 1 && a.H >= 4 && pwr_resblock_small_supported(a.H, a.W, a.C, norm_mode, dtype)) {
+      if (lazy_x.valid) { err = "unconsumed fused producer"; }
+      lazy_x = LazyX{true, 2, out.off, a.off, h2.off};
+    } else {
+      fwd.push_back([=](Ctx& c) {
+        return pwr_upsample_add_fwd(c.arena + h2.off, c.arena + a.off, c.arena + out.off, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream);
+      });
+    }
     if (tr) {
       bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
       bwd_cur.insert(bwd_cur.end(), after_h2.begin(), after_h2.end());        // resblock h1 -> h2

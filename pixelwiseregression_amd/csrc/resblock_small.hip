@@ -27,6 +27,12 @@ struct RbFwdParams {
   const float* ga; const float* bta; const float* gb; const float* btb; const float* gc; const float* btc;
   float* sa; float* sb; float* sc;                            // [4][B][C] norm states (written)
   int B; float eps;
+  // xmode 0: the block input is x.  1: x = maxpool2x2(xa), xa [B,2W,2W,C] (model.py:40, the hourglass level's down_sample).
+  // 2: x = nearest-upsample(xh) + xa, xh [B,W/2,W/2,C], xa [B,W,W,C] (model.py:45-47).  In modes 1 / 2 the kernel computes x on the fly
+  // (the arithmetic of maxpool_fwd_kernel / upsample_add_kernel) and ALSO writes it to `x` (xw), where the backward pass expects it:
+  // one launch of 5 - 7 us less on the chain per level.
+  int xmode = 0;
+  const bf16_t* xa = nullptr; const bf16_t* xh = nullptr; bf16_t* xw = nullptr;
 };
 struct RbBwdParams {
   const bf16_t* gout; const bf16_t* x; const bf16_t* t1; const bf16_t* t2;
@@ -145,20 +151,8 @@ extern "C" int pwr_resblock_small_supported(int H, int W, int C, int norm_mode, 
   return on && dtype == PWR_BF16 && norm_mode == 0 && C == 128 && H == W && (W == 2 || W == 4 || W == 8 || W == 16);
 }
 
-extern "C" int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* out, const void* wa, const void* wb, const void* wc,
-                                      const float* bias_a, const float* bias_b, const float* bias_c, const float* gamma_a,
-                                      const float* beta_a, const float* gamma_b, const float* beta_b, const float* gamma_c,
-                                      const float* beta_c, float* state_a, float* state_b, float* state_c, int B, int H, int W, int C,
-                                      float eps, int dtype, void* stream) {
-  if (!(dtype == PWR_BF16 && C == 128 && H == W && (W == 2 || W == 4 || W == 8 || W == 16))) return (int)hipErrorInvalidValue;
-  RbFwdParams p;
-  p.x = (const bf16_t*)x; p.t1 = (bf16_t*)t1; p.t2 = (bf16_t*)t2; p.out = (bf16_t*)out;
-  p.wa = (const char*)wa; p.wb = (const char*)wb; p.wc = (const char*)wc;
-  p.ba = bias_a; p.bb = bias_b; p.bc = bias_c;
-  p.ga = gamma_a; p.bta = beta_a; p.gb = gamma_b; p.btb = beta_b; p.gc = gamma_c; p.btc = beta_c;
-  p.sa = state_a; p.sb = state_b; p.sc = state_c;
-  p.B = B; p.eps = eps;
-  hipStream_t s = (hipStream_t)stream;
+static int rb_fwd_launch(const RbFwdParams& p, int W, hipStream_t s) {
+  const int B = p.B;
   const int wide = PWR_DBG_ENV("PWR_RESBLOCK_WAVES", 1);
   // 0: four waves everywhere (round 1); 1: eight on the 16x16 / 8x8 maps (measured best); 2: eight everywhere.
   if (W == 16 && wide) hipLaunchKernelGGL((resblock_fwd_small_kernel<4, 8>), dim3(B), dim3(512), 0, s, p);
@@ -170,6 +164,34 @@ extern "C" int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* o
   else if (wide == 2) hipLaunchKernelGGL((resblock_fwd_small_kernel<1, 8>), dim3(B), dim3(512), 0, s, p);
   else hipLaunchKernelGGL((resblock_fwd_small_kernel<1, 4>), dim3(B), dim3(256), 0, s, p);
   return (int)hipGetLastError();
+}
+
+// xmode 0: x is the block input.  1: x (written) = maxpool2x2(xa [B,2H,2W,C]).  2: x (written) = nearest-upsample(xh [B,H/2,W/2,C]) + xa [B,H,W,C].
+extern "C" int pwr_resblock_fwd_small_x(int xmode, const void* xa, const void* xh, void* x, void* t1, void* t2, void* out, const void* wa,
+                                        const void* wb, const void* wc, const float* bias_a, const float* bias_b, const float* bias_c,
+                                        const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                                        const float* gamma_c, const float* beta_c, float* state_a, float* state_b, float* state_c, int B,
+                                        int H, int W, int C, float eps, int dtype, void* stream) {
+  if (!(dtype == PWR_BF16 && C == 128 && H == W && (W == 2 || W == 4 || W == 8 || W == 16))) return (int)hipErrorInvalidValue;
+  if (xmode < 0 || xmode > 2 || (xmode == 1 && !xa) || (xmode == 2 && (!xa || !xh || W < 4)) || !x) return PWR_EINVAL;
+  RbFwdParams p;
+  p.x = (const bf16_t*)x; p.t1 = (bf16_t*)t1; p.t2 = (bf16_t*)t2; p.out = (bf16_t*)out;
+  p.wa = (const char*)wa; p.wb = (const char*)wb; p.wc = (const char*)wc;
+  p.ba = bias_a; p.bb = bias_b; p.bc = bias_c;
+  p.ga = gamma_a; p.bta = beta_a; p.gb = gamma_b; p.btb = beta_b; p.gc = gamma_c; p.btc = beta_c;
+  p.sa = state_a; p.sb = state_b; p.sc = state_c;
+  p.B = B; p.eps = eps;
+  p.xmode = xmode; p.xa = (const bf16_t*)xa; p.xh = (const bf16_t*)xh; p.xw = (bf16_t*)x;
+  return rb_fwd_launch(p, W, (hipStream_t)stream);
+}
+
+extern "C" int pwr_resblock_fwd_small(const void* x, void* t1, void* t2, void* out, const void* wa, const void* wb, const void* wc,
+                                      const float* bias_a, const float* bias_b, const float* bias_c, const float* gamma_a,
+                                      const float* beta_a, const float* gamma_b, const float* beta_b, const float* gamma_c,
+                                      const float* beta_c, float* state_a, float* state_b, float* state_c, int B, int H, int W, int C,
+                                      float eps, int dtype, void* stream) {
+  return pwr_resblock_fwd_small_x(0, nullptr, nullptr, const_cast<void*>(x), t1, t2, out, wa, wb, wc, bias_a, bias_b, bias_c, gamma_a, beta_a,
+                                  gamma_b, beta_b, gamma_c, beta_c, state_a, state_b, state_c, B, H, W, C, eps, dtype, stream);
 }
 
 extern "C" int pwr_resblock_bwd_small(const void* gout, const void* x, const void* t1, const void* t2, void* dx, void* dt1, void* dt2,

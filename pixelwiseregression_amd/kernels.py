@@ -296,6 +296,25 @@ def resblock_fwd_small(x, packs, biases, gammas, betas, eps=1e-5):
     return out, t1, t2, st
 
 
+def resblock_fwd_small_x(xmode, xa, xh, packs, biases, gammas, betas, eps=1e-5):
+    """resblock_fwd_small with its input's producer fused into the load: xmode 1: x = maxpool2x2(xa); xmode 2: x = upsample(xh) + xa.
+    Returns x (as the kernel wrote it), out, t1, t2, states."""
+    l = _lib.lib()
+    B, Ha, Wa, C = xa.shape
+    H, W = (Ha // 2, Wa // 2) if xmode == 1 else (Ha, Wa)
+    dev = xa.device
+    x = torch.full((B, H, W, C), float("nan"), dtype=xa.dtype, device=dev)
+    t1 = torch.empty(B, H, W, C // 2, dtype=xa.dtype, device=dev)
+    t2 = torch.empty_like(t1)
+    out = torch.empty_like(x)
+    st = [torch.empty(4, B, c, dtype=torch.float32, device=dev) for c in (C, C // 2, C // 2)]
+    _lib.check(l.pwr_resblock_fwd_small_x(int(xmode), _p(xa), _p(xh), _p(x), _p(t1), _p(t2), _p(out), _p(packs[0]), _p(packs[1]), _p(packs[2]),
+                                          _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(gammas[0]), _p(betas[0]), _p(gammas[1]),
+                                          _p(betas[1]), _p(gammas[2]), _p(betas[2]), _p(st[0]), _p(st[1]), _p(st[2]), B, H, W, C, eps,
+                                          _dt(xa), _s(xa)), "pwr_resblock_fwd_small_x")
+    return x, out, t1, t2, st
+
+
 def resblock_bwd_small(gout, x, t1, t2, packs_d, states):
     """One-launch ResBlock backward.  packs_d: kind-1 packs of (a, b, c).  Returns dx, dt1, dt2, (sums_a, sums_b, sums_c)."""
     l = _lib.lib()

@@ -633,3 +633,34 @@ def test_conv_epilogue_norm_backward_sums(case, dtype):
         assert_close(dy1.double().cpu(), dy0.double().cpu(), t, "dy (mode %d)" % mode)
         assert_close(dg1.double().cpu(), dg0.double().cpu(), 1e-4, "dgamma")
         assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
+
+
+@pytest.mark.parametrize("B,H,xmode", [(3, 2, 1), (2, 4, 1), (5, 8, 1), (2, 16, 1), (33, 4, 1), (2, 4, 2), (5, 8, 2), (3, 16, 2)])
+def test_resblock_small_fused_input(B, H, xmode):
+    """pwr_resblock_fwd_small_x: the one-launch ResBlock computing its input on the fly -- xmode 1: x = maxpool2x2(a) (model.py:40),
+    xmode 2: x = nearest-upsample(h) + a (model.py:45-47) -- and writing x where the backward pass expects it.  Everything it writes
+    (x, t1, t2, out, the three norm states) is BIT-identical to the stand-alone pool / up-sample kernel followed by
+    pwr_resblock_fwd_small."""
+    from pixelwiseregression_amd import kernels as K
+    C, Fh, dt = 128, 64, torch.bfloat16
+    ws = [rnd(Fh, C, 1, 1, seed=2, scale=C ** -0.5), rnd(Fh, Fh, 3, 3, seed=3, scale=(9 * Fh) ** -0.5), rnd(C, Fh, 1, 1, seed=4, scale=Fh ** -0.5)]
+    bs = [rnd(Fh, seed=5, scale=0.1), rnd(Fh, seed=6, scale=0.1), rnd(C, seed=7, scale=0.1)]
+    gs = [1 + 0.2 * rnd(C, seed=8), 1 + 0.2 * rnd(Fh, seed=9), 1 + 0.2 * rnd(Fh, seed=10)]
+    bes = [0.2 * rnd(C, seed=11), 0.2 * rnd(Fh, seed=12), 0.2 * rnd(Fh, seed=13)]
+    dev = lambda t: t.float().to(DEV)
+    wf = [K.pack_conv(dev(w), 0, K.BF16) for w in ws]
+    bd, gmd, bed = [dev(t) for t in bs], [dev(t) for t in gs], [dev(t) for t in bes]
+    if xmode == 1:
+        a = nhwc(rnd(B, C, 2 * H, 2 * H, seed=21), dt)
+        h = None
+        x_ref = K.maxpool_fwd(a)
+    else:
+        a = nhwc(rnd(B, C, H, H, seed=21), dt)
+        h = nhwc(rnd(B, C, H // 2, H // 2, seed=22), dt)
+        x_ref = K.upsample_add(h, a)
+    out0, t10, t20, st0 = K.resblock_fwd_small(x_ref, wf, bd, gmd, bed)
+    x1, out1, t11, t21, st1 = K.resblock_fwd_small_x(xmode, a, h, wf, bd, gmd, bed)
+    assert torch.equal(x1, x_ref)
+    assert torch.equal(out1, out0) and torch.equal(t11, t10) and torch.equal(t21, t20)
+    for s0, s1 in zip(st0, st1):
+        assert torch.equal(s0, s1)
