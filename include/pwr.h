@@ -102,6 +102,13 @@ int pwr_conv_fwd_stats(const void* x, const void* wpack, const float* bias, cons
                        float* st_partial, const void* nb_y, const float* nb_state, float* nb_partial, int nb_relu, int dtype,
                        void* stream);
 
+/* Two pwr_conv_fwd_stats calls (forward statistics form: st_partial, stride 1, no residual) of ONE shape on different tensors / weights
+ * in ONE launch -- the two regression heads of a stage (model.py:54-65 / :103-114).  PWR_EUNSUPPORTED: no pair kernel for the shape, launch
+ * them one after the other.  Results are those of the two single launches, bit for bit. */
+int pwr_conv_fwd_stats_pair(const void* xa, const void* wa, const float* bias_a, const float* in_norm_a, void* ya, float* st_partial_a,
+                            const void* xb, const void* wb, const float* bias_b, const float* in_norm_b, void* yb, float* st_partial_b,
+                            int relu_in, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream);
+
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 /* dw[cout_real][cin_real][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
  * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout]; Cin / Cout may include zero-padded channels beyond cin_real /

@@ -196,6 +196,8 @@ static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 :
 bool conv_patch_applicable(const ConvParams& p, int dtype);
 int conv_patch_stats_chunks(const ConvParams& p, int dtype);   // slab rows per sample of the column statistics, 0 = unsupported
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s);
+bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype);   // two convs of one shape in one launch
+int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s);
 bool conv_tr2_applicable(const ConvParams& p, int dtype);   // stride-2 data gradient as four parity-class patch convs
 int launch_conv_tr2(const ConvParams& p, hipStream_t s);
 void set_debug_stamps(long long* ptr);

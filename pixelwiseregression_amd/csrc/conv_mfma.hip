@@ -1169,6 +1169,22 @@ extern "C" int pwr_conv_fwd_stats(const void* x, const void* wpack, const float*
   return dtype == PWR_BF16 ? pwr::launch_conv<bf16_t>(p, (hipStream_t)stream) : pwr::launch_conv<float>(p, (hipStream_t)stream);
 }
 
+// Two pwr_conv_fwd_stats launches (forward statistics form, stride 1, no residual) of ONE shape as one launch; PWR_EUNSUPPORTED when the
+// shape has no pair kernel (the caller then launches them one after the other)
+extern "C" int pwr_conv_fwd_stats_pair(const void* xa, const void* wa, const float* bias_a, const float* in_norm_a, void* ya, float* st_partial_a,
+                                       const void* xb, const void* wb, const float* bias_b, const float* in_norm_b, void* yb, float* st_partial_b,
+                                       int relu_in, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream) {
+  pwr::ConvParams a, b;
+  int rc = conv_params_fill(a, xa, wa, bias_a, in_norm_a, relu_in, nullptr, ya, nullptr, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  rc = conv_params_fill(b, xb, wb, bias_b, in_norm_b, relu_in, nullptr, yb, nullptr, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  if (!st_partial_a || !st_partial_b || !ya || !yb) return PWR_EINVAL;
+  if (dtype != PWR_BF16 || !pwr::conv_patch_pair_applicable(a, b, dtype)) return PWR_EUNSUPPORTED;
+  a.st_partial = st_partial_a; b.st_partial = st_partial_b;
+  return pwr::launch_conv_patch_pair(a, b, (hipStream_t)stream);
+}
+
 extern "C" size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits) {
   const int cinpad = (cin + 127) / 128 * 128;
   return (size_t)splits * ksize * ksize * cinpad * pwr_conv_out_pad(cout) * sizeof(float);

@@ -56,7 +56,7 @@ template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW 
 #ifndef PWR_OCC_HINT
 #define PWR_OCC_HINT 1
 #endif
-__global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void conv3x3_patch_kernel(ConvParams p) {
+__device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
   typedef typename Vec16<T>::type V;
   static_assert(MF == 32 || (MF == 16 && sizeof(T) == 2 && DMA), "the 16x16x32 form exists for the bf16 LDS-DMA kernel");
   constexpr int MR4 = MR * 2, NR4 = NR * 2;     // 16-row / 16-column blocks of the wave tile (MF == 16)
@@ -694,6 +694,20 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   stamp(p, 4);
 }
 
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32>
+__global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void conv3x3_patch_kernel(ConvParams p) {
+  conv3x3_patch_body<T, CIN, WM, WN, MR, NR, DMA, TW, GEO, MF>(p);
+}
+
+// Two convs of the same shape and kernel variant in ONE launch (blockIdx.z picks the job): the two regression heads of a stage run the
+// same three 128 -> 128 convs on different tensors (model.py:54-65 / :103-114), and a launch boundary between two full-chip launches of
+// this kernel costs 8 - 9 us (tools/launch_bubble.py: 2 x B = 32 takes 85.5 us, 1 x B = 64 takes 76.4 us).
+struct ConvPair { ConvParams a, b; };
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32>
+__global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void conv3x3_patch_pair_kernel(ConvPair g) {
+  conv3x3_patch_body<T, CIN, WM, WN, MR, NR, DMA, TW, GEO, MF>(blockIdx.z ? g.b : g.a);
+}
+
 // small square maps of the inner hourglass levels (64 -> 64 channels): whole images per tile
 static bool small_map(const ConvParams& p, int dtype) {
   static const bool on = (PWR_DBG_ENV("PWR_PATCH_SMALL", 1) != 0);
@@ -867,6 +881,25 @@ static int launch_patch_s2(const ConvParams& p, hipStream_t s) {
   if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 2, true, 32, 6>), grid, block, 0, s, p);
   else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 2, 2, 2, 1, true, 32, 6>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((conv3x3_patch_kernel<bf16_t, CIN, 4, 1, 1, 1, true, 32, 6>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+// The pair form exists for the kernel variant of the heads' convs: bf16, 3x3 stride 1, 128 -> 128 channels, 4 x 32-pixel tiles,
+// 16x16x32 MFMAs with the one-pass epilogue; both jobs of one geometry.
+bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype) {
+  static const bool on = (PWR_DBG_ENV("PWR_PATCH_PAIR", 1) != 0);
+  auto ok = [&](const ConvParams& p) {
+    return dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 && p.W % 32 == 0 &&
+           p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && !small_map(p, dtype);
+  };
+  return on && ok(a) && ok(b) && a.B == b.B && a.H == b.H && a.W == b.W && PWR_DBG_ENV("PWR_PATCH_MF16", 1) != 0 && PWR_DBG_ENV("PWR_PATCH_BIG", 0) == 0;
+}
+int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s) {
+  ConvPair g{a, b};
+  g.a.epi16 = g.b.epi16 = 1;
+  g.a.stamps = g.b.stamps = nullptr;
+  dim3 grid(a.B * (a.H / 4) * (a.W / 32), a.CoutPad / 128, 2), block(256);
+  hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, g);
   return (int)hipGetLastError();
 }
 

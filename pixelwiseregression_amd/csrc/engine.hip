@@ -407,6 +407,52 @@ struct Engine {
     if (out_norm) norm_fwd(y, *out_norm);
     return y;
   }
+  // Two convs of the same shape on different tensors / weights, each followed by its norm (the two regression heads of a stage): one
+  // launch for both when the shape allows (pwr_conv_fwd_stats_pair), then the two finalize launches.  Forward only: the backward ops
+  // are registered per head as before.
+  void conv_fwd_pair(const Tn& xa, const NormL* nra, const ConvL& ca, const NormL& ona, Tn& ya,
+                     const Tn& xb, const NormL* nrb, const ConvL& cb, const NormL& onb, Tn& yb, bool grad) {
+    static const bool on = PWR_DBG_ENV("PWR_HEAD_PAIR", 1) != 0;
+    const int chunks = (stats_mask() & 1) ? pwr_conv_stats_chunks(xa.H, xa.W, ca.Cin, ca.Cout, ca.k, ca.stride, 0, dtype) : 0;
+    const bool same = xa.H == xb.H && xa.W == xb.W && ca.Cin == cb.Cin && ca.Cout == cb.Cout && ca.k == cb.k && ca.stride == 1 && cb.stride == 1;
+    if (!on || chunks <= 0 || !same || norm_mode != 0) {
+      ya = conv_fwd(xa, nra, ca, nullptr, grad, &ona);
+      yb = conv_fwd(xb, nrb, cb, nullptr, grad, &onb);
+      return;
+    }
+    ya = tensor(xa.H, xa.W, ca.Cout, grad);
+    yb = tensor(xb.H, xb.W, cb.Cout, grad);
+    const size_t half = ((size_t)B * chunks * 3 * ca.Cout * 4 + 255) / 256 * 256;
+    if (2 * half > need_cpartial) need_cpartial = 2 * half;
+    norm_fwd_sizes(ya); norm_fwd_sizes(yb);
+    const int Bc = B, dt = dtype, HWo = xa.H * xa.W;
+    const bool ha = nra != nullptr, hb = nrb != nullptr;
+    const NormL na = ha ? *nra : NormL{}, nb = hb ? *nrb : NormL{};
+    const Tn ta = ya, tb = yb;
+    Engine* E = this;
+    fwd.push_back([=](Ctx& c) {
+      float* pa = (float*)(c.arena + E->scr_cpartial);
+      float* pb = (float*)(c.arena + E->scr_cpartial + half);
+      int rc = pwr_conv_fwd_stats_pair(c.arena + xa.off, c.packs + ca.pack_f, c.params + ca.b, ha ? (float*)(c.arena + na.state) : nullptr,
+                                       c.arena + ta.off, pa, c.arena + xb.off, c.packs + cb.pack_f, c.params + cb.b,
+                                       hb ? (float*)(c.arena + nb.state) : nullptr, c.arena + tb.off, pb, 1, Bc, xa.H, xa.W, ca.Cin, ca.Cout,
+                                       ca.k, dt, c.stream);
+      if (rc == PWR_EUNSUPPORTED) {
+        rc = pwr_conv_fwd_stats(c.arena + xa.off, c.packs + ca.pack_f, c.params + ca.b, ha ? (float*)(c.arena + na.state) : nullptr, 1, nullptr,
+                                c.arena + ta.off, Bc, xa.H, xa.W, ca.Cin, ca.Cout, ca.k, 1, 0, pa, nullptr, nullptr, nullptr, 1, dt, c.stream);
+        if (rc) return rc;
+        rc = pwr_conv_fwd_stats(c.arena + xb.off, c.packs + cb.pack_f, c.params + cb.b, hb ? (float*)(c.arena + nb.state) : nullptr, 1, nullptr,
+                                c.arena + tb.off, Bc, xb.H, xb.W, cb.Cin, cb.Cout, cb.k, 1, 0, pb, nullptr, nullptr, nullptr, 1, dt, c.stream);
+      }
+      if (rc) return rc;
+      rc = pwr_norm_finalize_partial(pa, chunks, c.params + ona.gamma, c.params + ona.beta, nullptr, nullptr, (float*)(c.arena + ona.state), Bc,
+                                     HWo, ca.Cout, 0, 1e-5f, 0.1f, c.stream);
+      if (rc) return rc;
+      return pwr_norm_finalize_partial(pb, chunks, c.params + onb.gamma, c.params + onb.beta, nullptr, nullptr, (float*)(c.arena + onb.state), Bc,
+                                       HWo, cb.Cout, 0, 1e-5f, 0.1f, c.stream);
+    });
+  }
+
   // backward of conv_fwd given y.goff complete.  Writes dW (and db if bias_grad), then dgrad into x.goff
   // (accumulating onto x.goff when accumulate_dx).  The caller applies norm_bwd afterwards when nr != null.
   // Returns the slab rows per sample of the norm-backward reductions that the data-gradient launch wrote for `nr`
@@ -659,28 +705,36 @@ struct Engine {
   }
   // ---- one regression head (model.py:54-65 / 103-114) ending in an NCHW fp32 map
   struct Head { ConvL c0, c1, c2, c3; NormL n0, n1, n2; Tn h1, h2, h3; size_t gT; };
-  // out_sel: 0 -> logits z in the arena (z_off), 1 -> external depthmaps output
-  Head head_fwd(const Tn& f, size_t z_off, int out_sel, int stage_idx) {
+  // Both heads of a stage (plane: logits z in the arena; depth: the external depth-map output), parameters in named_parameters order
+  // (plane head first), the three 128 -> 128 convs of the same depth launched pairwise (conv_fwd_pair)
+  void heads_fwd(const Tn& f, size_t z_off, int stage_idx, Head& hp, Head& hd) {
     const bool tr = training;
     const int Bc = B, dt = dtype, Jc = J;
-    Head h;
-    scope = "s" + std::to_string(stage_idx) + (out_sel == 0 ? ".plane" : ".depth");
-    h.c0 = conv_params(F, F, ks, 1, true, true); h.n0 = norm_params(F);
-    h.c1 = conv_params(F, F, ks, 1, true, true); h.n1 = norm_params(F);
-    h.c2 = conv_params(F, F, ks, 1, true, true); h.n2 = norm_params(F);
-    h.c3 = conv_params(F, J, ks, 1, true, true);
-    h.h1 = conv_fwd(f, nullptr, h.c0, nullptr, tr, &h.n0);
-    h.h2 = conv_fwd(h.h1, &h.n0, h.c1, nullptr, tr, &h.n1);
-    h.h3 = conv_fwd(h.h2, &h.n1, h.c2, nullptr, tr, &h.n2);
-    const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3;
-    fwd.push_back([=](Ctx& c) {
-      float* dst = out_sel == 0 ? (float*)(c.arena + z_off) : c.out_D[stage_idx];
-      return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.state),
-                          1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
-    });
+    Head* hs[2] = {&hp, &hd};
+    for (int k = 0; k < 2; ++k) {
+      Head& h = *hs[k];
+      scope = "s" + std::to_string(stage_idx) + (k == 0 ? ".plane" : ".depth");
+      h.c0 = conv_params(F, F, ks, 1, true, true); h.n0 = norm_params(F);
+      h.c1 = conv_params(F, F, ks, 1, true, true); h.n1 = norm_params(F);
+      h.c2 = conv_params(F, F, ks, 1, true, true); h.n2 = norm_params(F);
+      h.c3 = conv_params(F, J, ks, 1, true, true);
+    }
+    scope = "s" + std::to_string(stage_idx) + ".heads";
+    conv_fwd_pair(f, nullptr, hp.c0, hp.n0, hp.h1, f, nullptr, hd.c0, hd.n0, hd.h1, tr);
+    conv_fwd_pair(hp.h1, &hp.n0, hp.c1, hp.n1, hp.h2, hd.h1, &hd.n0, hd.c1, hd.n1, hd.h2, tr);
+    conv_fwd_pair(hp.h2, &hp.n1, hp.c2, hp.n2, hp.h3, hd.h2, &hd.n1, hd.c2, hd.n2, hd.h3, tr);
+    for (int k = 0; k < 2; ++k) {
+      const Head& h = *hs[k];
+      const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3;
+      const int out_sel = k;
+      fwd.push_back([=](Ctx& c) {
+        float* dst = out_sel == 0 ? (float*)(c.arena + z_off) : c.out_D[stage_idx];
+        return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.state),
+                            1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
+      });
+    }
     const int Jp = pad_narrow(J);
-    h.gT = tr ? alloc((size_t)B * P * P * Jp * esz, "gT") : 0;
-    return h;
+    for (int k = 0; k < 2; ++k) hs[k]->gT = tr ? alloc((size_t)B * P * P * Jp * esz, "gT") : 0;
   }
   // g_nchw_off: arena offset of the fp32 [B,J,N] gradient of the head's output map
   void head_bwd(const Tn& f, const Head& h, size_t g_nchw_off, bool accumulate_df) {
@@ -795,8 +849,8 @@ struct Engine {
       R.w_off = method == 0 ? take_param(J) : -1;
       scope = "s" + std::to_string(s) + ".dec";
       R.z = alloc((size_t)B * J * N * 4, "z");
-      Head hp = head_fwd(f, R.z, 0, s);
-      Head hd = head_fwd(f, 0, 1, s);
+      Head hp, hd;
+      heads_fwd(f, R.z, s, hp, hd);
       const size_t zoff = R.z;
       const long long woff = R.w_off;
       fwd.push_back([=](Ctx& c) {

@@ -355,6 +355,20 @@ def conv_fwd_stats(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_i
     return y, partial, chunks
 
 
+def conv_fwd_stats_pair(xa, wa, xb, wb, cout, ksize, bias_a=None, bias_b=None, norm_a=None, norm_b=None, relu_in=True):
+    """Two conv_fwd_stats (forward statistics form) of one shape in one launch.  Returns (ya, partial_a), (yb, partial_b), chunks."""
+    l = _lib.lib()
+    B, H, W, Cin = xa.shape
+    chunks = l.pwr_conv_stats_chunks(H, W, Cin, cout, ksize, 1, 0, _dt(xa))
+    if chunks <= 0:
+        raise _lib.PwrError("conv shape does not support epilogue statistics")
+    ya, yb = (torch.empty(B, H, W, cout, dtype=xa.dtype, device=xa.device) for _ in range(2))
+    pa, pb = (torch.full((B * chunks, 3, cout), float("nan"), dtype=torch.float32, device=xa.device) for _ in range(2))
+    _lib.check(l.pwr_conv_fwd_stats_pair(_p(xa), _p(wa), _p(bias_a), _p(norm_a), _p(ya), _p(pa), _p(xb), _p(wb), _p(bias_b), _p(norm_b), _p(yb),
+                                         _p(pb), int(relu_in), B, H, W, Cin, cout, ksize, _dt(xa), _s(xa)), "pwr_conv_fwd_stats_pair")
+    return (ya, pa), (yb, pb), chunks
+
+
 def norm_finalize_partial(partial, chunks, gamma, beta, B, HW, mode=0, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     l = _lib.lib()
     C = gamma.numel()

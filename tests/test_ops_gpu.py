@@ -664,3 +664,23 @@ def test_resblock_small_fused_input(B, H, xmode):
     assert torch.equal(out1, out0) and torch.equal(t11, t10) and torch.equal(t21, t20)
     for s0, s1 in zip(st0, st1):
         assert torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 8, 32), (33, 64, 64)])
+def test_conv_pair_launch(B, H, W):
+    """pwr_conv_fwd_stats_pair: the two heads' convs of one depth (3x3 128 -> 128, different inputs, weights, biases and norm states) in
+    ONE launch -- outputs and statistics rows bit-identical to the two single launches; one job with a norm prologue, one without
+    (the heads' first convs read the raw hourglass output)."""
+    from pixelwiseregression_amd import kernels as K
+    C = 128
+    xa, xb = nhwc(rnd(B, C, H, W, seed=31), torch.bfloat16), nhwc(rnd(B, C, H, W, seed=32), torch.bfloat16)
+    wa = K.pack_conv(rnd(C, C, 3, 3, seed=33, scale=(9 * C) ** -0.5).float().to(DEV), 0, K.BF16)
+    wb = K.pack_conv(rnd(C, C, 3, 3, seed=34, scale=(9 * C) ** -0.5).float().to(DEV), 0, K.BF16)
+    ba, bb = rnd(C, seed=35, scale=0.1).float().to(DEV), rnd(C, seed=36, scale=0.1).float().to(DEV)
+    sta = K.norm_stats(xa, (1 + 0.2 * rnd(C, seed=37)).float().to(DEV), (0.2 * rnd(C, seed=38)).float().to(DEV))
+    for na, nb in ((sta, None), (None, None)):
+        ya, pa, _ = K.conv_fwd_stats(xa, wa, C, 3, 1, bias=ba, norm=na)
+        yb, pb, _ = K.conv_fwd_stats(xb, wb, C, 3, 1, bias=bb, norm=nb)
+        (ya2, pa2), (yb2, pb2), _ = K.conv_fwd_stats_pair(xa, wa, xb, wb, C, 3, bias_a=ba, bias_b=bb, norm_a=na, norm_b=nb)
+        assert torch.equal(ya, ya2) and torch.equal(yb, yb2)
+        assert torch.equal(pa, pa2) and torch.equal(pb, pb2)
