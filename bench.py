@@ -249,7 +249,14 @@ def self_launch(n):
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
-    env.setdefault("OMP_NUM_THREADS", "4")
+    # Host side of a rank: ONE Python thread issues the whole step (6 ms of ctypes calls per 6 ms step: `rccl.host_issue_ms_per_step`), plus
+    # RCCL's proxy thread -- two busy cores per rank, no OpenMP work at all.  Two OpenMP threads leave torch's few CPU ops room without
+    # oversubscribing a 16-CPU box at 8 ranks.
+    env.setdefault("OMP_NUM_THREADS", "2")
+    # RCCL channel budget: the three all-reduces of a step move 5.8 + 5.8 + 0.9 MiB (latency-bound on xGMI); every channel is a persistent
+    # workgroup that takes a CU from the full-chip convs it runs beside.  4 channels are plenty for 6 MiB and cost at most 4 of 256 CUs.
+    env.setdefault("NCCL_MAX_NCHANNELS", "4")
+    env.setdefault("NCCL_MIN_NCHANNELS", "1")
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for l_ in proc.stdout:
@@ -361,6 +368,10 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
+        # (also when the driver's torch.distributed.run started this rank: the defaults of self_launch(), read by RCCL at communicator creation)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
@@ -404,6 +415,14 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # host time to ISSUE one step (the caller's thread returns before the GPU has finished): what one rank's Python thread needs per step
+    host_issue_ms = None
+    if args.warmup > 0:
+        th = time.perf_counter()
+        for _ in range(min(10, args.warmup)):
+            step()
+        host_issue_ms = (time.perf_counter() - th) / min(10, args.warmup) * 1e3
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -445,6 +464,13 @@ def main():
             "infer_frames_per_s": world * B_PER_GPU / dt_inf,
             "final_loss": final_loss,
         }
+        if use_dist:
+            # what went over RCCL: the ranks of the process group and the bytes of each per-segment all-reduce (flat fp32 gradient slices in
+            # backward-completion order: last stage, ..., stage 0, stem; ddp.py), the host threads each rank was given
+            out["rccl"] = {"ranks": torch.distributed.get_world_size(), "backend": args.dist_backend,
+                           "allreduce_bytes_per_segment": [4 * (e - b) for (b, e) in model.segment_ranges()],
+                           "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                           "host_issue_ms_per_step": host_issue_ms}
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         step_flops = 3 * 20.88e9 * B_PER_GPU            # 20.88 GFLOP/frame forward at C2, x3 for training
         out["step_mfma_frac"] = step_flops / (dt / args.steps) / (peak * 1e12)

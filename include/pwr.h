@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 3   /* 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h (debug build only) */
+#define PWR_ABI_VERSION 4   /* 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -109,6 +109,13 @@ int pwr_conv_fwd_stats_pair(const void* xa, const void* wa, const float* bias_a,
                             const void* xb, const void* wb, const float* bias_b, const float* in_norm_b, void* yb, float* st_partial_b,
                             int relu_in, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream);
 
+/* Two data gradients of stride-1 3x3 convs of ONE shape in ONE launch -- pwr_conv_fwd_stats in its norm-backward form (x = dy, kind-1 pack,
+ * no bias, no prologue, nb_partial) for both regression heads of a stage, which walk their convs backwards in lock-step
+ * (autograd of model.py:54-65 / :103-114).  PWR_EUNSUPPORTED: no pair kernel for the shape.  Results are those of the two single launches, bit for bit. */
+int pwr_conv_dgrad_stats_pair(const void* dya, const void* wa, void* dxa, const void* nb_y_a, const float* nb_state_a, float* nb_partial_a,
+                              const void* dyb, const void* wb, void* dxb, const void* nb_y_b, const float* nb_state_b, float* nb_partial_b,
+                              int nb_relu, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream);
+
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 /* dw[cout_real][cin_real][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).
  * x: forward input [B,H,W,Cin]; dy: [B,Ho,Wo,Cout]; Cin / Cout may include zero-padded channels beyond cin_real /
@@ -117,6 +124,14 @@ size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 int pwr_conv_wgrad(const void* x, const void* dy, const float* in_norm, int relu_in, float* slab,
                    float* dw, int accumulate, int B, int H, int W, int Cin, int cin_real, int Cout, int cout_real, int ksize,
                    int stride, int splits, int dtype, void* stream);
+
+/* Two pwr_conv_wgrad calls of ONE geometry (3x3, stride 1, bf16, Cin and Cout multiples of 128, no padded channels) in ONE kernel launch
+ * + ONE reduce launch: the weight gradients of the two regression heads' convs of the same depth (model.py:55-63 / :104-112).
+ * slab: 2 x pwr_conv_wgrad_slab_bytes(Cout, Cin, 3, splits).  in_norm_a / in_norm_b: both NULL or both set.  PWR_EUNSUPPORTED: shape
+ * without a pair kernel.  Bit-identical to two pwr_conv_wgrad calls with the same `splits`. */
+int pwr_conv_wgrad_pair(const void* xa, const void* dya, const float* in_norm_a, float* dwa, const void* xb, const void* dyb,
+                        const float* in_norm_b, float* dwb, int relu_in, float* slab, int B, int H, int W, int Cin, int Cout, int splits,
+                        int dtype, void* stream);
 
 /* Stem conv with Cin = 1 (model.py:165).  img: fp32 [B,S,S]; w: OIHW fp32 [C0,1,k,k]; y: [B,S,S,C0]. */
 int pwr_stem_conv_fwd(const float* img, const float* w, const float* bias, void* y, int B, int S, int C0, int ksize,

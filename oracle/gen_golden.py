@@ -455,14 +455,59 @@ def gen_checkpoint(ref_model, ref_utils):
     print("checkpoint written by the reference:", os.path.getsize(path), "bytes")
 
 
+def gen_trained(ref_model):
+    """BASELINE C2's architecture with TRAINED weights (tools/make_trained_weights.py on the GPU box: 600 AdamW steps of the reference's
+    loop on rendered synthetic hands -> gpurun_out/trained_c2_weights.npz) evaluated by the REFERENCE in float64 and in fp32 on four
+    held-out frames: the fixture that pins the bf16 (throughput) engine to the reference on a well-conditioned network
+    (tests/test_trained_fixture_gpu.py); the CPU oracle is checked against it in tests/test_oracle_golden.py.  Forward + the gradient of
+    the train.py:197-205 loss (alpha = 1) in float64."""
+    src = os.path.join(ROOT, "gpurun_out", "trained_c2_weights.npz")
+    if not os.path.exists(src):       # regenerate from the weights and inputs the committed fixture already holds
+        src = os.path.join(OUT, "trained_c2.npz")
+    w = dict(np.load(src))
+    cfg = dict(joints=14, stage=2, label_size=64, features=128, level=4, kernel_size=3, norm_method="instance", heatmap_method="softmax")
+    sd = {k[3:]: torch.from_numpy(w[k]) for k in w if k.startswith("sd_")}
+    batch = {k[3:]: torch.from_numpy(w[k]) for k in w if k.startswith("in_")}
+    batch["heatmaps"] = torch.zeros(1); batch["depthmaps"] = torch.zeros(1)      # (alpha = 1: the dense terms have weight zero)
+    with torch.no_grad():
+        out32, _, _ = _run_model(ref_model, cfg, sd, batch, None, train=False)
+    out64, g64, _ = _run_model(ref_model, cfg, sd, {k: v for k, v in batch.items()}, 1.0, train=True, double=True)
+    rec = {"cfg_" + k: np.array(v) for k, v in cfg.items()}
+    rec.update({"sd_" + k: v.numpy() for k, v in sd.items()})
+    for k in ("img", "label_img", "mask", "uvd", "box_size", "cube_size", "com"):
+        rec["in_" + k] = batch[k].numpy()
+    for s in range(2):
+        rec["f64_s%d_uvd" % s] = out64["s%d_uvd" % s]
+        # maps of the first two frames, stored in fp32 (rounded once from the float64 evaluation); per-map summaries of all four
+        rec["f64_s%d_p" % s] = out64["s%d_p" % s][:2].astype(np.float32)
+        rec["f64_s%d_D" % s] = out64["s%d_D" % s][:2].astype(np.float32)
+        rec["f64_s%d_p_max" % s] = out64["s%d_p" % s].max(axis=(2, 3))
+        rec["f64_s%d_p_argmax" % s] = out64["s%d_p" % s].reshape(4, 14, -1).argmax(axis=2)
+        rec["f32_s%d_uvd" % s] = out32["s%d_uvd" % s]
+    rec["f64_loss"] = out64["loss"]
+    # the float64 gradient of the train.py:197-205 loss (alpha = 1, training mode), flat in named_parameters order, rounded to bf16 and
+    # stored as the upper 16 bits (3 significant digits: enough to bound a bf16 engine's gradient, half the bytes), + per-tensor norms in float64
+    gflat = np.concatenate([g64[k].ravel() for k in g64]).astype(np.float32)
+    u = gflat.view(np.uint32).astype(np.uint64)
+    rec["f64_grad_bf16bits"] = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    rec["f64_grad_norms"] = np.array([float(np.linalg.norm(g64[k].ravel())) for k in g64])
+    rec["grad_keys"] = np.array(list(g64.keys()))
+    rec["grad_numel"] = np.array([g64[k].size for k in g64])
+    rec["mm_trained"] = w["mm_trained"]
+    rec["train_steps"] = w["train_steps"]
+    np.savez_compressed(os.path.join(OUT, "trained_c2.npz"), **rec)
+    e = max(float(np.abs(out32["s%d_uvd" % s] - out64["s%d_uvd" % s]).max()) for s in range(2))
+    print("trained fixture:", os.path.getsize(os.path.join(OUT, "trained_c2.npz")), "bytes; reference fp32 vs float64 uvd", e)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1:     # (add named fixtures without regenerating the others): targets | wellcond | checkpoint | preprocess | tiny
+    if len(sys.argv) > 1:     # (add named fixtures without regenerating the others): targets | wellcond | checkpoint | preprocess | tiny | trained
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(8)
         ref_model, ref_utils, ref_datasets = import_reference()
         for what in sys.argv[1:]:
             {"targets": lambda: gen_targets(ref_utils), "wellcond": lambda: gen_wellcond(ref_model), "tiny": lambda: gen_tiny(ref_model),
-             "checkpoint": lambda: gen_checkpoint(ref_model, ref_utils),
+             "checkpoint": lambda: gen_checkpoint(ref_model, ref_utils), "trained": lambda: gen_trained(ref_model),
              "preprocess": lambda: gen_preprocess(ref_utils, ref_datasets)}[what]()
         sys.exit(0)
     os.makedirs(OUT, exist_ok=True)

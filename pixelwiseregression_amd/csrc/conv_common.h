@@ -206,4 +206,9 @@ void set_debug_stamps(long long* ptr);
 bool wgrad3d_applicable(const WgradParams& p);
 int launch_wgrad3d(const WgradParams& p, hipStream_t s);
 
+// conv_wgrad_ws.hip: 3x3 weight gradient of whole 128-channel tiles, wave-specialised (4 MFMA waves + 4 loader waves per workgroup);
+// one job or two jobs of one geometry per launch
+bool wgrad3w_applicable(const WgradParams& p);
+int launch_wgrad3w(const WgradParams& a, const WgradParams* b, hipStream_t s);
+
 }  // namespace pwr

@@ -1035,6 +1035,7 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   const int taps = p.ksize * p.ksize;
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
   if constexpr (sizeof(T) == 2) {
+    if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // whole 128-channel tiles: the wave-specialised kernel
     if (wgrad3d_applicable(p)) return launch_wgrad3d(p, s);                  // operands by LDS-DMA (no norm to apply on the way)
     if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
       dim3 g3(24 * ((p.S + 7) / 8), grid.y, 1);
@@ -1185,6 +1186,24 @@ extern "C" int pwr_conv_fwd_stats_pair(const void* xa, const void* wa, const flo
   return pwr::launch_conv_patch_pair(a, b, (hipStream_t)stream);
 }
 
+// Two data gradients of stride-1 3x3 convs of ONE shape (pwr_conv_fwd_stats in its norm-backward form: x = dy, kind-1 pack, no bias, no
+// prologue; nb_partial = the reductions of the norm backward of the tensor the gradient belongs to) as one launch: the two regression
+// heads walk their three 128 -> 128 convs backwards in lock-step (model.py:54-65 / :103-114)
+extern "C" int pwr_conv_dgrad_stats_pair(const void* dya, const void* wa, void* dxa, const void* nb_y_a, const float* nb_state_a, float* nb_partial_a,
+                                         const void* dyb, const void* wb, void* dxb, const void* nb_y_b, const float* nb_state_b, float* nb_partial_b,
+                                         int nb_relu, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream) {
+  pwr::ConvParams a, b;
+  int rc = conv_params_fill(a, dya, wa, nullptr, nullptr, 0, nullptr, dxa, nullptr, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  rc = conv_params_fill(b, dyb, wb, nullptr, nullptr, 0, nullptr, dxb, nullptr, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  if (!nb_partial_a || !nb_partial_b || !dxa || !dxb || !nb_y_a || !nb_y_b || !nb_state_a || !nb_state_b) return PWR_EINVAL;
+  if (dtype != PWR_BF16 || !pwr::conv_patch_pair_applicable(a, b, dtype)) return PWR_EUNSUPPORTED;
+  a.nb_y = nb_y_a; a.nb_state = nb_state_a; a.nb_partial = nb_partial_a; a.nb_relu = nb_relu;
+  b.nb_y = nb_y_b; b.nb_state = nb_state_b; b.nb_partial = nb_partial_b; b.nb_relu = nb_relu;
+  return pwr::launch_conv_patch_pair(a, b, (hipStream_t)stream);
+}
+
 extern "C" size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits) {
   const int cinpad = (cin + 127) / 128 * 128;
   return (size_t)splits * ksize * ksize * cinpad * pwr_conv_out_pad(cout) * sizeof(float);
@@ -1214,6 +1233,42 @@ extern "C" int pwr_conv_wgrad(const void* x, const void* dy, const float* in_nor
     hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<9, 3>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
   else
     hipLaunchKernelGGL((pwr::wgrad_reduce_fast_kernel<1, 16>), g, dim3(256), 0, s, slab, dw, p.S, taps, cout_real, p.CinPad, p.CoutPad, cin_real, accumulate);
+  return (int)hipGetLastError();
+}
+
+static void wgrad_params_fill(pwr::WgradParams& p, const void* x, const void* dy, const float* in_norm, int relu_in, float* slab, int B, int H, int W,
+                              int Cin, int Cout, int ksize, int stride, int splits, int KE) {
+  p.x = x; p.dy = dy; p.in_norm = in_norm; p.slab = slab;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.ksize = ksize; p.stride = stride; p.pad = ksize / 2;
+  p.Ho = (H + 2 * p.pad - ksize) / stride + 1; p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
+  p.CoutPad = pwr_conv_out_pad(Cout); p.CinPad = (Cin + 127) / 128 * 128;
+  p.relu_in = relu_in; p.M = B * p.Ho * p.Wo;
+  const int total_steps = (p.M + KE - 1) / KE;
+  p.steps_per_split = (total_steps + splits - 1) / splits;
+  p.S = (total_steps + p.steps_per_split - 1) / p.steps_per_split;   // effective splits (<= requested)
+}
+
+// Two pwr_conv_wgrad calls of ONE geometry (3x3, stride 1, bf16, whole 128-channel tiles, no padded channels) as ONE launch of the
+// wave-specialised kernel (conv_wgrad_ws.hip) + ONE reduce launch: the two regression heads' convs of the same depth.  `slab` holds both
+// jobs' slabs (2 x pwr_conv_wgrad_slab_bytes).  Results are those of two single calls with the same `splits`, bit for bit.
+extern "C" int pwr_conv_wgrad_pair(const void* xa, const void* dya, const float* in_norm_a, float* dwa, const void* xb, const void* dyb,
+                                   const float* in_norm_b, float* dwb, int relu_in, float* slab, int B, int H, int W, int Cin, int Cout,
+                                   int splits, int dtype, void* stream) {
+  if (dtype != PWR_BF16 || splits < 1 || Cin % 128 || Cout % 128) return PWR_EUNSUPPORTED;
+  pwr::WgradParams a, b;
+  wgrad_params_fill(a, xa, dya, in_norm_a, relu_in, slab, B, H, W, Cin, Cout, 3, 1, splits, 32);
+  const size_t half = pwr_conv_wgrad_slab_bytes(Cout, Cin, 3, splits) / sizeof(float);
+  wgrad_params_fill(b, xb, dyb, in_norm_b, relu_in, slab + half, B, H, W, Cin, Cout, 3, 1, splits, 32);
+  if (!pwr::wgrad3w_applicable(a) || (in_norm_a == nullptr) != (in_norm_b == nullptr)) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = pwr::launch_wgrad3w(a, &b, s);
+  if (rc) return rc;
+  pwr::ReduceGroup r;
+  const int per = ((Cout + 31) / 32) * Cin;
+  r.n = 2; r.total = 2 * per;
+  r.job[0] = pwr::ReduceJob{slab, dwa, a.S, 9, Cout, a.CinPad, a.CoutPad, Cin, 0, 0};
+  r.job[1] = pwr::ReduceJob{slab + half, dwb, b.S, 9, Cout, b.CinPad, b.CoutPad, Cin, 0, per};
+  hipLaunchKernelGGL((pwr::wgrad_reduce_group_kernel<9, 3>), dim3(r.total), dim3(256), 0, s, r);
   return (int)hipGetLastError();
 }
 

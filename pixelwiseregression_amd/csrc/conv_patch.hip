@@ -884,22 +884,25 @@ static int launch_patch_s2(const ConvParams& p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-// The pair form exists for the kernel variant of the heads' convs: bf16, 3x3 stride 1, 128 -> 128 channels, 4 x 32-pixel tiles,
-// 16x16x32 MFMAs with the one-pass epilogue; both jobs of one geometry.
+// The pair form exists for the kernel variants of the heads' convs and of their data gradients: bf16, 3x3 stride 1, 4 x 32-pixel tiles,
+// 128 output channels, 32 / 64 / 128 input channels (128: 16x16x32 MFMAs with the one-pass epilogue, as the single launch picks it;
+// 32 / 64 -- the heads' last data gradient, J padded to a K chunk -- the 32x32x16 form); both jobs of one geometry.
 bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype) {
   static const bool on = (PWR_DBG_ENV("PWR_PATCH_PAIR", 1) != 0);
   auto ok = [&](const ConvParams& p) {
-    return dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 && p.W % 32 == 0 &&
-           p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && !small_map(p, dtype);
+    return dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && (p.Cin == 128 || p.Cin == 64 || p.Cin == 32) && p.Cout == 128 &&
+           p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && !small_map(p, dtype);
   };
-  return on && ok(a) && ok(b) && a.B == b.B && a.H == b.H && a.W == b.W && PWR_DBG_ENV("PWR_PATCH_MF16", 1) != 0 && PWR_DBG_ENV("PWR_PATCH_BIG", 0) == 0;
+  return on && ok(a) && ok(b) && a.B == b.B && a.H == b.H && a.W == b.W && a.Cin == b.Cin && PWR_DBG_ENV("PWR_PATCH_MF16", 1) == 1 && PWR_DBG_ENV("PWR_PATCH_BIG", 0) == 0;
 }
 int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s) {
   ConvPair g{a, b};
   g.a.epi16 = g.b.epi16 = 1;
   g.a.stamps = g.b.stamps = nullptr;
   dim3 grid(a.B * (a.H / 4) * (a.W / 32), a.CoutPad / 128, 2), block(256);
-  hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, g);
+  if (a.Cin == 128) hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, g);
+  else if (a.Cin == 64) hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 64, 2, 2, 2, 2, true>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 32, 2, 2, 2, 2, true>), grid, block, 0, s, g);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,391 @@
+// bf16 weight gradient of a 3x3 stride-1 conv with 128-channel tiles, WAVE-SPECIALISED (round 4): one 512-thread workgroup per CU,
+//   waves 0-3  MFMA waves: nothing but transposing LDS fragment reads and v_mfma_f32_32x32x16_bf16 (a 64 ci x 64 co x 3 taps register
+//              tile each: 192 accumulator registers -- the 128 x 128 x 3 tile that one wave per SIMD could not feed in rounds 1-3)
+//   waves 4-7  loader waves: bring both operands into an LDS ring by LDS-DMA (global_load_lds), apply the operand's pending
+//              norm + ReLU to the landed input tile IN LDS, zero the out-of-image halo pixels -- all the VALU work of the layer
+//
+//   dW[co][ci][ky][kx] = sum_{b, y, x} a[b][y + ky - 1][x + kx - 1][ci] * dy[b][y][x][co]          (/root/reference/model.py:55-63 /
+//   :104-112: the weight gradients of the heads' 128 -> 128 convs under autograd; a = the conv's input AFTER its norm + ReLU)
+//
+// Wave w and wave w + 4 share a SIMD (a workgroup's waves go to SIMDs 0 -> 2 -> 1 -> 3 cyclically), and the matrix pipe and the
+// vector ALU of a SIMD are separate pipes: the loader's norm arithmetic (the 78 VALU instructions per wave and K step that the
+// 128-wide in-LDS-norm tile of round 3 could not hide behind its own MFMAs) issues beside its partner's MFMAs.  The MFMA waves
+// issue no vector-memory instruction at all, so their LDS reads are ordinary compiler-visible loads (the wait-count pass has no
+// LDS-DMA in their path to fence with vmcnt(0)): no inline-asm read whose result arrives behind the compiler's back, which is what
+// conv_wgrad_dma.hip needs its code-object scan for.  The loader waves' LDS accesses ARE inline asm (they sit behind LDS-DMAs in
+// flight), but every read is one asm block that ends in its own s_waitcnt: an output is defined when the statement ends.
+//
+// Same decomposition as conv_wgrad3_kernel / conv_wgrad3d_kernel -- workgroup = (split, kernel row ky), K step = 32 output pixels
+// of one image row with a 34-pixel input row segment serving kx = 0, 1, 2, per-accumulator MFMA sequence (step by step, K half
+// by K half) -- so the slabs are bit-identical to theirs at the same split count, and the same reduce finishes the job.
+//
+// LDS: a ring of NS = 6 stages of [34 px][128 ci] + [32 px][128 co] bf16 rows (17 KiB), 16-byte slots XOR-swizzled by (row & 3) so
+// that the four pixel rows of a ds_read_b64_tr_b16 group fall on different bank quarters; the swizzle and the halo go into the
+// per-lane SOURCE address of the DMA (cdna_hip_programming.md rule 21).  Per K step s, between barrier s and barrier s + 1:
+//   MFMA waves    read stage s (the first fragments were read ahead during step s - 1), 24 MFMAs each
+//   loader waves  issue the DMA of step s + 5 into the stage read during step s - 1; normalise the tile of step s + 2 in place;
+//                 wait until their own pieces of step s + 3 have landed (counted vmcnt: steps s + 4, s + 5 stay in flight)
+// so a DMA has three K steps to land, a tile is normalised one full step before it is read, and a stage is overwritten only after
+// a barrier every MFMA wave reached with its reads retired.
+#include "conv_common.h"
+#include "pwr.h"
+
+namespace pwr {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_ws;
+
+struct WgradPair { WgradParams a, b; };
+
+namespace ws {
+constexpr int KP = 32, XROWS = KP + 2, RB = 256;                 // K step, staged input pixels, bytes per staged pixel (128 ch bf16)
+constexpr int XCH = (XROWS * RB + 1023) / 1024, YCH = KP * RB / 1024, NCH = XCH + YCH;     // 1-KiB DMA pieces: 9 + 8
+constexpr int NLW = 4, NCW = (NCH + NLW - 1) / NLW;              // loader waves; pieces per loader wave and step (5, three of them padding)
+constexpr int XBYTES = XCH * 1024, STAGE = NCH * 1024;
+constexpr int NS = 6, D = NS - 1;                                // ring stages; a step's pieces are issued D steps ahead
+constexpr int MAXSB = 8;                                         // norm states of at most this many samples per split
+constexpr int STATE_BYTES = MAXSB * 3 * 128 * 4;
+constexpr int LDS_BYTES = NS * STAGE + STATE_BYTES;
+
+// byte offset of 16-byte slot `slot` of row `row` (256-byte rows)
+__device__ __forceinline__ int swz(int row, int slot) { return row * RB + ((slot ^ ((row & 3) << 2)) << 4); }
+// lane part of the address of an MFMA 32x32x16 operand fragment read by two ds_read_b64_tr_b16 (rows +0 / +4): 8 K values = pixels
+// k0 + 8 (lane / 32) .. + 7 of channel chb + lane % 32 (conv_wgrad_dma.hip: wfrag_lane)
+__device__ __forceinline__ int frag_lane(int k0, int chb, int lane) {
+  const int li = lane & 15, cg = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, pp = li & 3;
+  return swz(k0 + 8 * h + q, (chb >> 3) + 2 * cg + (pp >> 1)) + 8 * (pp & 1);
+}
+__device__ __forceinline__ bf16x8 frag(const char* a) {
+  typedef __attribute__((address_space(3))) bf16x4_ws* lptr;
+  const bf16x4_ws lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)a);
+  const bf16x4_ws hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(a + 4 * RB));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+constexpr unsigned vmwait(int n) { return (unsigned)((n & 15) | ((n >> 4) << 14) | 0x0070); }      // s_waitcnt vmcnt(n) lgkmcnt(0)
+}  // namespace ws
+
+template <bool NRM, bool RELU>
+__global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
+  using namespace ws;
+  typedef bf16_t T;
+  typedef bf16x8 V;
+  const WgradParams p = blockIdx.z ? g.b : g.a;          // (by value: scalar registers, no kernarg reloads inside the loops)
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // blockIdx.x enumerates (split, ky) so that the three ky workgroups of one split are 8 ids apart (one XCD, speed only)
+  const int grp = blockIdx.x / 24, rr = blockIdx.x - grp * 24;
+  const int ky = rr >> 3;
+  const int split = grp * 8 + (rr & 7);
+  if (split >= p.S) return;
+  const int ntn = p.CoutPad / 128;
+  const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
+  const int ci0 = mtile * 128, co0 = ntile * 128;
+  const int step0 = split * p.steps_per_split;
+  const int total_steps = p.M / KP;
+  int nsteps = total_steps - step0;
+  if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+  const int tiles_x = p.W / KP;
+  // tile coordinates of the split's first step
+  const int b0 = step0 / (p.H * tiles_x);
+  const int rem0 = step0 - b0 * p.H * tiles_x;
+  const int y0 = rem0 / tiles_x, x0 = rem0 - y0 * tiles_x;
+
+  if constexpr (NRM) {
+    // The norm states (mean, scale, beta) of the samples this split touches go to LDS BEFORE the first DMA is issued: a global load
+    // inside the loop would make the wait-count pass put vmcnt(0) -- a wait for every prefetch in flight -- in front of its use.
+    const size_t plane = (size_t)p.B * p.Cin;
+    float* stl = reinterpret_cast<float*>(smem + NS * STAGE);
+    const int lastb = (step0 + (nsteps > 0 ? nsteps - 1 : 0)) / (p.H * tiles_x);
+    const int cnt = (lastb - b0 + 1) * 3 * 128;
+    for (int idx = tid; idx < cnt; idx += 512) {
+      const int sb = idx / (3 * 128), k = (idx >> 7) % 3, ch = idx & 127;
+      stl[idx] = p.in_norm[(size_t)(k == 0 ? 0 : k + 1) * plane + (size_t)(b0 + sb) * p.Cin + ci0 + ch];
+    }
+    __syncthreads();
+  }
+
+  if (wid >= NLW) {
+    // =================================================================== loader waves
+    const int lw = wid - NLW, lt = tid - 64 * NLW;         // loader wave 0..3, loader thread 0..255
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    // per-lane descriptors of this wave's DMA pieces (constant over the steps; only the tile origin moves): loader wave lw issues the
+    // pieces lw, lw + 4, ... -- five for wave 0 (it holds the halo pixels 0 and 33, pieces 0 and 8: one clamp delta each), four for the others
+    constexpr int I_R = ((XROWS - 1) * RB / 1024) / NLW;
+    static_assert(((XROWS - 1) * RB / 1024) % NLW == 0 && I_R != 0 && I_R < NCW && NCH == NLW * (NCW - 1) + 1, "wave 0: NCW pieces, the others NCW - 1");
+    int d_lds[NCW], d_off[NCW], d_dl = 0, d_dr = 0;
+    bool d_isx[NCW];
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+      int c = lw + NLW * i;
+      if (c >= NCH) c = lw;                         // (not issued: only wave 0 has a fifth piece)
+      d_lds[i] = c * 1024;
+      d_isx[i] = c < XCH;
+      const int cx_ = c < XCH ? c : c - XCH;
+      const int q = 64 * cx_ + lane;
+      const int r0 = q >> 4, s1 = q & 15;             // row and physical slot of this lane's 16 bytes
+      const int xr = r0 < XROWS ? r0 : XROWS - 1;     // rows beyond the 34th: nobody reads them
+      const int sl = s1 ^ ((r0 & 3) << 2);            // the channel slot that belongs there
+      const int xoff = (xr - 1) * p.Cin + ci0 + 8 * sl;
+      const int yoff = r0 * p.Cout + co0 + 8 * sl;
+      d_off[i] = d_isx[i] ? xoff : yoff;
+      if (i == 0) d_dl = (d_isx[i] && xr == 0) ? p.Cin : 0;              // out-of-image halo: clamped into the row, zeroed in LDS afterwards
+      if (i == I_R) d_dr = (d_isx[i] && xr == XROWS - 1) ? -p.Cin : 0;
+    }
+    const bool five = lw == 0;                          // (wave-uniform)
+    int ib = b0, iyy = y0, ix = x0, issued = 0;         // next step to ISSUE
+    auto issue = [&](int soff) {
+      const int iy = iyy + ky - 1;
+      const bool rowok = iy >= 0 && iy < p.H;
+      const T* xrow = x + (((long long)ib * p.H + (rowok ? iy : iyy)) * p.W + ix * KP) * p.Cin;
+      const T* drow = dy + (((long long)ib * p.H + iyy) * p.W + ix * KP) * p.Cout;
+      const int first = ix == 0 ? 1 : 0, last = ix == tiles_x - 1 ? 1 : 0;
+      char* base = smem + soff;
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) {
+        if (i == NCW - 1 && !five) break;
+        const T* src = (d_isx[i] ? xrow : drow) + (d_off[i] + (i == 0 ? first * d_dl : 0) + (i == I_R ? last * d_dr : 0));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(base + d_lds[i]), 16, 0, 0);
+      }
+      ++issued;
+      if (++ix == tiles_x) { ix = 0; if (++iyy == p.H) { iyy = 0; ++ib; } }
+    };
+    // all but this wave's pieces of the `k` most recently issued steps have landed, and every LDS access of the wave has retired
+    auto landed_but = [&](int k) {
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      if (five) {
+        if (k >= 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * NCW));
+        else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * NCW));
+        else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NCW));
+        else __builtin_amdgcn_s_waitcnt(vmwait(0));
+      } else {
+        if (k >= 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * (NCW - 1)));
+        else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * (NCW - 1)));
+        else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NCW - 1));
+        else __builtin_amdgcn_s_waitcnt(vmwait(0));
+      }
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    };
+
+    // ---- the in-LDS pass over a landed input tile: norm + ReLU (NRM), zeros for the out-of-image halo pixels, and an all-zero tile where
+    // the whole input ROW lies outside the image (ky = 0 / 2 at the top / bottom: the step then adds nothing, without a branch or a select
+    // in the MFMA waves).  Loader thread lt owns the 16-byte slots lt and lt + 256 of the tile's 34 x 16 slots (rows lt / 16 and + 16); the
+    // 32 slots of rows 32 and 33 go to the threads 192 .. 223 (rows 12, 13 + 20: the SAME eight channels, the swizzle repeats every 4 rows)
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    const unsigned nrl = lds0 + lt * 16;
+    const int nr_row = lt >> 4;
+    const int nr_ch = 8 * ((lt & 15) ^ ((nr_row & 3) << 2));      // first of the eight channels (relative to ci0)
+    const bool third = lt >= 192 && lt < 224;                     // (wave 3 only)
+    constexpr int OFF3 = (512 - 192) * 16;                        // byte offset of the third slot from the first
+    float mu[8], sc[8], be[8];
+    int state_b = -1;
+    int nb = b0, ny = y0, nx = x0;                                // tile coordinates of the step whose tile is processed next
+    auto nr_state = [&]() {                                       // (a change of sample: at most every H * W / 32 steps)
+      if (nb != state_b) {
+        const unsigned a = lds0 + NS * STAGE + (nb - b0) * (3 * 128 * 4) + nr_ch * 4;
+        f32x4 q0, q1, q2, q3, q4, q5;
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:512\n\tds_read_b128 %3, %6 offset:528\n\t"
+                     "ds_read_b128 %4, %6 offset:1024\n\tds_read_b128 %5, %6 offset:1040\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(a) : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mu[e] = q0[e]; mu[4 + e] = q1[e]; sc[e] = q2[e]; sc[4 + e] = q3[e]; be[e] = q4[e]; be[4 + e] = q5[e]; }
+        state_b = nb;
+      }
+    };
+    auto nr_math = [&](f32x4 raw) {                               // conv_wgrad3_kernel's arithmetic: bit-identical tile
+      V v = __builtin_bit_cast(V, raw), o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = fmaf((float)v[e] - mu[e], sc[e], be[e]);
+        if constexpr (RELU) f = fmaxf(f, 0.f);
+        o[e] = (bf16_t)f;
+      }
+      return __builtin_bit_cast(f32x4, o);
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto tile_pass = [&](int soff) {                              // soff: byte offset of the ring stage that holds the tile
+      const bool zl = nx == 0, zr = nx == tiles_x - 1;            // the tile touches the left / right image border
+      const int iy = ny + ky - 1;
+      const bool rowzero = iy < 0 || iy >= p.H;                   // the whole input row is zero padding
+      const unsigned a = nrl + soff;
+      if constexpr (NRM) {
+#ifdef PWR_DEBUG_BUILD
+        if (p.dbg & 4) { if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } } return; }       // elimination: no tile pass at all
+#endif
+        nr_state();
+        f32x4 r0, r1, r2;
+        if (lw == NLW - 1) {                                       // (wave-uniform: the wave that owns rows 32 and 33)
+          asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(a), "n"(OFF3) : "memory");
+        } else {
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a) : "memory");
+          r2 = zero4;
+        }
+        f32x4 o0 = nr_math(r0), o1 = nr_math(r1);
+#ifdef PWR_DEBUG_BUILD
+        if (p.dbg & 1) { o0 = r0; o1 = r1; }                       // elimination: no norm arithmetic (raw values stored back)
+        if (p.dbg & 2) { if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } } return; }       // elimination: reads + arithmetic, no stores
+#endif
+        if (rowzero | zl | zr) {                                   // (wave-uniform, rare: image borders)
+          if (rowzero || (zl && nr_row == 0)) o0 = zero4;
+          if (rowzero) o1 = zero4;
+        }
+        asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(o0) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(o1) : "memory");
+        if (lw == NLW - 1) {
+          f32x4 o2 = nr_math(r2);
+          if (rowzero || (zr && lt >= 208)) o2 = zero4;            // (threads 208 .. 223 hold row 33)
+          if (third) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(o2), "n"(OFF3) : "memory");
+        }
+      } else {
+        if (rowzero) {
+          asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(zero4) : "memory");
+          asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(zero4) : "memory");
+          if (third) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(zero4), "n"(OFF3) : "memory");
+        } else if (lt < 16) {                                      // one 256-byte pixel row = 16 slots
+          if (zl) asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(zero4) : "memory");
+          if (zr) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(zero4), "n"((XROWS - 1) * RB) : "memory");
+        }
+      }
+      if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } }
+    };
+
+    // ---- prologue: steps 0 .. D-1 in flight, tiles 0 and 1 processed, tile 2 landed
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < nsteps) issue(k * STAGE);
+    landed_but(issued - 2);                                        // tiles 0 and 1 are needed
+    __builtin_amdgcn_s_barrier();                                  // (P) every loader's pieces of tiles 0 and 1 have landed
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    tile_pass(0);
+    if (nsteps > 1) tile_pass(STAGE);
+    landed_but(issued - 3);
+    int stg = 0;                                                   // ring stage of step s
+#pragma nounroll
+    for (int s = 0; s < nsteps; ++s) {
+      __builtin_amdgcn_s_barrier();                                // barrier s
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      const int istg = stg == 0 ? NS - 1 : stg - 1;                // (s + D) % NS: the stage read during step s - 1
+      if (s + D < nsteps) issue(istg * STAGE);
+      if (s + 2 < nsteps) { const int t2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2; tile_pass(t2 * STAGE); }
+      // issued so far: the steps up to min(s + D, nsteps - 1); needed at barrier s + 1: step s + 3 landed (and every LDS store retired)
+      landed_but((s + D < nsteps - 1 ? s + D : nsteps - 1) - (s + 3));
+      stg = stg + 1 == NS ? 0 : stg + 1;
+    }
+    __builtin_amdgcn_s_waitcnt(vmwait(0));                         // (no DMA may be in flight when the workgroup's LDS is released)
+    __builtin_amdgcn_s_barrier();                                  // barrier nsteps (the MFMA waves' last)
+    return;
+  }
+
+  // ===================================================================== MFMA waves
+  const int wm = wid >> 1, wn = wid & 1;
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+  // lane parts of the fragment addresses: input tile per (tap, 32-channel block), dy tile per 32-channel block
+  const char* xl[3][2];
+  const char* yl[2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xl[t][i] = smem + frag_lane(t, wm * 64 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) yl[j] = smem + XBYTES + frag_lane(0, wn * 64 + j * 32, lane);
+
+  // unit u = (K half h = u / 3, tap t = u % 3): two input fragments (the wave's two 32-channel blocks), four MFMAs against the two dy
+  // fragments of half h.  Input fragments in a ring of three units (read two units ahead), dy fragments double-buffered by half.
+  V A[3][2], Bf[2][2];
+  auto loadA = [&](V (&a)[2], int soff, int u) {
+    const int h = u / 3, t = u - 3 * h;
+    a[0] = frag(xl[t][0] + soff + h * 16 * RB);
+    a[1] = frag(xl[t][1] + soff + h * 16 * RB);
+  };
+  auto loadB = [&](V (&b)[2], int soff, int h) {
+    b[0] = frag(yl[0] + soff + h * 16 * RB);
+    b[1] = frag(yl[1] + soff + h * 16 * RB);
+  };
+  auto mma = [&](int t, const V (&a)[2], const V (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+  };
+  // interleave: one MFMA, then the next unit's LDS reads behind it
+#define PWR_WS_SCHED(reads)                                  \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
+  __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);   \
+  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+
+  __syncthreads();                                                 // (P)
+  __syncthreads();                                                 // barrier 0: stages 0 and 1 are complete
+  loadA(A[0], 0, 0); loadA(A[1], 0, 1); loadB(Bf[0], 0, 0);
+  int stg = 0;
+#pragma nounroll
+  for (int s = 0; s < nsteps; ++s) {
+    const int soff = stg * STAGE;
+    const int nstg = stg + 1 == NS ? 0 : stg + 1;
+    const int noff = nstg * STAGE;
+    // (an out-of-image input ROW -- ky = 0 / 2 at the top / bottom -- arrives as an all-zero tile from the loader waves: acc + 0 = acc bit
+    // for bit, one straight-line loop body; a branch around the MFMAs made the register allocator copy the 192 accumulators between the
+    // two paths and spill them)
+    loadA(A[2], soff, 2); loadB(Bf[1], soff, 1);
+    mma(0, A[0], Bf[0]); PWR_WS_SCHED(8)
+    loadA(A[0], soff, 3); mma(1, A[1], Bf[0]); PWR_WS_SCHED(4)
+    loadA(A[1], soff, 4); mma(2, A[2], Bf[0]); PWR_WS_SCHED(4)
+    loadA(A[2], soff, 5); loadB(Bf[0], noff, 0);
+    mma(0, A[0], Bf[1]); PWR_WS_SCHED(8)
+    loadA(A[0], noff, 0); mma(1, A[1], Bf[1]); PWR_WS_SCHED(4)
+    loadA(A[1], noff, 1); mma(2, A[2], Bf[1]); PWR_WS_SCHED(4)
+    stg = nstg;
+    __syncthreads();                                               // barrier s + 1: this wave's reads of stage s have retired; stage s + 2 is complete
+  }
+#undef PWR_WS_SCHED
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* __restrict__ out = p.slab + ((size_t)(split * 9 + ky * 3 + t) * p.CinPad) * p.CoutPad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = ci0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int co = co0 + wn * 64 + j * 32 + r;
+          out[(size_t)ci * p.CoutPad + co] = acc[t][i][j][e];
+        }
+  }
+}
+
+// 3x3 stride 1, 32-pixel row segments, whole 128-channel tiles on both sides; a split spans at most MAXSB samples' norm states
+bool wgrad3w_applicable(const WgradParams& p) {
+  const bool on = PWR_DBG_ENV("PWR_WGRAD3W", 1) != 0;      // (debug build: read per call, so that one process can A/B the kernels)
+  if (!on || p.ksize != 3 || p.stride != 1 || p.W % 32 || p.M % 32 || p.Cin % 128 || p.Cout % 128 || p.CoutPad != p.Cout || p.CinPad != p.Cin) return false;
+  return p.steps_per_split <= (ws::MAXSB - 1) * (p.H * p.W / 32);
+}
+
+// one job (b == nullptr) or two jobs of ONE geometry (the two regression heads' layers of the same depth) in one launch
+int launch_wgrad3w(const WgradParams& a, const WgradParams* b, hipStream_t s) {
+  if (b && (a.B != b->B || a.H != b->H || a.W != b->W || a.Cin != b->Cin || a.Cout != b->Cout || a.S != b->S || a.steps_per_split != b->steps_per_split ||
+            (a.in_norm == nullptr) != (b->in_norm == nullptr)))
+    return PWR_EINVAL;
+  WgradPair g{a, b ? *b : a};
+  g.a.dbg = g.b.dbg = PWR_DBG_ENV("PWR_WGRAD3W_DBG", 0);     // (debug build: timing by elimination, results are WRONG)
+  dim3 grid(24 * ((a.S + 7) / 8), (a.Cin / 128) * (a.Cout / 128), b ? 2 : 1), block(512);
+  if (a.in_norm && a.relu_in) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, true>), grid, block, 0, s, g);
+  else if (a.in_norm) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, false>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((conv_wgrad3w_kernel<false, false>), grid, block, 0, s, g);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pwr

@@ -303,6 +303,16 @@ struct Engine {
     static const int tr_target = PWR_DBG_ENV("PWR_WGRAD_TR_SLOTS", 512);
     int s = w3 ? (target / tiles) / 8 * 8 : (tr_target + tiles - 1) / tiles;
     if (w3 && s < 8) s = 8;
+    // whole 128-channel tiles on both sides: the wave-specialised kernel (conv_wgrad_ws.hip).  Its 512-thread workgroup takes a whole CU
+    // (8 waves x 250 registers), so it is given FEW, long-running workgroups -- 72 = 24 splits x 3 kernel rows of a 128 -> 128 layer --
+    // and the other CUs stay free for the chain: measured on the train step (same box, profiles/r4_experiments.md): 80 splits (240
+    // workgroups: every small chain kernel waits for a CU) 6.28 ms, 48: 6.00, 32: 5.91, 24: 5.82 - 5.87, 16: 5.97, 12: 6.45; the
+    // register-staged kernel at its 80 splits: 6.01 - 6.14.  At least one split per six samples (the kernel keeps <= 8 samples' norm states).
+    if (w3 && cin % 128 == 0 && cout % 128 == 0 && PWR_DBG_ENV("PWR_WGRAD3W", 1)) {
+      s = PWR_DBG_ENV("PWR_WGRAD3W_SPLITS", 24) / per;
+      if (s < (B + 5) / 6) s = (B + 5) / 6;
+      if (s < 1) s = 1;
+    }
     const int maxs = steps / 8 > 0 ? steps / 8 : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -336,7 +346,7 @@ struct Engine {
   }
   // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
   // chunks > 0: the data-gradient conv that produced g already wrote the two reductions (conv_bwd's return value)
-  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0, bool handoff = false) {
+  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0, bool handoff = false, size_t cpart_off = 0) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
     Engine* E = this;
     const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
@@ -346,7 +356,7 @@ struct Engine {
       if (elim_mask() & 2) return 0;
       const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
       if (chunks > 0 && mode != 2)   // (eval-mode batch norm: statistics are constants, the plain path handles it)
-        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart),
+        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart + cpart_off),
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
                                          c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
@@ -775,6 +785,122 @@ struct Engine {
     conv_bwd(f, nullptr, h.c0, h.h1, false, true, accumulate_df);
   }
 
+  // Both heads of a stage backwards in LOCK-STEP (round 4): the plane and the depth head run the same three 128 -> 128 convs on different
+  // tensors, so their data gradients of one depth go out as ONE launch (pwr_conv_dgrad_stats_pair: a boundary between two full-chip
+  // launches of the dominant conv costs 8 - 9 us, tools/launch_bubble.py) and their weight gradients as ONE launch of the
+  // wave-specialised kernel + ONE reduce (pwr_conv_wgrad_pair: half the splits per layer -- half the split-K slab traffic -- at twice the
+  // K extent).  Same kernels, same per-launch arithmetic as head_bwd() twice; falls back to that when a shape has no pair kernel.
+  void heads_bwd(const Tn& f, const Head& hp, const Head& hd, size_t gz_off, size_t gD_off) {
+    static const bool on = PWR_DBG_ENV("PWR_HEAD_BWD_PAIR", 1) != 0;
+    const int Jp = pad_narrow(J);
+    const int ch = (stats_mask() & 2) ? pwr_conv_stats_chunks(P, P, F, F, ks, 1, 0, dtype) : 0;
+    const int ch3 = (stats_mask() & 2) ? pwr_conv_stats_chunks(P, P, Jp, F, ks, 1, 0, dtype) : 0;
+    if (!on || dtype != PWR_BF16 || norm_mode != 0 || ks != 3 || F != 128 || ch <= 0 || ch3 != ch || (Jp != 32 && Jp != 64) || P % 32) {
+      head_bwd(f, hp, gz_off, false);
+      head_bwd(f, hd, gD_off, true);
+      return;
+    }
+    scope = "s" + std::to_string(cur_stage) + ".heads.bwd";
+    const int Bc = B, dt = dtype, Jc = J, Pc = P, Fc = F, kk = ks;
+    const int M = B * P * P;
+    const size_t half = ((size_t)B * ch * 2 * F * 4 + 255) / 256 * 256;
+    if (2 * half > need_cpartial) need_cpartial = 2 * half;
+    const int splits3 = splits_for(M, F, Jp, ks);
+    want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits3));
+    const bool wpair = PWR_DBG_ENV("PWR_HEAD_WGRAD_PAIR", 0) != 0;      // weight gradients of the two heads in one launch (measured: no gain)
+    const int splits_pair = wpair ? std::max(1, splits_for(M, F, F, ks) / 2) : splits_for(M, F, F, ks);
+    want_slab(2 * pwr_conv_wgrad_slab_bytes(F, F, ks, splits_pair));
+    Engine* E = this;
+    const Head P_ = hp, D_ = hd;
+    // ---- the heads' last convs (F -> J): output gradients to NHWC, bias sums, the two weight gradients, the paired data gradient
+    bwd_cur.push_back([=](Ctx& c) {
+      const Head* hs[2] = {&P_, &D_};
+      const size_t gsrc[2] = {gz_off, gD_off};
+      int rc = 0;
+      for (int k = 0; k < 2 && !rc; ++k) {
+        const Head& h = *hs[k];
+        rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + gsrc[k]), c.arena + h.gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
+        if (!rc) rc = pwr_planesum_nchw((const float*)(c.arena + gsrc[k]), (float*)(c.arena + E->scr_S1), c.grads + h.c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
+      }
+      for (int k = 0; k < 2 && !rc; ++k) {
+        const Head h = *hs[k];
+        rc = run_on_side(c, [=](Ctx& c2) {
+          return pwr_conv_wgrad(c2.arena + h.h3.off, c2.arena + h.gT, (float*)(c2.arena + h.n2.state), 1, (float*)(c2.arena + E->scr_slab + c2.slab_off),
+                                c2.grads + h.c3.w, 0, Bc, Pc, Pc, Fc, Fc, Jp, Jc, kk, 1, splits3, dt, c2.stream);
+        });
+      }
+      if (rc) return rc;
+      float* pa = (float*)(c.arena + E->scr_cpartial);
+      float* pb = (float*)(c.arena + E->scr_cpartial + half);
+      rc = pwr_conv_dgrad_stats_pair(c.arena + P_.gT, c.packs + P_.c3.pack_d, c.arena + P_.h3.goff, c.arena + P_.h3.off, (float*)(c.arena + P_.n2.state), pa,
+                                     c.arena + D_.gT, c.packs + D_.c3.pack_d, c.arena + D_.h3.goff, c.arena + D_.h3.off, (float*)(c.arena + D_.n2.state), pb,
+                                     1, Bc, Pc, Pc, Jp, Fc, kk, dt, c.stream);
+      if (rc != PWR_EUNSUPPORTED) return rc;
+      rc = pwr_conv_fwd_stats(c.arena + P_.gT, c.packs + P_.c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + P_.h3.goff, Bc, Pc, Pc, Jp, Fc, kk, 1, 0,
+                              nullptr, c.arena + P_.h3.off, (float*)(c.arena + P_.n2.state), pa, 1, dt, c.stream);
+      if (rc) return rc;
+      return pwr_conv_fwd_stats(c.arena + D_.gT, c.packs + D_.c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + D_.h3.goff, Bc, Pc, Pc, Jp, Fc, kk, 1, 0,
+                                nullptr, c.arena + D_.h3.off, (float*)(c.arena + D_.n2.state), pb, 1, dt, c.stream);
+    });
+    norm_bwd(hp.h3, hp.n2, 0, false, ch, false, 0);
+    norm_bwd(hd.h3, hd.n2, 0, false, ch, false, half);
+    // ---- conv depth 2, 1: (x, its norm, conv, y) per head
+    struct Lvl { Tn xp, xd, yp, yd; NormL np, nd; ConvL cp, cd; };
+    const Lvl lv[2] = {{hp.h2, hd.h2, hp.h3, hd.h3, hp.n1, hd.n1, hp.c2, hd.c2}, {hp.h1, hd.h1, hp.h2, hd.h2, hp.n0, hd.n0, hp.c1, hd.c1}};
+    for (int q = 0; q < 2; ++q) {
+      const Lvl L = lv[q];
+      bwd_cur.push_back([=](Ctx& c) {
+        int rc = run_on_side(c, [=](Ctx& c2) {
+          float* slab = (float*)(c2.arena + E->scr_slab + c2.slab_off);
+          int r2 = !wpair ? PWR_EUNSUPPORTED
+                          : pwr_conv_wgrad_pair(c2.arena + L.xp.off, c2.arena + L.yp.goff, (float*)(c2.arena + L.np.state), c2.grads + L.cp.w,
+                                                c2.arena + L.xd.off, c2.arena + L.yd.goff, (float*)(c2.arena + L.nd.state), c2.grads + L.cd.w, 1, slab, Bc, Pc, Pc,
+                                                Fc, Fc, splits_pair, dt, c2.stream);
+          if (r2 != PWR_EUNSUPPORTED) return r2;
+          r2 = pwr_conv_wgrad(c2.arena + L.xp.off, c2.arena + L.yp.goff, (float*)(c2.arena + L.np.state), 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
+                              Fc, kk, 1, splits_pair, dt, c2.stream);
+          if (r2) return r2;
+          return pwr_conv_wgrad(c2.arena + L.xd.off, c2.arena + L.yd.goff, (float*)(c2.arena + L.nd.state), 1, slab, c2.grads + L.cd.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
+                                Fc, kk, 1, splits_pair, dt, c2.stream);
+        });
+        if (rc) return rc;
+        if (elim_mask() & 4) return 0;
+        float* pa = (float*)(c.arena + E->scr_cpartial);
+        float* pb = (float*)(c.arena + E->scr_cpartial + half);
+        rc = pwr_conv_dgrad_stats_pair(c.arena + L.yp.goff, c.packs + L.cp.pack_d, c.arena + L.xp.goff, c.arena + L.xp.off, (float*)(c.arena + L.np.state), pa,
+                                       c.arena + L.yd.goff, c.packs + L.cd.pack_d, c.arena + L.xd.goff, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb,
+                                       1, Bc, Pc, Pc, Fc, Fc, kk, dt, c.stream);
+        if (rc != PWR_EUNSUPPORTED) return rc;
+        rc = pwr_conv_fwd_stats(c.arena + L.yp.goff, c.packs + L.cp.pack_d, nullptr, nullptr, 0, nullptr, c.arena + L.xp.goff, Bc, Pc, Pc, Fc, Fc, kk, 1, 0,
+                                nullptr, c.arena + L.xp.off, (float*)(c.arena + L.np.state), pa, 1, dt, c.stream);
+        if (rc) return rc;
+        return pwr_conv_fwd_stats(c.arena + L.yd.goff, c.packs + L.cd.pack_d, nullptr, nullptr, 0, nullptr, c.arena + L.xd.goff, Bc, Pc, Pc, Fc, Fc, kk, 1, 0,
+                                  nullptr, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb, 1, dt, c.stream);
+      });
+      norm_bwd(L.xp, L.np, 0, false, ch, false, 0);
+      norm_bwd(L.xd, L.nd, 0, false, ch, false, half);
+    }
+    // ---- the heads' first convs read the hourglass output f as it is: paired weight gradient (no norm), then f.g = both data gradients
+    bwd_cur.push_back([=](Ctx& c) {
+      int rc = run_on_side(c, [=](Ctx& c2) {
+        float* slab = (float*)(c2.arena + E->scr_slab + c2.slab_off);
+        int r2 = !wpair ? PWR_EUNSUPPORTED
+                        : pwr_conv_wgrad_pair(c2.arena + f.off, c2.arena + P_.h1.goff, nullptr, c2.grads + P_.c0.w, c2.arena + f.off, c2.arena + D_.h1.goff, nullptr,
+                                              c2.grads + D_.c0.w, 1, slab, Bc, Pc, Pc, Fc, Fc, splits_pair, dt, c2.stream);
+        if (r2 != PWR_EUNSUPPORTED) return r2;
+        r2 = pwr_conv_wgrad(c2.arena + f.off, c2.arena + P_.h1.goff, nullptr, 1, slab, c2.grads + P_.c0.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
+        if (r2) return r2;
+        return pwr_conv_wgrad(c2.arena + f.off, c2.arena + D_.h1.goff, nullptr, 1, slab, c2.grads + D_.c0.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
+      });
+      if (rc) return rc;
+      if (elim_mask() & 4) return 0;
+      rc = pwr_conv_fwd(c.arena + P_.h1.goff, c.packs + P_.c0.pack_d, nullptr, nullptr, 0, nullptr, c.arena + f.goff, nullptr, Bc, Pc, Pc, Fc, Fc, kk, 1, 0, dt, c.stream);
+      if (rc) return rc;
+      return pwr_conv_fwd(c.arena + D_.h1.goff, c.packs + D_.c0.pack_d, nullptr, nullptr, 0, c.arena + f.goff, c.arena + f.goff, nullptr, Bc, Pc, Pc, Fc, Fc, kk, 1, 0, dt,
+                          c.stream);
+    });
+  }
+
   // ---------------------------------------------------------------- whole network
   bool build() {
     const bool tr = training;
@@ -889,8 +1015,7 @@ struct Engine {
           if (rc || woff < 0) return rc;
           return pwr_decode_gw_reduce((const float*)(c.arena + Rc.gwp), c.grads + woff, Bc, Jc, 0, c.stream);
         });
-        head_bwd(f, hp, R.gz, false);
-        head_bwd(f, hd, R.gDt, true);
+        heads_bwd(f, hp, hd, R.gz, R.gDt);
         bwd_cur.insert(bwd_cur.end(), hg_bwd.begin(), hg_bwd.end());
         // stage-input conv backward
         if (s == 0) {

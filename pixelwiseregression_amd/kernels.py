@@ -369,6 +369,33 @@ def conv_fwd_stats_pair(xa, wa, xb, wb, cout, ksize, bias_a=None, bias_b=None, n
     return (ya, pa), (yb, pb), chunks
 
 
+def conv_dgrad_stats_pair(dya, wa, nb_y_a, nb_state_a, dyb, wb, nb_y_b, nb_state_b, cout, ksize, nb_relu=True):
+    """Two stride-1 data gradients with norm-backward sums (conv_fwd_stats with nb_y) of one shape in one launch.
+    Returns (dxa, partial_a), (dxb, partial_b), chunks."""
+    l = _lib.lib()
+    B, H, W, Cin = dya.shape
+    chunks = l.pwr_conv_stats_chunks(H, W, Cin, cout, ksize, 1, 0, _dt(dya))
+    if chunks <= 0:
+        raise _lib.PwrError("conv shape does not support epilogue statistics")
+    xa, xb = (torch.empty(B, H, W, cout, dtype=dya.dtype, device=dya.device) for _ in range(2))
+    pa, pb = (torch.full((B * chunks, 2, cout), float("nan"), dtype=torch.float32, device=dya.device) for _ in range(2))
+    _lib.check(l.pwr_conv_dgrad_stats_pair(_p(dya), _p(wa), _p(xa), _p(nb_y_a), _p(nb_state_a), _p(pa), _p(dyb), _p(wb), _p(xb), _p(nb_y_b),
+                                           _p(nb_state_b), _p(pb), int(nb_relu), B, H, W, Cin, cout, ksize, _dt(dya), _s(dya)), "pwr_conv_dgrad_stats_pair")
+    return (xa, pa), (xb, pb), chunks
+
+
+def conv_wgrad_pair(xa, dya, xb, dyb, norm_a=None, norm_b=None, relu_in=True, splits=42):
+    """Two 3x3 stride-1 weight gradients of one geometry in one launch + one reduce (pwr_conv_wgrad_pair).  Returns dwa, dwb."""
+    l = _lib.lib()
+    B, H, W, Cin = xa.shape
+    Cout = dya.shape[-1]
+    slab = torch.empty(2 * l.pwr_conv_wgrad_slab_bytes(Cout, Cin, 3, splits) // 4, dtype=torch.float32, device=xa.device)
+    dwa, dwb = (torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=xa.device) for _ in range(2))
+    _lib.check(l.pwr_conv_wgrad_pair(_p(xa), _p(dya), _p(norm_a), _p(dwa), _p(xb), _p(dyb), _p(norm_b), _p(dwb), int(relu_in), _p(slab), B, H, W,
+                                     Cin, Cout, splits, _dt(xa), _s(xa)), "pwr_conv_wgrad_pair")
+    return dwa, dwb
+
+
 def norm_finalize_partial(partial, chunks, gamma, beta, B, HW, mode=0, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     l = _lib.lib()
     C = gamma.numel()

@@ -101,3 +101,85 @@ def test_rccl_path_single_rank_is_bit_identical_to_single_gpu(tmp_path):
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     _, same_p, same_g, same_l, maxdiff = lines[0].split()
     assert same_p == "True" and same_g == "True" and same_l == "True", lines[0]
+
+
+WORKER_RCCL2 = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pixelwiseregression_amd import PixelwiseRegression
+from pixelwiseregression_amd.ddp import DataParallel
+from pixelwiseregression_amd.synthetic import make_pose_batch
+from pixelwiseregression_amd.train import TrainStep
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)       # "nccl" IS RCCL on ROCm
+J, S, Bs = 14, 128, 8                                                              # per-rank shard of a global batch of world * Bs
+big = make_pose_batch(world * Bs, J, S, seed=300, device=dev)                      # every rank renders the same global batch
+shard = {k: v[rank * Bs:(rank + 1) * Bs].contiguous() for k, v in big.items()}
+def model(seed):
+    torch.manual_seed(seed)
+    return PixelwiseRegression(J, stage=2, label_size=S // 2, features=128, level=4, norm_method="instance").to(dev).set_precision("fp32").train()
+def loss_of(m, b):
+    res = m(b["img"], b["label_img"], b["mask"])
+    return sum(torch.mean(torch.sum((uvd - b["uvd"]) ** 2, dim=2)) for (_, _, uvd) in res)
+# (1) the averaged shard gradient == the single-GPU gradient of the big batch (instance norm: samples are independent, losses are batch means)
+m = model(5 + rank)                          # different initial weights per rank: the broadcast must fix that
+DataParallel(m)
+ref = model(5)                               # rank 0's weights, no data parallelism
+assert torch.equal(ref.flat_parameters(), m.flat_parameters()), "broadcast did not deliver rank 0's parameters"
+loss_of(ref, big).backward()
+loss_of(m, shard).backward()
+torch.cuda.synchronize()
+g, gr = m.flat_grad().double(), ref.flat_grad().double()
+rel = float((g - gr).norm() / gr.norm())
+# (2) four AdamW steps on the native train step (per-segment all-reduce beside the backward, 1 / world in the optimizer kernel): all
+# ranks hold identical parameters afterwards, bit for bit
+m2 = model(9 + rank).set_precision("bf16")
+DataParallel(m2)
+ts = TrainStep(m2, opt="adam", lr=1e-3)
+for it in range(4):
+    b = make_pose_batch(Bs, J, S, seed=400 + 10 * it + rank, device=dev)
+    ts(b["img"], b["label_img"], b["mask"], b["uvd"])
+torch.cuda.synchronize()
+gathered = [torch.empty_like(m2.flat_parameters()) for _ in range(world)]
+dist.all_gather(gathered, m2.flat_parameters())
+same = all(torch.equal(gathered[0], t) for t in gathered)
+print("RESULT", rank, rel, same, flush=True)
+dist.destroy_process_group()
+""" % ROOT
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: the first multi-rank RCCL run (the driver's 8-GPU node; a 1-GPU box skips)")
+def test_rccl_two_ranks_gradient_equals_the_big_batch_gradient(tmp_path):
+    """TWO real RCCL ranks on two GPUs (fresh child processes; skipped on the 1-GPU boxes of this pool): (1) the gradient the
+    data-parallel path leaves on every rank -- all-reduce(SUM) of the per-segment slices over RCCL, divided by the world size -- equals
+    the single-GPU gradient of the global batch to 1e-6 relative L2 (fp32 engine, instance norm); (2) after four AdamW steps of the
+    native train step on different shards every rank holds bit-identical parameters; (3) bench.py --gpus 2 prints one line with
+    parallelism dp2 and the RCCL fields."""
+    script = tmp_path / "worker_rccl2.py"
+    script.write_text(WORKER_RCCL2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29655", str(script)], capture_output=True, text=True, env=env, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(lines) == 2, (r.stdout[-2000:], r.stderr[-3000:])
+    for l in lines:
+        _, rank, rel, same = l.split()
+        assert float(rel) < 1e-6, l
+        assert same == "True", l
+    import json
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--accuracy-steps", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+    out = [l for l in b.stdout.splitlines() if l.startswith("{")]
+    assert b.returncode == 0 and len(out) == 1, (b.stdout[-2000:], b.stderr[-2000:])
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64
+    assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "nccl" and len(d["rccl"]["allreduce_bytes_per_segment"]) == 3

@@ -684,3 +684,77 @@ def test_conv_pair_launch(B, H, W):
         (ya2, pa2), (yb2, pb2), _ = K.conv_fwd_stats_pair(xa, wa, xb, wb, C, 3, bias_a=ba, bias_b=bb, norm_a=na, norm_b=nb)
         assert torch.equal(ya, ya2) and torch.equal(yb, yb2)
         assert torch.equal(pa, pa2) and torch.equal(pb, pb2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(3, 64, 64, 128), (2, 8, 32, 32), (5, 64, 64, 32), (2, 16, 64, 64)])
+def test_conv_dgrad_pair_launch(B, H, W, Cin):
+    """pwr_conv_dgrad_stats_pair: the two heads' data gradients of one depth (kind-1 packs, norm-backward sums in the epilogue; 128 <- 128
+    for the middle convs, 128 <- 32 / 64 for the last conv's padded J channels) in ONE launch: gradients and slab rows bit-identical to
+    the two single launches."""
+    from pixelwiseregression_amd import kernels as K
+    C = 128
+    dya, dyb = nhwc(rnd(B, Cin, H, W, seed=41), torch.bfloat16), nhwc(rnd(B, Cin, H, W, seed=42), torch.bfloat16)
+    wa = K.pack_conv(rnd(Cin, C, 3, 3, seed=43, scale=(9 * C) ** -0.5).float().to(DEV), 1, K.BF16)
+    wb = K.pack_conv(rnd(Cin, C, 3, 3, seed=44, scale=(9 * C) ** -0.5).float().to(DEV), 1, K.BF16)
+    ya, yb = nhwc(rnd(B, C, H, W, seed=45), torch.bfloat16), nhwc(rnd(B, C, H, W, seed=46), torch.bfloat16)
+    sta = K.norm_stats(ya, (1 + 0.2 * rnd(C, seed=47)).float().to(DEV), (0.2 * rnd(C, seed=48)).float().to(DEV))
+    stb = K.norm_stats(yb, (1 + 0.2 * rnd(C, seed=49)).float().to(DEV), (0.2 * rnd(C, seed=50)).float().to(DEV))
+    xa, pa, _ = K.conv_fwd_stats(dya, wa, C, 3, 1, relu_in=False, nb_y=ya, nb_state=sta)
+    xb, pb, _ = K.conv_fwd_stats(dyb, wb, C, 3, 1, relu_in=False, nb_y=yb, nb_state=stb)
+    (xa2, pa2), (xb2, pb2), _ = K.conv_dgrad_stats_pair(dya, wa, ya, sta, dyb, wb, yb, stb, C, 3)
+    assert float(xa.float().abs().max()) > 0
+    assert torch.equal(xa, xa2) and torch.equal(xb, xb2)
+    assert torch.equal(pa, pa2) and torch.equal(pb, pb2)
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 85), (5, 64, 64, 128, 128, 37), (3, 20, 96, 128, 128, 24), (2, 8, 32, 128, 256, 3), (2, 32, 32, 256, 128, 8),
+                                  (32, 64, 64, 128, 128, 85)])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_wgrad3_wave_specialised(case, prologue):
+    """conv_wgrad_ws.hip (whole 128-channel tiles: 4 MFMA waves + 4 loader waves per workgroup, the operand's norm + ReLU applied in LDS by
+    the loader waves): against F.conv2d's float64 weight gradient of the normalised, bf16-rounded operand -- splits that straddle a sample
+    (the per-sample norm state changes inside a split), image borders, a ragged last split, several channel tiles -- and bit-identical over
+    repeated launches; with an identity norm state the in-LDS pass gives the bits of the no-norm form."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, splits = case
+    x, dy = rnd(B, Cin, H, W, seed=23), rnd(B, Cout, H, W, seed=24)
+    xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
+    st = None
+    xin = q(x, torch.bfloat16)
+    if prologue:
+        gamma, beta = (1 + 0.3 * rnd(Cin, seed=25)).float().to(DEV), (0.3 * rnd(Cin, seed=26)).float().to(DEV)
+        st = K.norm_stats(xd, gamma, beta, mode=0)
+        mean, scale, shift = (st[i].double().cpu()[:, :, None, None] for i in (0, 2, 3))
+        xin = q(torch.relu((xin - mean) * scale + shift), torch.bfloat16)
+    outs = [K.conv_wgrad(xd, dyd, Cout, 3, 1, norm=st, relu_in=True, splits=splits).clone() for _ in range(6)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), float((outs[0] - o).abs().max())
+    if B <= 8:
+        w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, w, None, padding=1).backward(q(dy, torch.bfloat16))
+        assert_close(outs[0].double().cpu(), w.grad, 1.5e-2, "wave-specialised wgrad %s" % (case,))
+    if not prologue:
+        ident = torch.zeros(4, B, Cin, device=DEV)
+        ident[1:3] = 1.0                                    # [mean, rstd, scale, beta] = [0, 1, 1, 0]
+        assert torch.equal(outs[0], K.conv_wgrad(xd, dyd, Cout, 3, 1, norm=ident, relu_in=False, splits=splits))
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 42), (3, 20, 96, 128, 128, 12), (2, 8, 32, 256, 128, 2)])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_wgrad_pair_launch(case, prologue):
+    """pwr_conv_wgrad_pair: the two heads' weight gradients of one depth in ONE launch + ONE reduce: bit-identical to two single calls with
+    the same split count; without a norm both jobs may read the same x (the heads' first convs both read the hourglass output)."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, splits = case
+    xa, xb = nhwc(rnd(B, Cin, H, W, seed=51), torch.bfloat16), nhwc(rnd(B, Cin, H, W, seed=52), torch.bfloat16)
+    dya, dyb = nhwc(rnd(B, Cout, H, W, seed=53), torch.bfloat16), nhwc(rnd(B, Cout, H, W, seed=54), torch.bfloat16)
+    sta = stb = None
+    if prologue:
+        sta = K.norm_stats(xa, (1 + 0.3 * rnd(Cin, seed=55)).float().to(DEV), (0.3 * rnd(Cin, seed=56)).float().to(DEV))
+        stb = K.norm_stats(xb, (1 + 0.3 * rnd(Cin, seed=57)).float().to(DEV), (0.3 * rnd(Cin, seed=58)).float().to(DEV))
+    else:
+        xb = xa
+    da = K.conv_wgrad(xa, dya, Cout, 3, 1, norm=sta, splits=splits)
+    db = K.conv_wgrad(xb, dyb, Cout, 3, 1, norm=stb, splits=splits)
+    pa, pb = K.conv_wgrad_pair(xa, dya, xb, dyb, norm_a=sta, norm_b=stb, splits=splits)
+    assert float(da.abs().max()) > 0 and torch.equal(da, pa) and torch.equal(db, pb)

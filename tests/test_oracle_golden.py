@@ -184,3 +184,21 @@ def test_oracle_reproduces_reference_written_checkpoint(golden_dir):
         np.testing.assert_allclose(uvd.numpy(), g["s%d_uvd" % s], atol=1e-5)
         np.testing.assert_allclose(p.numpy(), g["s%d_p" % s], atol=1e-5)
         np.testing.assert_allclose(D.numpy(), g["s%d_D" % s], atol=1e-4)
+
+
+def test_oracle_on_trained_c2_fixture(golden_dir):
+    """tests/golden/trained_c2.npz: BASELINE C2's architecture with TRAINED weights (600 AdamW steps on rendered hands, 11.8 mm), outputs
+    and loss gradient written by the REFERENCE in float64 (oracle/gen_golden.py trained).  On this well-conditioned network the
+    reference's own fp32 run is 3.7e-7 from its float64 run; the oracle in float64 must reproduce the float64 outputs to 1e-9, in fp32
+    to 1e-5 -- the fixture the bf16 engine is held to in tests/test_trained_fixture_gpu.py."""
+    g = _load(golden_dir, "trained_c2.npz")
+    cfg = model_ref.RefConfig(14, 2, 64, 128, 4, 3, "instance", "softmax")
+    for dt, tol in ((torch.float64, 1e-9), (torch.float32, 1e-5)):
+        sd = {k[3:]: (torch.from_numpy(g[k]).to(dt) if g[k].dtype.kind == "f" else torch.from_numpy(g[k])) for k in g.files if k.startswith("sd_")}
+        with torch.no_grad():
+            res = model_ref.forward(sd, cfg, torch.from_numpy(g["in_img"][:2]).to(dt), torch.from_numpy(g["in_label_img"][:2]).to(dt),
+                                    torch.from_numpy(g["in_mask"][:2]).to(dt), training=False)
+        for s, (p, D, uvd) in enumerate(res):
+            assert np.abs(uvd.double().numpy() - g["f64_s%d_uvd" % s][:2]).max() <= tol
+            assert np.abs(p.double().numpy() - g["f64_s%d_p" % s]).max() <= max(tol, 1e-7)       # (stored in fp32)
+            assert np.abs(D.double().numpy() - g["f64_s%d_D" % s]).max() <= max(10 * tol, 1e-6)

@@ -1,0 +1,115 @@
+"""The bf16 (throughput) engine -- the configuration bench.py reports -- pinned to the REFERENCE on a well-conditioned network.
+
+tests/golden/trained_c2.npz holds BASELINE C2's architecture (/root/reference/model.py:154-210: 14 joints, features 128, level 4,
+stage 2, instance norm) with TRAINED weights (tools/make_trained_weights.py: 600 AdamW steps of the reference's loop,
+train.py:158-212, on rendered synthetic hands; 11.8 mm mean joint error), four held-out frames, and what the REFERENCE computes on
+them in float64: outputs of both stages and the gradient of the train.py:197-205 loss (oracle/gen_golden.py trained).  On this
+network the reference's own fp32 run is 3.7e-7 away from its float64 run, so the fixture measures the engine's arithmetic, not the
+network's conditioning (on an untrained network the soft-argmax amplifies bf16 rounding to O(0.1): test_engine_gpu.py).
+
+Bounds are ABSOLUTE; measured values (MI355X, round 4) are quoted beside each.  Stock bf16 autocast through the library convs
+(tests/aten_reference.py) is printed as information only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(golden_dir):
+    from pixelwiseregression_amd import PixelwiseRegression
+    g = np.load(os.path.join(golden_dir, "trained_c2.npz"))
+    m = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, kernel_size=3, norm_method="instance", heatmap_method="softmax")
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
+    batch = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith("in_")}
+    return g, m.to(DEV), batch
+
+
+def _errors(res, g):
+    out = {}
+    for s, (p, D, uvd) in enumerate(res):
+        out["uvd%d" % s] = float(np.abs(uvd.detach().double().cpu().numpy() - g["f64_s%d_uvd" % s]).max())
+        pe = p.detach().double().cpu().numpy()[:2] - g["f64_s%d_p" % s]
+        out["p_l1_%d" % s] = float(np.abs(pe).sum(axis=(2, 3)).max())            # L1 distance of the heat maps as distributions (0 .. 2)
+        out["p_max_%d" % s] = float(np.abs(pe).max())
+        # the depth-head map enters the result only where the heat map has mass: compare it weighted by the reference's heat map
+        De = np.abs(D.detach().double().cpu().numpy()[:2] - g["f64_s%d_D" % s])
+        out["D_w_%d" % s] = float((De * g["f64_s%d_p" % s]).sum(axis=(2, 3)).max())
+        out["argmax_same_%d" % s] = float((p.detach().reshape(4, 14, -1).argmax(dim=2).cpu().numpy() == g["f64_s%d_p_argmax" % s]).mean())
+    return out
+
+
+def test_fp32_engine_on_the_trained_fixture(golden_dir):
+    """Parity mode on the trained network: 1e-4 like everywhere else (north_star), without an escape hatch.  Measured: uvd 3.5e-7, heat maps
+    2.5e-8, weighted depth maps 3.9e-7 -- what the reference's own fp32 run is away from its float64 run (3.7e-7)."""
+    g, m, b = _load(golden_dir)
+    m.set_precision("fp32").eval()
+    with torch.no_grad():
+        e = _errors(m(b["img"], b["label_img"], b["mask"]), g)
+    print("fp32 engine vs the reference in float64:", e)
+    for s in range(2):
+        assert e["uvd%d" % s] <= 1e-4 and e["p_max_%d" % s] <= 1e-4 and e["D_w_%d" % s] <= 1e-4, e
+
+
+def test_bf16_engine_outputs_against_the_reference_in_float64(golden_dir):
+    """The benchmarked path.  uvd is in crop units (the crop spans [-0.5, 0.5]; one heat-map pixel = 1/63 = 1.6e-2; 1e-2 = 1.5 mm at the
+    150 mm cube).  Measured on MI355X (round 4), stage 0 / stage 1: uvd 9.8e-3 / 7.7e-3, heat-map L1 distance 0.067 / 0.090, max |p - p_ref|
+    7.5e-4 / 6.7e-4, heat-map-weighted depth-map error 1.4e-2 / 1.0e-2 (stock bf16 autocast through the library convs: 1.2e-2 / 7.7e-3,
+    0.090 / 0.066, 7.3e-4 / 6.9e-4, 1.0e-2 / 9.5e-3 -- the same distance from float64).  Bounds, absolute: uvd 1.5e-2 per coordinate (one
+    heat-map pixel), L1 0.15, max |p - p_ref| 2e-3, weighted depth-map error 2.5e-2; the mean 3D joint error moves by < 1 mm.  (The arg-max
+    PIXEL of a trained heat map is not a stable statistic -- the maps are broad, neighbouring pixels tie to three digits, and bf16 moves
+    it in 16 - 27 % of the maps for the engine and for stock autocast alike -- it is printed, not asserted.)"""
+    g, m, b = _load(golden_dir)
+    m.set_precision("bf16").eval()
+    with torch.no_grad():
+        res = m(b["img"], b["label_img"], b["mask"])
+    e = _errors(res, g)
+    print("bf16 engine vs the reference in float64:", e)
+    try:
+        from aten_reference import aten_forward
+        with torch.no_grad():
+            print("stock bf16 autocast (library convs), information only:", _errors(aten_forward(m, b["img"], b["label_img"], b["mask"]), g))
+    except Exception as ex:       # the yardstick must never fail the parity test
+        print("autocast yardstick unavailable:", ex)
+    for s in range(2):
+        assert e["uvd%d" % s] <= 1.5e-2, e
+        assert e["p_l1_%d" % s] <= 0.15 and e["p_max_%d" % s] <= 2e-3, e
+        assert e["D_w_%d" % s] <= 2.5e-2, e
+    # the metric of record (train.py:254-285) moves by less than a millimetre
+    from pixelwiseregression_amd.synthetic import joint_error_mm
+    mm16 = joint_error_mm(res[-1][2], b).mean()
+    mm64 = joint_error_mm(torch.from_numpy(g["f64_s1_uvd"]).float(), b).mean()
+    print("mean joint error on the held-out frames: bf16 engine %.3f mm, reference float64 %.3f mm" % (mm16, mm64))
+    assert abs(mm16 - mm64) < 1.0
+
+
+@pytest.mark.parametrize("prec,tol_flat,tol_tensor", [("fp32", 2e-4, 2e-3), ("bf16", 6e-2, 0.25)])
+def test_engine_gradient_against_the_reference_in_float64(golden_dir, prec, tol_flat, tol_tensor):
+    """Backward on the trained network (training mode, loss of train.py:197-205 with alpha = 1) against the reference's float64
+    gradient (stored rounded to bf16: 3 digits).  Relative L2 error of the flat gradient, and per tensor relative to the tensor's own
+    norm for every tensor that carries more than 1e-3 of the gradient's norm (biases in front of an InstanceNorm have an exactly
+    zero gradient: rounding noise only)."""
+    g, m, b = _load(golden_dir)
+    m.set_precision(prec).train()
+    res = m(b["img"], b["label_img"], b["mask"])
+    loss = sum(torch.mean(torch.sum((uvd - b["uvd"]) ** 2, dim=2)) for (_, _, uvd) in res)
+    assert abs(loss.item() - float(g["f64_loss"])) <= (1e-5 if prec == "fp32" else 5e-3) * max(1.0, float(g["f64_loss"])), (loss.item(), float(g["f64_loss"]))
+    loss.backward()
+    ref = torch.from_numpy((g["f64_grad_bf16bits"].astype(np.uint32) << 16).view(np.float32)).double()
+    got = torch.cat([p.grad.detach().flatten() for _, p in m.named_parameters()]).double().cpu()
+    assert [k for k, _ in m.named_parameters()] == list(g["grad_keys"])
+    rel = float((got - ref).norm() / ref.norm())
+    cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
+    worst, o = ("", 0.0), 0
+    for k, n, nrm in zip(g["grad_keys"], g["grad_numel"], g["f64_grad_norms"]):
+        if nrm > 1e-3 * float(ref.norm()):
+            r = float((got[o:o + n] - ref[o:o + n]).norm() / nrm)
+            if r > worst[1]:
+                worst = (str(k), r)
+        o += int(n)
+    print("%s engine gradient vs the reference in float64: rel L2 %.3e, cosine %.6f, worst tensor %s %.3e" % (prec, rel, cos, worst[0], worst[1]))
+    assert rel <= tol_flat, (rel, cos)
+    assert worst[1] <= tol_tensor, worst
