@@ -25,7 +25,8 @@
 //   MFMA waves    read stage s (the first fragments were read ahead during step s - 1), 24 MFMAs each
 //   loader waves  issue the DMA of step s + 5 into the stage read during step s - 1; normalise the tile of step s + 2 in place;
 //                 wait until their own pieces of step s + 3 have landed (counted vmcnt: steps s + 4, s + 5 stay in flight)
-// so a DMA has three K steps to land, a tile is normalised one full step before it is read, and a stage is overwritten only after
+// so a DMA has three K steps to land (a ring of 8 stages -- five steps to land -- measured no faster in the step and 3 - 7 % slower
+// isolated: the loop is not latency-bound), a tile is normalised one full step before it is read, and a stage is overwritten only after
 // a barrier every MFMA wave reached with its reads retired.
 #include "conv_common.h"
 #include "pwr.h"
@@ -41,7 +42,10 @@ constexpr int KP = 32, XROWS = KP + 2, RB = 256;                 // K step, stag
 constexpr int XCH = (XROWS * RB + 1023) / 1024, YCH = KP * RB / 1024, NCH = XCH + YCH;     // 1-KiB DMA pieces: 9 + 8
 constexpr int NLW = 4, NCW = (NCH + NLW - 1) / NLW;              // loader waves; pieces per loader wave and step (5, three of them padding)
 constexpr int XBYTES = XCH * 1024, STAGE = NCH * 1024;
-constexpr int NS = 6, D = NS - 1;                                // ring stages; a step's pieces are issued D steps ahead
+#ifndef PWR_WS_NS
+#define PWR_WS_NS 6
+#endif
+constexpr int NS = PWR_WS_NS, D = NS - 1;                        // ring stages; a step's pieces are issued D steps ahead
 constexpr int MAXSB = 8;                                         // norm states of at most this many samples per split
 constexpr int STATE_BYTES = MAXSB * 3 * 128 * 4;
 constexpr int LDS_BYTES = NS * STAGE + STATE_BYTES;
@@ -156,13 +160,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
     // all but this wave's pieces of the `k` most recently issued steps have landed, and every LDS access of the wave has retired
     auto landed_but = [&](int k) {
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      static_assert(D - 3 <= 5 && 5 * NCW < 64, "wait cases below; vmcnt is a 6-bit counter");
       if (five) {
-        if (k >= 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * NCW));
+        if (k >= 5) __builtin_amdgcn_s_waitcnt(vmwait(5 * NCW));
+        else if (k == 4) __builtin_amdgcn_s_waitcnt(vmwait(4 * NCW));
+        else if (k == 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * NCW));
         else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * NCW));
         else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NCW));
         else __builtin_amdgcn_s_waitcnt(vmwait(0));
       } else {
-        if (k >= 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * (NCW - 1)));
+        if (k >= 5) __builtin_amdgcn_s_waitcnt(vmwait(5 * (NCW - 1)));
+        else if (k == 4) __builtin_amdgcn_s_waitcnt(vmwait(4 * (NCW - 1)));
+        else if (k == 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * (NCW - 1)));
         else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * (NCW - 1)));
         else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NCW - 1));
         else __builtin_amdgcn_s_waitcnt(vmwait(0));

@@ -86,30 +86,89 @@ def test_bf16_engine_outputs_against_the_reference_in_float64(golden_dir):
     assert abs(mm16 - mm64) < 1.0
 
 
-@pytest.mark.parametrize("prec,tol_flat,tol_tensor", [("fp32", 2e-4, 2e-3), ("bf16", 6e-2, 0.25)])
-def test_engine_gradient_against_the_reference_in_float64(golden_dir, prec, tol_flat, tol_tensor):
-    """Backward on the trained network (training mode, loss of train.py:197-205 with alpha = 1) against the reference's float64
-    gradient (stored rounded to bf16: 3 digits).  Relative L2 error of the flat gradient, and per tensor relative to the tensor's own
-    norm for every tensor that carries more than 1e-3 of the gradient's norm (biases in front of an InstanceNorm have an exactly
-    zero gradient: rounding noise only)."""
+def _functional(res, g):
+    up = lambda a: torch.from_numpy(np.kron(a, np.ones((8, 8), dtype=np.float32))).to(DEV)
+    return sum((u_ * torch.from_numpy(g["GU%d" % s_]).to(DEV)).sum() + (p_ * up(g["GH%d" % s_])).sum() + (D_ * up(g["GD%d" % s_])).sum()
+               for s_, (p_, D_, u_) in enumerate(res))
+
+
+def _flat_grad(m):
+    return torch.cat([p.grad.detach().flatten() for _, p in m.named_parameters()]).double().cpu()
+
+
+def _group_errors(got, ref, g):
+    """relative L2 error per parameter group: stem, and per stage its input conv / hourglass / plane head / depth head"""
+    groups, o = {}, 0
+    for k, n in zip(g["grad_keys"], g["grad_numel"]):
+        k, n = str(k), int(n)
+        grp = "stem" if k.startswith("conv.") else ".".join(k.split(".")[:3])
+        d = groups.setdefault(grp, [0.0, 0.0])
+        d[0] += float((got[o:o + n] - ref[o:o + n]).pow(2).sum())
+        d[1] += float(ref[o:o + n].pow(2).sum())
+        o += n
+    return {k: (v[0] / v[1]) ** 0.5 for k, v in groups.items()}
+
+
+def test_fp32_engine_gradient_against_the_reference_in_float64(golden_dir):
+    """Backward on the trained network (training mode) against the reference's float64 gradient -- of a fixed LINEAR functional of all
+    outputs, L = sum_s <uvd_s, GU_s> + <p_s, GH_s> + <D_s, GD_s> with seeded random weights stored in the fixture (at a trained point the
+    gradient of the training loss, 2 (uvd - target) / (B J), is as small as the rounding error of uvd, so it measures the forward noise,
+    not the backward kernels).  The whole flat gradient is stored rounded to bf16 (it resolves 2e-3, and the fp32 engine measures 2.0e-3
+    against it: the rounding of the fixture itself): 3e-3 on the flat gradient and 6e-3 per parameter group.  Twelve tensors (stem, heads,
+    innermost hourglass level, stage input, soft-max temperatures, a norm's affine pair) are stored in full fp32: 5e-3 per tensor relative
+    to the tensor's norm (measured: 5e-6 ... 6e-4; 2.2e-3 on the stem's first conv, the last tensor of the backward pass)."""
     g, m, b = _load(golden_dir)
-    m.set_precision(prec).train()
-    res = m(b["img"], b["label_img"], b["mask"])
-    loss = sum(torch.mean(torch.sum((uvd - b["uvd"]) ** 2, dim=2)) for (_, _, uvd) in res)
-    assert abs(loss.item() - float(g["f64_loss"])) <= (1e-5 if prec == "fp32" else 5e-3) * max(1.0, float(g["f64_loss"])), (loss.item(), float(g["f64_loss"]))
+    m.set_precision("fp32").train()
+    loss = _functional(m(b["img"], b["label_img"], b["mask"]), g)
+    assert abs(loss.item() - float(g["f64_loss"])) <= 1e-4 * max(1.0, abs(float(g["f64_loss"]))), (loss.item(), float(g["f64_loss"]))
     loss.backward()
     ref = torch.from_numpy((g["f64_grad_bf16bits"].astype(np.uint32) << 16).view(np.float32)).double()
-    got = torch.cat([p.grad.detach().flatten() for _, p in m.named_parameters()]).double().cpu()
+    got = _flat_grad(m)
     assert [k for k, _ in m.named_parameters()] == list(g["grad_keys"])
     rel = float((got - ref).norm() / ref.norm())
-    cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
-    worst, o = ("", 0.0), 0
-    for k, n, nrm in zip(g["grad_keys"], g["grad_numel"], g["f64_grad_norms"]):
-        if nrm > 1e-3 * float(ref.norm()):
-            r = float((got[o:o + n] - ref[o:o + n]).norm() / nrm)
-            if r > worst[1]:
-                worst = (str(k), r)
-        o += int(n)
-    print("%s engine gradient vs the reference in float64: rel L2 %.3e, cosine %.6f, worst tensor %s %.3e" % (prec, rel, cos, worst[0], worst[1]))
-    assert rel <= tol_flat, (rel, cos)
-    assert worst[1] <= tol_tensor, worst
+    grp = _group_errors(got, ref, g)
+    print("fp32 engine gradient vs the reference in float64: rel L2 %.3e; by group %s" % (rel, {k: "%.1e" % v for k, v in grp.items()}))
+    assert rel <= 3e-3 and max(grp.values()) <= 6e-3, (rel, grp)
+    grads = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+    sub = {}
+    for key in g.files:
+        if key.startswith("f64_grad_") and key[9:] in grads:
+            r = torch.from_numpy(g[key]).double()
+            if float(r.norm()) > 2e-5 * float(ref.norm()):            # (skip tensors whose true gradient is zero: rounding noise only)
+                sub[key[9:]] = float((grads[key[9:]] - r).norm() / r.norm())
+    print("fp32 engine, tensors stored in fp32: %s" % {k: "%.2e" % v for k, v in sub.items()})
+    assert len(sub) >= 8 and max(sub.values()) <= 5e-3, sub
+
+
+def test_bf16_engine_gradient_against_the_reference_in_float64(golden_dir):
+    """The same functional through the bf16 engine.  What bf16 STORAGE of the activation gradients does to this network is large and is
+    not a property of the kernels: every InstanceNorm backward subtracts the channel mean of the incoming gradient, a cancellation that
+    turns the 2^-9 rounding of the bf16 gradient maps into a far larger relative error of what is left -- measured (MI355X, round 4),
+    relative L2 error of the gradient by parameter group, walking backwards: last stage's depth head 2.5 %, plane head 7 %, its hourglass
+    60 %, everything below about 100 % (cosine of the flat gradient 0.46) -- for the engine and for stock bf16 autocast through the library
+    convs alike (2.6 %, 8 %, 60 %, ~105 %; cosine 0.49), and bit-identically for the round-3 and the round-4 backward paths.  (It averages out
+    over samples and steps: the bf16 engine trains to the same error as the fp32 engine, tests/test_train_step_gpu.py.)
+    Asserted: ABSOLUTE bounds where the gradient has passed through the heads' convs only -- the last stage's depth head <= 5 %, plane
+    head <= 12 % of the group's norm: the bf16 weight- and data-gradient kernels of the hot layers against float64 -- and, for the
+    groups below, no further from float64 than 1.15 x stock autocast on the same GPU."""
+    g, m, b = _load(golden_dir)
+    ref = torch.from_numpy((g["f64_grad_bf16bits"].astype(np.uint32) << 16).view(np.float32)).double()
+    m.set_precision("bf16").train()
+    loss = _functional(m(b["img"], b["label_img"], b["mask"]), g)
+    assert abs(loss.item() - float(g["f64_loss"])) <= 2e-2 * max(1.0, abs(float(g["f64_loss"]))), (loss.item(), float(g["f64_loss"]))
+    loss.backward()
+    got = _flat_grad(m)
+    grp = _group_errors(got, ref, g)
+    rel, cos = float((got - ref).norm() / ref.norm()), float(torch.dot(got, ref) / (got.norm() * ref.norm()))
+    print("bf16 engine gradient vs the reference in float64: rel L2 %.3f, cosine %.4f; by group %s" % (rel, cos, {k: "%.3f" % v for k, v in grp.items()}))
+    assert grp["stages.1.depth_regression"] <= 0.05 and grp["stages.1.plane_regression"] <= 0.12, grp
+    from aten_reference import aten_forward
+    m.zero_grad(set_to_none=True)
+    _functional(aten_forward(m, b["img"], b["label_img"], b["mask"]), g).backward()
+    got_a = _flat_grad(m)
+    grp_a = _group_errors(got_a, ref, g)
+    rel_a = float((got_a - ref).norm() / ref.norm())
+    print("stock bf16 autocast: rel L2 %.3f; by group %s" % (rel_a, {k: "%.3f" % v for k, v in grp_a.items()}))
+    assert rel <= 1.15 * rel_a, (rel, rel_a)
+    for k in grp:
+        assert grp[k] <= 1.15 * grp_a[k] + 0.01, (k, grp[k], grp_a[k])
