@@ -283,6 +283,11 @@ long long pwr_engine_generation(void* engine);
  * segment `seg`; segment 0 first zeroes grads[0:n_grad_floats].  Parameter gradients are written (not
  * accumulated) into the bound flat gradient buffer, in the layout of the parameters. */
 int pwr_engine_backward(void* engine, const void* const* gouts, int seg, long long n_grad_floats, void* stream);
+/* The backward segments leave `stream` with the DATA gradients in order, but the parameter-gradient kernels run on the engine's side
+ * streams; `stream` waits for them after the LAST segment only.  A consumer of an earlier segment's parameter gradients (the all-reduce
+ * of that segment's slice in the data-parallel mode, ddp.py) calls this right after the segment was issued: `waiter` then waits for
+ * everything issued so far on `chain_stream` and on the side streams. */
+int pwr_engine_wait_segment(void* engine, void* chain_stream, void* waiter);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-step tail (train.py:139-142, 195-208) on the flat fp32 buffers.

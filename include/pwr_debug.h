@@ -13,8 +13,8 @@ int pwr_debug_copy_if(const int* flag, const void* src, void* dst, size_t bytes,
 void pwr_debug_set_stamps(void* stamps);
 /* arena layout as text lines "offset bytes tag"; returns the size needed */
 size_t pwr_engine_layout(void* engine, char* buf, size_t cap);
-/* 1 (the product's only mode): every backward segment ends with its parameter gradients complete on the stream; 0: only the last
- * one does (1 % faster on one GPU; the configuration under which round 1's rare non-reproducible step occurred) */
+/* 0 (the product's mode since round 4): the caller's stream waits for the side streams after the last segment only; 1: after every
+ * segment (rounds 2 - 3) */
 void pwr_engine_set_join(void* engine, int each_segment);
 #ifdef __cplusplus
 }

@@ -214,7 +214,7 @@ struct Engine {
   std::string err;
   long long generation = 0;
   Ctx ctx;
-  bool join_each_segment = true;
+  bool join_each_segment = PWR_DBG_ENV("PWR_JOIN_EACH", 0) != 0;      // (debug build: PWR_JOIN_EACH=1 makes the caller's stream wait for the side streams after EVERY segment, rounds 2 - 3)
 
   // arena layout record (debugging aid: pwr_engine_layout)
   struct AllocRec { size_t off, bytes; std::string tag; };
@@ -1175,6 +1175,31 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
 }
 extern "C" long long pwr_engine_generation(void* h) { return ((Engine*)h)->generation; }
 
+// Make `waiter` wait until everything the backward segments issued so far have written is complete: the data-gradient chain on
+// `chain_stream` (the stream the segments were issued on) AND the parameter-gradient kernels on the engine's side streams.  Called by the
+// data-parallel mode right after segment k has been issued, for the stream its all-reduce of that segment's gradient slice runs on.
+extern "C" int pwr_engine_wait_segment(void* h, void* chain_stream, void* waiter) {
+  Engine* e = (Engine*)h;
+  Ctx& c = e->ctx;
+  if (!c.attached) return 0;            // (no backward has run yet)
+  hipError_t er = hipSuccess;
+  for (int k = 0; c.use_side && k < c.n_side && er == hipSuccess; ++k) {
+    er = hipEventRecord(c.ev_join[k], c.side[k]);
+    if (er == hipSuccess) er = hipStreamWaitEvent((hipStream_t)waiter, c.ev_join[k], 0);
+  }
+  if (er == hipSuccess && chain_stream != waiter) {
+    hipEvent_t ev = c.n_fork ? c.ev_fork[c.fork_rr] : nullptr;
+    if (ev) {
+      c.fork_rr = (c.fork_rr + 1) % c.n_fork;
+      er = hipEventRecord(ev, (hipStream_t)chain_stream);
+      if (er == hipSuccess) er = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    } else {
+      er = hipStreamSynchronize((hipStream_t)chain_stream);      // (no side streams, no event pool: rare debug configuration)
+    }
+  }
+  return (int)er;
+}
+
 // gouts: host array of 3*stage device pointers (NULL = zero gradient).  Runs backward segment `seg`
 // (0 = last stage ... num_segments-1 = stem); segment 0 also zeroes the flat gradient buffer first.
 extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, long long n_grad_floats, void* stream) {
@@ -1199,9 +1224,11 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
       rc = ops[i](c);
       if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
     }
-    // join: the parameter gradients of this segment are complete before anything later on the stream (the caller all-reduces each
-    // segment's slice as it finishes).  Joining once after the last segment is 1 % faster on one GPU; it is the configuration under
-    // which round 1's rare non-reproducible step occurred and exists in the debug build only (pwr_engine_set_join, pwr_debug.h).
+    // join: the caller's stream waits for the side streams after the LAST segment only (the optimizer, and the next forward, need every
+    // parameter gradient).  Whoever needs an earlier segment's gradients complete -- the data-parallel all-reduce of that segment's
+    // slice -- makes ITS stream wait with pwr_engine_wait_segment(); the chain does not stop for it (round 4: a join per segment cost
+    // 0.06 - 0.14 ms of a 5.8 ms step; it was kept in rounds 2 - 3 beside the fix of round 1's non-reproducible step -- the packed-f32
+    // form, DESIGN.md section 2 -- and measured then at 1 %).
     const bool join_now = e->join_each_segment || seg + 1 == (int)e->bwd.size();
     for (int k = 0; join_now && c.use_side && k < c.n_side; ++k) {
       hipEventRecord(c.ev_join[k], c.side[k]);

@@ -30,6 +30,7 @@ class DataParallel:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.works = []
+        self._comm = None
         self.ranges = model.segment_ranges()
         if broadcast:
             dist.broadcast(model.flat_parameters(), src=0, group=process_group)
@@ -37,13 +38,28 @@ class DataParallel:
                 dist.broadcast(model._flat_buf, src=0, group=process_group)
         model._ddp = self
 
-    def segment_done(self, model, seg, nseg):
+    def segment_done(self, model, seg, nseg, plan=None):
+        """Called right after backward segment `seg` has been issued.  The engine's parameter-gradient kernels run on side streams that
+        the caller's stream joins after the LAST segment only, so the all-reduce of an earlier segment's slice is issued from a
+        communication stream that pwr_engine_wait_segment() has made wait for the chain and the side streams: the collective starts when
+        that segment's gradients are complete, and the next segment's backward does not stop for it."""
         if self.mode == "end":
             if seg == nseg - 1:
                 self.works.append(dist.all_reduce(model.flat_grad(), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         b, e = self.ranges[seg]
-        self.works.append(dist.all_reduce(model.flat_grad()[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        grad = model.flat_grad()
+        if plan is None or not grad.is_cuda or seg == nseg - 1:
+            # (the last segment ends with everything joined on the caller's stream; CPU stand-ins of the tests have no streams)
+            self.works.append(dist.all_reduce(grad[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        from . import _lib
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=grad.device)
+        cur = torch.cuda.current_stream(grad.device)
+        _lib.check(_lib.lib().pwr_engine_wait_segment(plan.h, cur.cuda_stream, self._comm.cuda_stream), "pwr_engine_wait_segment")
+        with torch.cuda.stream(self._comm):
+            self.works.append(dist.all_reduce(grad[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
         """Block the current stream until every segment's all-reduce (SUM) has finished; the caller scales by 1/world."""

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-# Side streams (parameter-gradient kernels) are joined at the end of EVERY backward segment (joining once is a
+# Side streams (parameter-gradient kernels) are joined into the caller's stream after the LAST backward segment (round 4; a join per segment is a
 # debug-build experiment, include/pwr_debug.h).
 
 
@@ -170,7 +170,7 @@ class _EngineFn(torch.autograd.Function):
         for seg in range(plan.n_seg):
             _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
             if ddp is not None and fresh:
-                ddp.segment_done(model, seg, plan.n_seg)
+                ddp.segment_done(model, seg, plan.n_seg, plan)
         if fresh:
             for p, v in zip(params, views):
                 if p.requires_grad:

@@ -104,7 +104,7 @@ class TrainStep:
         for seg in range(plan.n_seg):
             _lib.check(l.pwr_engine_backward(plan.h, arr, seg, n, stream), "pwr_engine_backward")
             if ddp is not None:
-                ddp.segment_done(m, seg, plan.n_seg)
+                ddp.segment_done(m, seg, plan.n_seg, plan)
         scale = 1.0
         if ddp is not None:
             ddp.wait()
