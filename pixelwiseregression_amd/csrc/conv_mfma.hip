@@ -1067,6 +1067,11 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
         return (int)hipGetLastError();
       }
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 2>), g3, block, 0, s, p);
+      else if (bn == 64 && p.Cin <= 64 && PWR_DBG_ENV("PWR_WGRAD3_BM64N64", 1)) {
+        // <= 64 input channels (the stem's 32 -> 64 conv, model.py:171): a 64 x 64 tile -- the 128-row tile multiplied 96 rows of zeros
+        dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
+        hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1>), g64, block, 0, s, p);
+      }
       else if (bn == 64) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 1>), g3, block, 0, s, p);
       else hipLaunchKernelGGL((conv_wgrad3_kernel<4, 1, 1, 1>), g3, block, 0, s, p);
       return (int)hipGetLastError();

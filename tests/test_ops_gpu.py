@@ -174,7 +174,7 @@ def test_conv_dgrad_stride2(dtype, B, H, Cin, Cout, k):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3, 1, 4), (2, 64, 64, 128, 128, 3, 1, 16), (3, 5, 7, 64, 64, 3, 1, 3),
-                                  (2, 16, 16, 128, 64, 1, 1, 2), (2, 32, 32, 64, 128, 3, 2, 8), (1, 2, 2, 16, 16, 3, 1, 1),
+                                  (2, 32, 64, 32, 64, 3, 1, 8), (3, 8, 32, 64, 64, 3, 1, 5), (2, 16, 16, 128, 64, 1, 1, 2), (2, 32, 32, 64, 128, 3, 2, 8), (1, 2, 2, 16, 16, 3, 1, 1),
                                   (2, 8, 8, 256, 32, 3, 1, 2), (2, 16, 16, 32, 32, 5, 1, 4), (2, 32, 32, 128, 128, 7, 1, 9),
                                   (3, 5, 7, 64, 16, 7, 1, 2), (2, 32, 32, 128, 128, 5, 2, 5), (2, 64, 64, 128, 16, 5, 1, 40)])
 @pytest.mark.parametrize("prologue", [False, True])
