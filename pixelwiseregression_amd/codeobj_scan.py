@@ -74,8 +74,8 @@ def _vregs(text):
     return out
 
 
-def async_lds_hazards(txt, name_filter="wgrad3d"):
-    """The kernels of csrc/conv_wgrad_dma.hip read LDS through inline asm (so that the compiler's wait-count pass does not fence the
+def async_lds_hazards(txt, name_filter=("wgrad3d", "wgrad3w")):
+    """The kernels of csrc/conv_wgrad_dma.hip and the loader waves of csrc/conv_wgrad_ws.hip read LDS through inline asm (so that the compiler's wait-count pass does not fence the
     LDS-DMA prefetches).  The compiler then believes an asm's output register is defined when the statement ends, while the data of
     a ds_read arrives later: any instruction that touches such a register between the read and the `s_waitcnt lgkmcnt` covering it
     copies or clobbers stale data -- round 3 shipped-candidate build had exactly that (a v_mov the register allocator put in front
@@ -85,7 +85,7 @@ def async_lds_hazards(txt, name_filter="wgrad3d"):
     for ln in txt.splitlines():
         m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
         if m:
-            cur, pending = (m.group(1) if name_filter in m.group(1) else None), []
+            cur, pending = (m.group(1) if any(f in m.group(1) for f in name_filter) else None), []
             continue
         if cur is None:
             continue

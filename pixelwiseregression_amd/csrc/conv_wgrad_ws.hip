@@ -43,7 +43,7 @@ constexpr int XCH = (XROWS * RB + 1023) / 1024, YCH = KP * RB / 1024, NCH = XCH 
 constexpr int NLW = 4, NCW = (NCH + NLW - 1) / NLW;              // loader waves; pieces per loader wave and step (5, three of them padding)
 constexpr int XBYTES = XCH * 1024, STAGE = NCH * 1024;
 #ifndef PWR_WS_NS
-#define PWR_WS_NS 6
+#define PWR_WS_NS 7
 #endif
 constexpr int NS = PWR_WS_NS, D = NS - 1;                        // ring stages; a step's pieces are issued D steps ahead
 constexpr int MAXSB = 8;                                         // norm states of at most this many samples per split
@@ -218,36 +218,49 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       return __builtin_bit_cast(f32x4, o);
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto tile_pass = [&](int soff) {                              // soff: byte offset of the ring stage that holds the tile
+    // The pass is split in two so that the LDS round trip of the raw values hides behind the arithmetic of the PREVIOUS tile (the serial
+    // chain read -> wait -> arithmetic -> store -> wait per K step was longer than the MFMA waves' 24 MFMAs: elimination in
+    // profiles/r4_experiments.md section 1):  tile_read() issues the reads of a landed tile (inline asm, no wait), tile_wait() is the
+    // lgkmcnt wait TIED to the three registers (every use depends on it), tile_finish() computes and stores.  The values cross one
+    // barrier in registers.  All loader waves read three slots (the third lies inside the stage for every thread; only the threads
+    // 192 .. 223 use it): one straight-line asm per step, no merge of an asynchronous register with a compiler-written one.
+    auto tile_read = [&](int soff, f32x4& r0, f32x4& r1, f32x4& r2) {
+      if constexpr (NRM) {
+        const unsigned a = nrl + soff;
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %3 offset:%4"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(a), "n"(OFF3) : "memory");
+      }
+    };
+    auto tile_wait = [&](f32x4& r0, f32x4& r1, f32x4& r2) {
+      if constexpr (NRM) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2)::"memory");
+    };
+    auto tile_finish = [&](int soff, const f32x4& r0, const f32x4& r1, const f32x4& r2) {      // soff: byte offset of the ring stage that holds the tile
       const bool zl = nx == 0, zr = nx == tiles_x - 1;            // the tile touches the left / right image border
       const int iy = ny + ky - 1;
       const bool rowzero = iy < 0 || iy >= p.H;                   // the whole input row is zero padding
       const unsigned a = nrl + soff;
       if constexpr (NRM) {
-#ifdef PWR_DEBUG_BUILD
-        if (p.dbg & 4) { if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } } return; }       // elimination: no tile pass at all
-#endif
         nr_state();
-        f32x4 r0, r1, r2;
-        if (lw == NLW - 1) {                                       // (wave-uniform: the wave that owns rows 32 and 33)
-          asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(a), "n"(OFF3) : "memory");
-        } else {
-          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a) : "memory");
-          r2 = zero4;
-        }
-        f32x4 o0 = nr_math(r0), o1 = nr_math(r1);
+        f32x4 o0, o1;
 #ifdef PWR_DEBUG_BUILD
         if (p.dbg & 1) { o0 = r0; o1 = r1; }                       // elimination: no norm arithmetic (raw values stored back)
-        if (p.dbg & 2) { if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } } return; }       // elimination: reads + arithmetic, no stores
+        else { o0 = nr_math(r0); o1 = nr_math(r1); }
+#else
+        o0 = nr_math(r0); o1 = nr_math(r1);
 #endif
         if (rowzero | zl | zr) {                                   // (wave-uniform, rare: image borders)
           if (rowzero || (zl && nr_row == 0)) o0 = zero4;
           if (rowzero) o1 = zero4;
         }
-        asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(o0) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(o1) : "memory");
-        if (lw == NLW - 1) {
+#ifdef PWR_DEBUG_BUILD
+        if (p.dbg & 2) asm volatile("" ::"v"(o0), "v"(o1));         // elimination: arithmetic, no stores
+        else
+#endif
+        {
+          asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(o0) : "memory");
+          asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(o1) : "memory");
+        }
+        if (lw == NLW - 1) {                                       // (wave-uniform: the wave that owns rows 32 and 33)
           f32x4 o2 = nr_math(r2);
           if (rowzero || (zr && lt >= 208)) o2 = zero4;            // (threads 208 .. 223 hold row 33)
           if (third) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(o2), "n"(OFF3) : "memory");
@@ -265,26 +278,36 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } }
     };
 
-    // ---- prologue: steps 0 .. D-1 in flight, tiles 0 and 1 processed, tile 2 landed
+    // ---- prologue: steps 0 .. D-1 in flight, tiles 0 and 1 finished, the raw tile 2 in registers, tile 3 landed
 #pragma unroll
     for (int k = 0; k < D; ++k)
       if (k < nsteps) issue(k * STAGE);
-    landed_but(issued - 2);                                        // tiles 0 and 1 are needed
-    __builtin_amdgcn_s_barrier();                                  // (P) every loader's pieces of tiles 0 and 1 have landed
+    landed_but(issued - 3);                                        // tiles 0, 1 and 2 are needed
+    __builtin_amdgcn_s_barrier();                                  // (P) every loader's pieces of tiles 0 .. 2 have landed
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    tile_pass(0);
-    if (nsteps > 1) tile_pass(STAGE);
-    landed_but(issued - 3);
+    f32x4 rc0 = zero4, rc1 = zero4, rc2 = zero4, rn0, rn1, rn2;
+    {
+      f32x4 t0, t1, t2;
+      tile_read(0, t0, t1, t2); tile_wait(t0, t1, t2); tile_finish(0, t0, t1, t2);
+      if (nsteps > 1) { tile_read(STAGE, t0, t1, t2); tile_wait(t0, t1, t2); tile_finish(STAGE, t0, t1, t2); }
+    }
+    tile_read(2 * STAGE, rc0, rc1, rc2);
+    tile_wait(rc0, rc1, rc2);
+    landed_but(issued - 4);
     int stg = 0;                                                   // ring stage of step s
 #pragma nounroll
     for (int s = 0; s < nsteps; ++s) {
-      __builtin_amdgcn_s_barrier();                                // barrier s
+      __builtin_amdgcn_s_barrier();                                // barrier s: every loader's pieces of tile s + 3 have landed
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      const int s2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2, s3 = stg + 3 >= NS ? stg + 3 - NS : stg + 3;
+      tile_read(s3 * STAGE, rn0, rn1, rn2);                        // (past the last step: a stage nobody uses any more)
       const int istg = stg == 0 ? NS - 1 : stg - 1;                // (s + D) % NS: the stage read during step s - 1
       if (s + D < nsteps) issue(istg * STAGE);
-      if (s + 2 < nsteps) { const int t2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2; tile_pass(t2 * STAGE); }
-      // issued so far: the steps up to min(s + D, nsteps - 1); needed at barrier s + 1: step s + 3 landed (and every LDS store retired)
-      landed_but((s + D < nsteps - 1 ? s + D : nsteps - 1) - (s + 3));
+      if (s + 2 < nsteps) tile_finish(s2 * STAGE, rc0, rc1, rc2);
+      // issued so far: the steps up to min(s + D, nsteps - 1); needed at barrier s + 1: step s + 4 landed (and every LDS access retired)
+      landed_but((s + D < nsteps - 1 ? s + D : nsteps - 1) - (s + 4));
+      tile_wait(rn0, rn1, rn2);
+      rc0 = rn0; rc1 = rn1; rc2 = rn2;
       stg = stg + 1 == NS ? 0 : stg + 1;
     }
     __builtin_amdgcn_s_waitcnt(vmwait(0));                         // (no DMA may be in flight when the workgroup's LDS is released)
