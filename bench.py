@@ -301,7 +301,8 @@ def pipeline_block(model, trainer, dev, steps):
         torch.cuda.synchronize()
         out[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
     out["frames_per_s"] = B_PER_GPU / (out["preprocess_plus_train_step_ms"] * 1e-3)
-    out["fallback_or_rejected_last_batch"] = int((prep()["fallback"] | prep()["rejected"]).sum())
+    last = prep()
+    out["fallback_or_rejected_in_one_batch"] = int((last["fallback"] | last["rejected"].cpu()).sum())      # (one fresh draw: informational)
     out["what"] = ("%d raw 480x640 fp32 frames in HBM -> preprocess_batch with a fresh augmentation draw per step -> TrainStep; %d timed steps; the "
                    "per-sample crop geometry and joint transforms are float64 host arithmetic like the reference's" % (B_PER_GPU, steps))
     return out
@@ -352,7 +353,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher around us: become one.  Nothing in this process has touched the GPU yet (device_count does not initialise HIP).
+        # no launcher around us: become one.  The ranks are FRESH child processes (no exec of this one), so it does not matter whether
+        # device_count() initialised HIP here (it may: without amdsmi it falls back to hipGetDeviceCount).
         if not args.same_device and torch.cuda.device_count() < args.gpus:
             print("bench.py --gpus %d: only %d GPU(s) visible (add --same-device --dist-backend gloo for the 1-GPU debug mode)"
                   % (args.gpus, torch.cuda.device_count()), file=sys.stderr)

@@ -96,16 +96,39 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
         if verbose:
             print("[pwr build] linked", LIB, flush=True)
         _scan_gate(LIB, verbose)
+    else:
+        from . import codeobj_scan
+        import json
+        ok = False
+        try:
+            rec = json.load(open(codeobj_scan.stamp_path(LIB)))
+            ok = rec.get("sha256") == codeobj_scan.lib_digest(LIB)
+        except (OSError, ValueError):
+            pass
+        if not ok:                       # an up-to-date library without a matching scan record: scan it now
+            _scan_gate(LIB, verbose)
     return LIB
 
 
 def _scan_gate(lib, verbose=True):
     """No packed f32 instruction with a cross-half op_sel may ship, and no instruction may touch the
-    destination of an inline-asm LDS read before its wait (conv_wgrad_dma.hip): checked on every link."""
+    destination of an inline-asm LDS read before its wait (conv_wgrad_dma.hip, the loader waves of conv_wgrad_ws.hip): checked on every
+    link, with the LLVM tools of the hipcc that built the library.  The result is written beside the library (<lib>.scan.json, keyed by
+    the library's sha256): tests/test_boundary_cpu.py refuses a product library without a matching, clean record.  A toolchain without
+    llvm-objdump FAILS the product build (the gate is the only protection against those two instruction forms, and a foreign toolchain is
+    exactly where they would come back) unless PWR_ALLOW_UNSCANNED=1 is set -- the record then says "unscanned"."""
+    import json
     from . import codeobj_scan
     if not codeobj_scan.available():
+        if os.environ.get("PWR_ALLOW_UNSCANNED") != "1":
+            os.remove(lib)
+            raise RuntimeError("llvm-objdump / llvm-objcopy not found next to %s: the code-object scan cannot run.  Point HIPCC at a ROCm "
+                               "prefix that has lib/llvm/bin, or set PWR_ALLOW_UNSCANNED=1 to build an UNSCANNED library (tests will flag it)"
+                               % os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+        with open(codeobj_scan.stamp_path(lib), "w") as f:
+            json.dump({"sha256": codeobj_scan.lib_digest(lib), "scanned": False}, f)
         if verbose:
-            print("[pwr build] llvm-objdump not found: code-object scan skipped", flush=True)
+            print("[pwr build] llvm-objdump not found: code-object scan SKIPPED by PWR_ALLOW_UNSCANNED=1", flush=True)
         return
     r = codeobj_scan.scan(lib)
     if r["packed_f32_cross_half_op_sel"]:
@@ -117,6 +140,9 @@ def _scan_gate(lib, verbose=True):
         os.remove(lib)
         raise RuntimeError("%s: %d instructions touch the destination of an inline-asm LDS read before the s_waitcnt that covers it "
                            "(e.g. %s) -- see codeobj_scan.async_lds_hazards" % (lib, r["async_lds_hazards"], r["async_lds_examples"][:2]))
+    with open(codeobj_scan.stamp_path(lib), "w") as f:
+        json.dump({"sha256": codeobj_scan.lib_digest(lib), "scanned": True, "llvm": codeobj_scan.LLVM, "functions": r["functions"],
+                   "packed_f32": r["packed_f32"], "packed_f32_cross_half_op_sel": 0, "async_lds_hazards": 0}, f)
     if verbose:
         print("[pwr build] code-object scan ok: %d functions, %d packed f32, 0 with cross-half op_sel, 0 uses of an LDS read in flight"
               % (r["functions"], r["packed_f32"]), flush=True)

@@ -9,11 +9,35 @@ tests/test_boundary_cpu.py on the library that is loaded.
 """
 import os, re, struct, subprocess, sys, tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_dir():
+    """The LLVM tools of the toolchain that BUILDS the library: next to the hipcc in use (HIPCC, default /opt/rocm/bin/hipcc:
+    <prefix>/bin/hipcc -> <prefix>/lib/llvm/bin), so that a library built with another ROCm prefix is scanned with that prefix's
+    disassembler -- not skipped because /opt/rocm happens to be absent."""
+    hipcc = os.path.realpath(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
+    for cand in (os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib", "llvm", "bin"), os.path.join(os.path.dirname(hipcc)), "/opt/rocm/lib/llvm/bin"):
+        if all(os.path.exists(os.path.join(cand, t)) for t in ("llvm-objcopy", "llvm-objdump")):
+            return cand
+    return None
+
+
+LLVM = _llvm_dir() or "/opt/rocm/lib/llvm/bin"
 
 
 def available():
     return all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "llvm-objdump"))
+
+
+def stamp_path(lib):
+    return lib + ".scan.json"
+
+
+def lib_digest(lib):
+    import hashlib
+    h = hashlib.sha256()
+    with open(lib, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 

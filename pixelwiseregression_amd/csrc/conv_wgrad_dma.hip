@@ -26,7 +26,11 @@
 // in flight -- in front of any LDS access it knows about behind an LDS-DMA.  The price: the compiler believes an asm's output is
 // defined when the statement ends, while the data arrives later.  Rules kept here: one definition and one tied wait per asynchronous
 // register, straight-line code between a read and its wait, and pixelwiseregression_amd/codeobj_scan.py::async_lds_hazards checks the
-// linked code object for any instruction that touches such a register too early (profiles/r3_experiments.md section 14).
+// linked code object for any instruction that touches such a register too early (profiles/r3_experiments.md section 14); the gate runs
+// in build() with the LLVM tools of the hipcc in use and FAILS the build where they are missing, its result is recorded beside the library
+// and tests/test_boundary_cpu.py refuses a library without a clean record (round 4).  Since round 4 the 128-channel layers run on
+// conv_wgrad_ws.hip instead, whose MFMA waves read LDS through compiler-visible loads and whose loader waves' reads are each tied to
+// their wait; this kernel remains for the 64-channel tiles.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -60,8 +64,9 @@ template <int RB, int OFF>
 __device__ __forceinline__ bf16x8 wfrag(unsigned lane_addr) {
   static_assert(OFF >= 0 && OFF + 4 * RB < 65536, "ds offset field");
   bf16x4_w lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lane_addr), "n"(OFF) : "memory");
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lane_addr), "n"(OFF + 4 * RB) : "memory");
+  // (early-clobber outputs: the destination may not share a register with the address, which the second read still needs)
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(lo) : "v"(lane_addr), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(hi) : "v"(lane_addr), "n"(OFF + 4 * RB) : "memory");
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
   return f;

@@ -563,6 +563,7 @@ struct Engine {
     r.nc = norm_params(Fh);
     r.cc = conv_params(Fh, x.C, 1, 1, true, true);
     if (pwr_resblock_small_supported(x.H, x.W, x.C, norm_mode, dtype)) return resblock_fused(x, r);
+    if (lazy_x.valid) err = "internal: a fused producer is pending in front of an unfused ResBlock (its input would never be written)";
     norm_fwd(x, r.na);
     r.t1 = conv_fwd(x, &r.na, r.ca, nullptr, tr, &r.nb);
     r.t2 = conv_fwd(r.t1, &r.nb, r.cb, nullptr, tr, &r.nc);
@@ -594,6 +595,7 @@ struct Engine {
     int xmode = 0;
     size_t xa_off = 0, xh_off = 0;
     if (lazy_x.valid && lazy_x.x_off == x.off) { xmode = lazy_x.mode; xa_off = lazy_x.a_off; xh_off = lazy_x.h_off; lazy_x.valid = false; }
+    else if (lazy_x.valid) err = "internal: a fused producer (max-pool / up-sample left to a one-launch ResBlock) was not consumed by the block it was registered for";
     fwd.push_back([=](Ctx& c) {
       return pwr_resblock_fwd_small_x(xmode, xmode ? c.arena + xa_off : nullptr, xmode == 2 ? c.arena + xh_off : nullptr,
                                     c.arena + x.off, tr ? c.arena + rb.t1.off : nullptr, tr ? c.arena + rb.t2.off : nullptr, c.arena + out.off,
@@ -1054,6 +1056,7 @@ struct Engine {
       std::swap(stem_bwd, bwd_cur);
     }
     if (pcur != poff.size()) { err = "parameter table longer than the network"; return false; }
+    if (lazy_x.valid) { err = "internal: a fused producer (max-pool / up-sample) is still pending at the end of the plan"; return false; }
     if (!err.empty()) return false;
     // shared scratch
     scope = "scratch";

@@ -66,13 +66,15 @@ class _Plan:
 MAX_PLANS = 4          # per module: e.g. (train B), (eval B), (ragged last eval batch), one spare
 
 
+PLAN_BUDGET_BYTES = None      # arena bytes the cached plans of one module may hold together; None = half of the device's memory
+
+
 def _plan_budget_bytes(dev):
     """Arena bytes the cached plans of one module may hold together (least recently used plans beyond it are dropped):
-    PWR_PLAN_BUDGET_GB, default half of the device's memory."""
-    import os
-    env = os.environ.get("PWR_PLAN_BUDGET_GB")
-    if env:
-        return int(float(env) * (1 << 30))
+    engine.PLAN_BUDGET_BYTES, default half of the device's memory.  (A module attribute, not an environment variable: the package, like
+    the library, reads no PWR_* variable.)"""
+    if PLAN_BUDGET_BYTES is not None:
+        return int(PLAN_BUDGET_BYTES)
     try:
         return torch.cuda.get_device_properties(dev).total_memory // 2
     except Exception:

@@ -15,7 +15,6 @@ Differences a caller can observe (all additive):
   * the module refuses to run on the CPU: there is no fallback path.
 """
 import math
-import os
 from collections import OrderedDict
 
 import numpy as np
@@ -137,7 +136,7 @@ class PixelwiseRegression(nn.Module):
             stages.append(blk)
         self.stages = nn.ModuleList(stages)
         b.xavier()
-        self._precision = os.environ.get("PWR_PRECISION", "fp32")
+        self._precision = "fp32"       # parity mode by default, like the reference; set_precision("bf16") or torch.autocast selects the bf16 engine
         self._flat = None
         self._flat_grad = None
         self._engine = None

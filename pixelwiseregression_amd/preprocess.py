@@ -161,12 +161,15 @@ def preprocess_batch(depth, joint_uvd, com, cube_size, intrinsics, image_size=12
             mask = torch.where(fb[:, None, None, None], mask0, mask)
             box[fallback], com_i[fallback], uvd[fallback] = box0[fallback], com0[fallback], uvd0[fallback]
     # datasets.py:358-365 (un-augmented heat map fails) and :385-390 (NaN anywhere, or fewer than 10 mask pixels): sample dropped
-    rejected = ~_footprint_ok(uvd, P)
-    bad = (torch.isnan(img).flatten(1).any(1) | torch.isnan(label).flatten(1).any(1) | (mask.flatten(1).sum(1) < 10)).cpu().numpy()
-    rejected |= bad | np.isnan(uvd).any(axis=(1, 2))
+    # `rejected` stays ON THE DEVICE (no host synchronisation here: the input pipeline must not serialise with the train step that runs
+    # beside it; the caller reads the flags when it needs them): the host-side footprint / NaN-joint flags go up, the image-side flags
+    # (NaN anywhere, mask.sum() < 10) are computed where the images are
+    rejected_host = ~_footprint_ok(uvd, P) | np.isnan(uvd).any(axis=(1, 2))
+    bad = torch.isnan(img).flatten(1).any(1) | torch.isnan(label).flatten(1).any(1) | (mask.flatten(1).sum(1) < 10)
+    rejected = torch.from_numpy(rejected_host).to(dev, non_blocking=True) | bad
     out = {"img": img, "label_img": label, "mask": mask, "box_size": torch.from_numpy(box.astype(np.float32)),
            "cube_size": torch.from_numpy(cube.astype(np.float32)), "com": torch.from_numpy(com_i.astype(np.float32)),
-           "uvd": torch.from_numpy(uvd.astype(np.float32)).to(dev), "fallback": torch.from_numpy(fallback), "rejected": torch.from_numpy(rejected)}
+           "uvd": torch.from_numpy(uvd.astype(np.float32)).to(dev), "fallback": torch.from_numpy(fallback), "rejected": rejected}
     if dense_targets:
         out["heatmaps"], out["depthmaps"] = make_targets(out["uvd"], label, mask, kernel_size, sigmoid)
     return out

@@ -226,6 +226,22 @@ def test_no_cross_half_packed_f32_in_shipped_code_objects():
     r = mod.scan(_lib.LIB_PATH)
     assert r["functions"] > 100 and r["instructions"] > 100000, r       # the scan really saw the library's kernels
     assert r["packed_f32_cross_half_op_sel"] == 0, r
+    assert r["async_lds_hazards"] == 0, r["async_lds_examples"]         # no use of an inline-asm LDS read before its wait (conv_wgrad_dma / _ws)
+
+
+def test_shipped_library_carries_a_clean_scan_record():
+    """build.build() writes <lib>.scan.json after every link: the sha256 of the library it scanned and the (clean) result.  A product
+    library without a matching record -- linked by hand, or built with PWR_ALLOW_UNSCANNED=1 on a toolchain without llvm-objdump -- is
+    refused here, wherever the tests run (the record travels with the library; no disassembler is needed to check it)."""
+    import json
+    import pytest
+    from pixelwiseregression_amd import _lib, codeobj_scan as mod
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpwr_hip.so not built")
+    assert os.path.exists(mod.stamp_path(_lib.LIB_PATH)), "no scan record beside the library: build it with pixelwiseregression_amd.build"
+    rec = json.load(open(mod.stamp_path(_lib.LIB_PATH)))
+    assert rec["sha256"] == mod.lib_digest(_lib.LIB_PATH), "the scan record belongs to another build of the library"
+    assert rec.get("scanned") is True and rec["packed_f32_cross_half_op_sel"] == 0 and rec["async_lds_hazards"] == 0, rec
 
 
 def test_shipped_library_has_one_configuration():
@@ -272,3 +288,16 @@ def test_input_gradients_are_refused_loudly():
     img = torch.zeros(1, 1, 32, 32, requires_grad=True)
     with pytest.raises(NotImplementedError, match="gradients with respect to img"):
         m(img, torch.zeros(1, 1, 16, 16), torch.ones(1, 1, 16, 16))
+
+
+def test_package_reads_no_experiment_variable():
+    """The Python package, like the library, has ONE configuration: no module of pixelwiseregression_amd reads a PWR_* environment
+    variable (round 3 left two: the default precision and the plan-cache budget; they are a constructor default and a module attribute
+    now).  HIPCC (the compiler to build with) and PWR_ALLOW_UNSCANNED (an explicit build opt-out that the tests flag) are build inputs."""
+    import glob
+    import re
+    from pixelwiseregression_amd import _lib
+    pkg = os.path.dirname(_lib.__file__)
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        for m in re.finditer(r"environ[^\n]*?[\"'](PWR_[A-Z0-9_]+)", open(f).read()):
+            assert m.group(1) == "PWR_ALLOW_UNSCANNED" and os.path.basename(f) == "build.py", (f, m.group(1))

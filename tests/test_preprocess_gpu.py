@@ -72,7 +72,7 @@ def test_device_pipeline_edge_cases_match_reference(golden_dir, kind):
         aug = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
     out = preprocess_batch(depth, joints, com, 150, INTR, 128, 64, augmentation=aug)
     want_rej = np.array([bool(g["%s%d_rejected" % (kind, i)]) for i in range(n)])
-    assert np.array_equal(out["rejected"].numpy(), want_rej) and want_rej.tolist() == [False] * 8 + [True]
+    assert np.array_equal(out["rejected"].cpu().numpy(), want_rej) and want_rej.tolist() == [False] * 8 + [True]
     want_fb = np.array([kind == "aug" and not want_rej[i] and np.array_equal(g["aug%d_img" % i], g["plain%d_img" % i]) for i in range(n)])
     assert np.array_equal(out["fallback"].numpy()[:8], want_fb[:8])
     for i in (6, 7):
