@@ -212,8 +212,9 @@ def cpu_baseline(Bc=B_PER_GPU, warmup=3, iters=10, budget_s=60.0):
             "infer_value": Bc / ti,
             "sample": "median of %d timed train steps (fwd+loss+bwd+AdamW) after %d warm-up of the CPU oracle at batch %d (the config's), "
                       "same architecture and 128x128 crops, fp32, %d threads (fastest of a scan over the usable CPUs); inference = median of 3 no_grad forwards. "
-                      "Oracle vs the reference itself (build container, 8 threads, B=8, profiles/r3_ref_vs_oracle_cpu.json): train 0.88-0.99x, inference "
-                      "0.78-0.79x of the reference's speed -- `infer_value` understates the reference by about a fifth"
+                      "Oracle vs the reference itself (build container, 8 threads, B=8, interleaved rounds, profiles/r4_ref_vs_oracle_cpu.json): the same ATen "
+                      "ops in the same counts (torch.profiler), inference 0.98x, train 0.91x of the reference's speed (per round 0.92-1.05 / 0.89-1.01: noise of "
+                      "a shared container; round 3's 0.79x was a single reference-first, oracle-second pass)"
                       % (iters, warmup, Bc, cores)}
 
 
@@ -478,35 +479,35 @@ def main():
         out["step_mfma_frac"] = step_flops / (dt / args.steps) / (peak * 1e12)
         if True:   # (kept as a block: the roofline probes run on every rank-0 report)
             t, flops = time_head_conv(dev, B_PER_GPU, precision=args.precision)
-            # HBM bytes per launch: NOT measured in this run -- replayed from the committed rocprofv3 PMC passes of the same kernel
-            # and shape (PMC collection needs its own rocprofv3 runs); `traffic_source` names the file
-            traffic, traffic_source = None, None
-            for tj in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+            # HBM bytes per launch are NOT measured in this run (PMC collection needs rocprofv3 passes of its own: tools/profile_r4.sh), so
+            # `traffic` is null here; the counter result of the committed profile of the same kernel and shape is quoted beside it
+            traffic_profile = None
+            for tj in ("r4_traffic.json", "r3_traffic.json"):
                 fp = os.path.join(ROOT, "profiles", tj)
-                if os.path.exists(fp):
-                    traffic = None if args.precision != "bf16" else json.load(open(fp)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
-                    traffic_source = "profiles/" + tj
-                    if traffic is not None:
+                if os.path.exists(fp) and args.precision == "bf16":
+                    v = json.load(open(fp)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
+                    if v is not None:
+                        traffic_profile = {"hbm_bytes_per_launch": v, "source": "profiles/" + tj, "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another lease"}
                         break
             out["roofline"] = {"bound": "mfma", "kernel": "conv3x3 128->128 @64x64, B=%d (+fused norm/ReLU), %s operands" % (B_PER_GPU, args.precision),
                                "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                               "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": t * 1e6,
+                               "frac": flops / t / 1e12 / peak, "traffic": None, "traffic_profile": traffic_profile, "us_per_launch": t * 1e6,
                                "flop_per_launch": flops}
             if args.precision == "bf16":
                 out["roofline"]["vendor_gemm_same_shape"] = vendor_gemm_yardstick(dev, B_PER_GPU)
             td, nb = time_decoder(dev, B_PER_GPU)
-            dtraffic = None
-            dsrc = None
-            for tj in ("r3_traffic.json", "r2_traffic.json"):
+            dprofile = None
+            for tj in ("r4_traffic.json", "r3_traffic.json"):
                 fp = os.path.join(ROOT, "profiles", tj)
-                if os.path.exists(fp) and dtraffic is None:
-                    dtraffic = json.load(open(fp)).get("decode_fwd B=%d J=%d P=%d" % (B_PER_GPU, J, P), {}).get("hbm_bytes_corrected")
-                    dsrc = "profiles/" + tj
+                if os.path.exists(fp) and dprofile is None:
+                    v = json.load(open(fp)).get("decode_fwd B=%d J=%d P=%d" % (B_PER_GPU, J, P), {}).get("hbm_bytes_corrected")
+                    if v is not None:
+                        dprofile = {"hbm_bytes_per_launch": v, "source": "profiles/" + tj}
             out["roofline_decoder"] = {"bound": "hbm", "achieved": nb / td / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": dtraffic, "traffic_source": dsrc,
+                                       "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "traffic_profile": dprofile,
                                        "us_per_launch": td * 1e6,
                                        "note": "23 MB per launch: launch / latency bound at this shape (the rocprofv3 average of the same probe is ~1 us longer than this "
-                                               "HIP-event figure: profiles/r3_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r3_dec_bench.jsonl)"}
+                                               "HIP-event figure: profiles/r4_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r4_dec_bench.jsonl)"}
         if world == 1 and args.with_pipeline and native:
             model.train()
             out["pipeline"] = pipeline_block(model, trainer, dev, max(10, min(args.steps, 100)))

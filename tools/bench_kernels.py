@@ -34,8 +34,10 @@ if which in ("all", "wgrad"):
     # the engine's split count for this layer (80) only, so that the rocprofv3 average of these launches is the number quoted in
     # DESIGN.md; `sweep` as third argument walks the split counts (round 2's 81 us "average" was over such a sweep)
     sweep = len(sys.argv) > 3 and sys.argv[3] == "sweep"
-    for splits in ((40, 57, 80, 85, 86, 96, 120, 160) if sweep else (80,)):
+    # (round 4: these layers run on conv_wgrad3w_kernel, the wave-specialised kernel; 24 splits = the engine's count in the train step -- few,
+    # long workgroups that leave the other CUs to the chain -- 80 = the one-round-of-the-chip count of the isolated comparison)
+    for splits in ((24, 40, 57, 80, 96, 120, 160) if sweep else (80, 24)):
         t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=st, splits=splits))
-        print(json.dumps({"kernel": "conv_wgrad3 (norm on load, register-staged) + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+        print(json.dumps({"kernel": "conv_wgrad3w<norm> (wave-specialised, norm + ReLU in LDS) + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
         t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=None, splits=splits))
-        print(json.dumps({"kernel": "conv_wgrad3d (no norm, LDS-DMA) + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+        print(json.dumps({"kernel": "conv_wgrad3w<no norm> + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 profiles (run on the GPU box from the repo root): per-kernel statistics of the train step (three streams, and everything on
+# Round-4 profiles (run on the GPU box from the repo root): per-kernel statistics of the train step (three streams, and everything on
 # one stream = the serial kernel time), of `bench.py --roofline-only` and of the isolated hot kernels, HBM traffic of the dominant conv
 # and of the decoder from separate PMC passes, MFMA utilisation.
-#   bash tools/profile_r3.sh  ->  gpurun_out/r3p/*  (summaries -> gpurun_out/r3p/summary by tools/profile_summary.py, then copied to profiles/)
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r3p; mkdir -p $O
+#   bash tools/profile_r4.sh  ->  gpurun_out/r4p/*  (summaries -> gpurun_out/r4p/summary by tools/profile_summary.py, then copied to profiles/)
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4p; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python3 $R/bench.py --steps 25 --warmup 5 --no-cpu-baseline --accuracy-steps 0 > $O/step_bench.json 2> $O/step.err
 PWR_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python3 $R/bench.py --debug-lib --steps 25 --warmup 5 --no-cpu-baseline --accuracy-steps 0 > $O/serial_bench.json 2> $O/serial.err
@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_de
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_dec -o w -- python3 $R/tools/bench_decoder.py > /dev/null 2> $O/pmc_write_dec.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python3 $R/tools/bench_kernels.py all 3 > /dev/null 2> $O/pmc_mfma.err
 cd $R
-python3 tools/profile_summary.py $O $O/summary r3 > $O/summary.log 2>&1; tail -60 $O/summary.log
+python3 tools/profile_summary.py $O $O/summary r4 > $O/summary.log 2>&1; tail -60 $O/summary.log
 # keep the merge-back small: the raw traces are large
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 du -sh $O

@@ -1,4 +1,4 @@
-"""Summaries of tools/profile_r3.sh's (round 2: profile_r2.sh) rocprofv3 output -> small csv / json files for profiles/ (run on the GPU
+"""Summaries of tools/profile_r4.sh's (rounds 2, 3: profile_r2.sh, profile_r3.sh) rocprofv3 output -> small csv / json files for profiles/ (run on the GPU
 box, right after).   python tools/profile_summary.py <raw dir> <out dir> [prefix = r3]"""
 import collections, csv, glob, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
@@ -41,8 +41,8 @@ def mean_by_kernel(d, counter):
 
 B, P, F_ = 32, 64, 128
 act = B * P * P * F_ * 2
-out = {"source": "tools/profile_r3.sh on MI355X: rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; both counters are KB; "
-                 "FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide streaming reads at 64 B, MI355X_MICROARCH.md section HBM)"}
+out = {"source": "tools/profile_r%s.sh on MI355X: rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; both counters are KB; "
+                 "FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide streaming reads at 64 B, MI355X_MICROARCH.md section HBM)" % PRE[1:]}
 fe, wr = mean_by_kernel("pmc_fetch", "FETCH_SIZE"), mean_by_kernel("pmc_write", "WRITE_SIZE")
 
 
@@ -62,6 +62,10 @@ entry(fe, wr, "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1", None, 2 * a
 entry(fe, wr, "conv_wgrad3d_kernel<64, 128>", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3d_kernel<64,128> same shape")
 entry(fe, wr, "conv_wgrad3_kernel<2, 2, 1, 2", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3_kernel<2,2,1,2> same shape")
 entry(fe, wr, "wgrad_reduce_fast_kernel<9", None, None, "wgrad_reduce_fast_kernel<9,3> same shape (80 slabs)")
+# round 4: the wave-specialised kernel, at the isolated comparison's 80 splits (240 workgroups of 512 threads) and at the engine's 24 (72)
+for sp, grid in ((80, 240 * 512), (24, 72 * 512)):
+    entry(fe, wr, "conv_wgrad3w_kernel<true, true>", grid, 2 * act + sp * 128 * 128 * 9 * 4, "conv_wgrad3w_kernel<norm> same shape, %d splits (algorithmic bytes incl. its split-K slabs)" % sp)
+    entry(fe, wr, "conv_wgrad3w_kernel<false, false>", grid, 2 * act + sp * 128 * 128 * 9 * 4, "conv_wgrad3w_kernel<no norm> same shape, %d splits (algorithmic bytes incl. its split-K slabs)" % sp)
 fd, wd = mean_by_kernel("pmc_fetch_dec", "FETCH_SIZE"), mean_by_kernel("pmc_write_dec", "WRITE_SIZE")
 for (Bd, Jd, Pd, nt) in ((32, 14, 64, 256), (64, 21, 64, 256), (128, 42, 128, 512)):
     grid = Bd * Jd * nt
@@ -75,11 +79,12 @@ f = find("pmc_mfma", "counter_collection.csv")
 if f:
     acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        key = r["Kernel_Name"] + (" grid %s" % r.get("Grid_Size", "") if "wgrad3w" in r["Kernel_Name"] else "")
+        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     mm = {}
     for k, c in acc.items():
-        if "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1" in k or "conv_wgrad3_kernel<2, 2, 1, 2" in k or "conv_wgrad3d_kernel<64, 128>" in k:
+        if "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1" in k or "conv_wgrad3_kernel<2, 2, 1, 2" in k or "conv_wgrad3d_kernel<64, 128>" in k or "conv_wgrad3w_kernel" in k:
             m = {n: sum(v) / len(v) for n, v in c.items()}
             e = {"mean_ns_under_pmc": sum(dur[k]) / len(dur[k]), **m}
             if m.get("GRBM_GUI_ACTIVE", 0) > 0:
