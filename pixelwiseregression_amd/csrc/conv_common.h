@@ -38,6 +38,7 @@ struct WgradParams {
   int B, H, W, Cin, Ho, Wo, Cout, CoutPad, CinPad;
   int ksize, stride, pad, relu_in, M, S, steps_per_split;
   int dbg = 0;            // debug build only: elimination bits of conv_wgrad3d_kernel (1 no MFMA, 2 no fragment reads, 4 no DMA after the prologue, 8 no slab stores)
+  long long* stamps = nullptr;   // debug build only (conv_wgrad_ws.hip): per wave {cycles in barriers, cycles in DMA waits, cycles in the loop, steps}
 };
 
 template <typename T> struct Mma;
@@ -208,6 +209,9 @@ int launch_wgrad3d(const WgradParams& p, hipStream_t s);
 
 // conv_wgrad_ws.hip: 3x3 weight gradient of whole 128-channel tiles, wave-specialised (4 MFMA waves + 4 loader waves per workgroup);
 // one job or two jobs of one geometry per launch
+// conv_wgrad_ws9.hip: the same layers with all nine taps per workgroup (64 x 64-channel tiles, the K walk down the image columns)
+bool wgrad9w_applicable(const WgradParams& p);
+int launch_wgrad9w(const WgradParams& p, hipStream_t s);
 bool wgrad3w_applicable(const WgradParams& p);
 int launch_wgrad3w(const WgradParams& a, const WgradParams* b, hipStream_t s);
 

@@ -1035,7 +1035,8 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   const int taps = p.ksize * p.ksize;
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
   if constexpr (sizeof(T) == 2) {
-    if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // whole 128-channel tiles: the wave-specialised kernel
+    if (wgrad9w_applicable(p)) return launch_wgrad9w(p, s);                  // whole 128-channel tiles: the wave-specialised nine-tap kernel
+    if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // (its three-tap predecessor: debug build, PWR_WGRAD9W=0)
     if (wgrad3d_applicable(p)) return launch_wgrad3d(p, s);                  // operands by LDS-DMA (no norm to apply on the way)
     if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
       dim3 g3(24 * ((p.S + 7) / 8), grid.y, 1);

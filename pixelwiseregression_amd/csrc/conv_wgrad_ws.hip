@@ -28,6 +28,9 @@
 // so a DMA has three K steps to land (a ring of 8 stages -- five steps to land -- measured no faster in the step and 3 - 7 % slower
 // isolated: the loop is not latency-bound), a tile is normalised one full step before it is read, and a stage is overwritten only after
 // a barrier every MFMA wave reached with its reads retired.
+#include <cstdlib>
+#include <type_traits>
+
 #include "conv_common.h"
 #include "pwr.h"
 
@@ -139,46 +142,29 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       if (i == I_R) d_dr = (d_isx[i] && xr == XROWS - 1) ? -p.Cin : 0;
     }
     const bool five = lw == 0;                          // (wave-uniform)
-    int ib = b0, iyy = y0, ix = x0, issued = 0;         // next step to ISSUE
-    auto issue = [&](int soff) {
+    // next step to ISSUE.  NHWC rows are contiguous, so the dy tile of step t starts at pixel 32 t and the input tile of kernel row ky at
+    // pixel 32 t + (ky - 1) W (an out-of-image row: the dy tile's own pixels, zero-filled by the pass): one running pixel offset
+    int ix = x0, iyy = y0, issued = 0;
+    long long ipix = (long long)step0 * KP;
+    const long long kyoff = (long long)(ky - 1) * p.W;
+    auto issue = [&](int soff, auto FIVE) {
       const int iy = iyy + ky - 1;
       const bool rowok = iy >= 0 && iy < p.H;
-      const T* xrow = x + (((long long)ib * p.H + (rowok ? iy : iyy)) * p.W + ix * KP) * p.Cin;
-      const T* drow = dy + (((long long)ib * p.H + iyy) * p.W + ix * KP) * p.Cout;
+      const T* xrow = x + (ipix + (rowok ? kyoff : 0)) * p.Cin;
+      const T* drow = dy + ipix * p.Cout;
       const int first = ix == 0 ? 1 : 0, last = ix == tiles_x - 1 ? 1 : 0;
       char* base = smem + soff;
 #pragma unroll
       for (int i = 0; i < NCW; ++i) {
-        if (i == NCW - 1 && !five) break;
+        if (i == NCW - 1 && !decltype(FIVE)::value) break;
         const T* src = (d_isx[i] ? xrow : drow) + (d_off[i] + (i == 0 ? first * d_dl : 0) + (i == I_R ? last * d_dr : 0));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(base + d_lds[i]), 16, 0, 0);
       }
       ++issued;
-      if (++ix == tiles_x) { ix = 0; if (++iyy == p.H) { iyy = 0; ++ib; } }
+      ipix += KP;
+      if (++ix == tiles_x) { ix = 0; if (++iyy == p.H) iyy = 0; }
     };
-    // all but this wave's pieces of the `k` most recently issued steps have landed, and every LDS access of the wave has retired
-    auto landed_but = [&](int k) {
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      static_assert(D - 3 <= 5 && 5 * NCW < 64, "wait cases below; vmcnt is a 6-bit counter");
-      if (five) {
-        if (k >= 5) __builtin_amdgcn_s_waitcnt(vmwait(5 * NCW));
-        else if (k == 4) __builtin_amdgcn_s_waitcnt(vmwait(4 * NCW));
-        else if (k == 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * NCW));
-        else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * NCW));
-        else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NCW));
-        else __builtin_amdgcn_s_waitcnt(vmwait(0));
-      } else {
-        if (k >= 5) __builtin_amdgcn_s_waitcnt(vmwait(5 * (NCW - 1)));
-        else if (k == 4) __builtin_amdgcn_s_waitcnt(vmwait(4 * (NCW - 1)));
-        else if (k == 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * (NCW - 1)));
-        else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * (NCW - 1)));
-        else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NCW - 1));
-        else __builtin_amdgcn_s_waitcnt(vmwait(0));
-      }
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    };
-
     // ---- the in-LDS pass over a landed input tile: norm + ReLU (NRM), zeros for the out-of-image halo pixels, and an all-zero tile where
     // the whole input ROW lies outside the image (ky = 0 / 2 at the top / bottom: the step then adds nothing, without a branch or a select
     // in the MFMA waves).  Loader thread lt owns the 16-byte slots lt and lt + 256 of the tile's 34 x 16 slots (rows lt / 16 and + 16); the
@@ -278,38 +264,77 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } }
     };
 
-    // ---- prologue: steps 0 .. D-1 in flight, tiles 0 and 1 finished, the raw tile 2 in registers, tile 3 landed
+    // ---- one copy of prologue + loop per kind of loader wave (wave 0: five DMA pieces per step; wave 3: the rows 32, 33 of the tile pass),
+    // so that the piece count, the wait counts and the extra slot are compile-time in the loop -- and the loop in two parts: the STEADY
+    // part (every step issues, finishes a tile and waits for the same count: no conditional but the rare image-border ones) and the
+    // last D steps (general).  The loop's own scalar control flow was 0.3 us of every 0.6 - 0.8 us K step before (elimination,
+    // profiles/r4_experiments.md section 7): the MFMA waves wait for it in the barrier.
+    auto run_loader = [&](auto FIVE) {
+      constexpr int NPW = decltype(FIVE)::value ? NCW : NCW - 1;       // this wave's DMA pieces per step
+      auto landed = [&](int k) {      // all but this wave's pieces of the k most recently issued steps have landed; every LDS access retired
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        static_assert(D - 3 <= 5 && 5 * NCW < 64, "wait cases below; vmcnt is a 6-bit counter");
+        if (k >= 5) __builtin_amdgcn_s_waitcnt(vmwait(5 * NPW));
+        else if (k == 4) __builtin_amdgcn_s_waitcnt(vmwait(4 * NPW));
+        else if (k == 3) __builtin_amdgcn_s_waitcnt(vmwait(3 * NPW));
+        else if (k == 2) __builtin_amdgcn_s_waitcnt(vmwait(2 * NPW));
+        else if (k == 1) __builtin_amdgcn_s_waitcnt(vmwait(NPW));
+        else __builtin_amdgcn_s_waitcnt(vmwait(0));
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      };
+      // prologue: steps 0 .. D-1 in flight, tiles 0 and 1 finished, the raw tile 2 in registers, tile 3 landed
 #pragma unroll
-    for (int k = 0; k < D; ++k)
-      if (k < nsteps) issue(k * STAGE);
-    landed_but(issued - 3);                                        // tiles 0, 1 and 2 are needed
-    __builtin_amdgcn_s_barrier();                                  // (P) every loader's pieces of tiles 0 .. 2 have landed
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    f32x4 rc0 = zero4, rc1 = zero4, rc2 = zero4, rn0, rn1, rn2;
-    {
-      f32x4 t0, t1, t2;
-      tile_read(0, t0, t1, t2); tile_wait(t0, t1, t2); tile_finish(0, t0, t1, t2);
-      if (nsteps > 1) { tile_read(STAGE, t0, t1, t2); tile_wait(t0, t1, t2); tile_finish(STAGE, t0, t1, t2); }
-    }
-    tile_read(2 * STAGE, rc0, rc1, rc2);
-    tile_wait(rc0, rc1, rc2);
-    landed_but(issued - 4);
-    int stg = 0;                                                   // ring stage of step s
-#pragma nounroll
-    for (int s = 0; s < nsteps; ++s) {
-      __builtin_amdgcn_s_barrier();                                // barrier s: every loader's pieces of tile s + 3 have landed
+      for (int k = 0; k < D; ++k)
+        if (k < nsteps) issue(k * STAGE, FIVE);
+      landed(issued - 3);                                            // tiles 0, 1 and 2 are needed
+      __builtin_amdgcn_s_barrier();                                  // (P) every loader's pieces of tiles 0 .. 2 have landed
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      const int s2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2, s3 = stg + 3 >= NS ? stg + 3 - NS : stg + 3;
-      tile_read(s3 * STAGE, rn0, rn1, rn2);                        // (past the last step: a stage nobody uses any more)
-      const int istg = stg == 0 ? NS - 1 : stg - 1;                // (s + D) % NS: the stage read during step s - 1
-      if (s + D < nsteps) issue(istg * STAGE);
-      if (s + 2 < nsteps) tile_finish(s2 * STAGE, rc0, rc1, rc2);
-      // issued so far: the steps up to min(s + D, nsteps - 1); needed at barrier s + 1: step s + 4 landed (and every LDS access retired)
-      landed_but((s + D < nsteps - 1 ? s + D : nsteps - 1) - (s + 4));
-      tile_wait(rn0, rn1, rn2);
-      rc0 = rn0; rc1 = rn1; rc2 = rn2;
-      stg = stg + 1 == NS ? 0 : stg + 1;
-    }
+      f32x4 rc0 = zero4, rc1 = zero4, rc2 = zero4, rn0, rn1, rn2;
+      {
+        f32x4 t0, t1, t2;
+        tile_read(0, t0, t1, t2); tile_wait(t0, t1, t2); tile_finish(0, t0, t1, t2);
+        if (nsteps > 1) { tile_read(STAGE, t0, t1, t2); tile_wait(t0, t1, t2); tile_finish(STAGE, t0, t1, t2); }
+      }
+      tile_read(2 * STAGE, rc0, rc1, rc2);
+      tile_wait(rc0, rc1, rc2);
+      landed(issued - 4);
+      int stg = 0, s = 0;                                            // ring stage of step s
+      // steady part: s + D < nsteps, so step s + D is issued, tile s + 2 finished, and exactly D - 4 later steps stay in flight
+#pragma nounroll
+      for (; s + D < nsteps; ++s) {
+        __builtin_amdgcn_s_barrier();                                // barrier s: every loader's pieces of tile s + 3 have landed
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const int s2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2, s3 = stg + 3 >= NS ? stg + 3 - NS : stg + 3;
+        tile_read(s3 * STAGE, rn0, rn1, rn2);
+        const int istg = stg == 0 ? NS - 1 : stg - 1;                // (s + D) % NS: the stage read during step s - 1
+#ifdef PWR_DEBUG_BUILD
+        if (!(p.dbg & 16))                                           // (elimination: no DMA after the prologue)
+#endif
+        issue(istg * STAGE, FIVE);
+        tile_finish(s2 * STAGE, rc0, rc1, rc2);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(vmwait((D - 4) * NPW));           // step s + 4 landed (own pieces), every LDS access retired
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        tile_wait(rn0, rn1, rn2);
+        rc0 = rn0; rc1 = rn1; rc2 = rn2;
+        stg = stg + 1 == NS ? 0 : stg + 1;
+      }
+      // the last D steps: nothing left to issue, the pipeline drains
+#pragma nounroll
+      for (; s < nsteps; ++s) {
+        __builtin_amdgcn_s_barrier();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const int s2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2, s3 = stg + 3 >= NS ? stg + 3 - NS : stg + 3;
+        tile_read(s3 * STAGE, rn0, rn1, rn2);                        // (past the last step: a stage nobody uses any more)
+        if (s + 2 < nsteps) tile_finish(s2 * STAGE, rc0, rc1, rc2);
+        landed(nsteps - 1 - (s + 4));
+        tile_wait(rn0, rn1, rn2);
+        rc0 = rn0; rc1 = rn1; rc2 = rn2;
+        stg = stg + 1 == NS ? 0 : stg + 1;
+      }
+    };
+    if (five) run_loader(std::true_type{});
+    else run_loader(std::false_type{});
     __builtin_amdgcn_s_waitcnt(vmwait(0));                         // (no DMA may be in flight when the workgroup's LDS is released)
     __builtin_amdgcn_s_barrier();                                  // barrier nsteps (the MFMA waves' last)
     return;
@@ -366,6 +391,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
   int stg = 0;
 #pragma nounroll
   for (int s = 0; s < nsteps; ++s) {
+#ifdef PWR_DEBUG_BUILD
+    if (p.dbg & 8) { __syncthreads(); continue; }                  // (elimination: the MFMA waves only keep the barriers)
+#endif
     const int soff = stg * STAGE;
     const int nstg = stg + 1 == NS ? 0 : stg + 1;
     const int noff = nstg * STAGE;

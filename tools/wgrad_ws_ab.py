@@ -32,25 +32,31 @@ def run(B, H, W, Cin, Cout, splits, norm):
     dy = torch.randn(B, H, W, Cout, device=dev).to(torch.bfloat16)
     st = K.norm_stats(x, 1 + 0.3 * torch.randn(Cin, device=dev), 0.3 * torch.randn(Cin, device=dev), mode=0) if norm else None
     out = {}
-    for mode in ("0", "1"):
-        os.environ["PWR_WGRAD3W"] = mode
-        out[mode] = K.conv_wgrad(x, dy, Cout, 3, 1, norm=st, relu_in=True, splits=splits).clone()
-    same = bool(torch.equal(out["0"], out["1"]))
-    t = {"0": [], "1": []}
+    modes = {"r3": ("0", "0"), "ws3": ("1", "0"), "ws9": ("1", "1")}        # (PWR_WGRAD3W, PWR_WGRAD9W): round-3 kernels, three-tap, nine-tap wave-specialised
+    def setmode(m):
+        os.environ["PWR_WGRAD3W"], os.environ["PWR_WGRAD9W"] = modes[m]
+    for m in modes:
+        setmode(m)
+        out[m] = K.conv_wgrad(x, dy, Cout, 3, 1, norm=st, relu_in=True, splits=splits).clone()
+    t = {m: [] for m in modes}
     for _ in range(3):
-        for mode in ("0", "1"):
-            os.environ["PWR_WGRAD3W"] = mode
-            t[mode].append(timeit(lambda: K.conv_wgrad(x, dy, Cout, 3, 1, norm=st, relu_in=True, splits=splits)))
+        for m in modes:
+            setmode(m)
+            t[m].append(timeit(lambda: K.conv_wgrad(x, dy, Cout, 3, 1, norm=st, relu_in=True, splits=splits)))
     flops = 2.0 * B * H * W * Cin * Cout * 9
-    rec = {"shape": [B, H, W, Cin, Cout], "splits": splits, "norm": norm, "bit_identical": same, "max_abs_diff": float((out["0"] - out["1"]).abs().max()),
-           "old_us": [round(v, 1) for v in t["0"]], "new_us": [round(v, 1) for v in t["1"]], "new_TFLOPs_incl_reduce": flops / (min(t["1"]) * 1e-6) / 1e12}
+    scale = float(out["r3"].abs().max())
+    rec = {"shape": [B, H, W, Cin, Cout], "splits": splits, "norm": norm, "ws3_bit_identical_to_r3": bool(torch.equal(out["r3"], out["ws3"])),
+           "ws9_max_rel_diff_to_r3": float((out["r3"] - out["ws9"]).abs().max()) / scale,
+           "r3_us": [round(v, 1) for v in t["r3"]], "ws3_us": [round(v, 1) for v in t["ws3"]], "ws9_us": [round(v, 1) for v in t["ws9"]],
+           "ws9_TFLOPs_incl_reduce": flops / (min(t["ws9"]) * 1e-6) / 1e12}
     print(json.dumps(rec), flush=True)
     return x, dy, st
 
 
 for norm in (True, False):
-    for splits in (80,):
+    for splits in (80, 24):
         x, dy, st = run(32, 64, 64, 128, 128, splits, norm)
+    continue
     # the pair launch: two layers, half the splits each
     os.environ["PWR_WGRAD3W"] = "1"
     x2 = torch.randn_like(x.float()).to(torch.bfloat16)

@@ -1,5 +1,6 @@
-"""Timing by elimination inside the wave-specialised weight gradient (debug build, PWR_WGRAD3W_DBG; results are WRONG by construction):
-1 no norm arithmetic, 2 no stores of the tile pass, 4 no tile pass at all.  C2 heads shape, 80 splits, kernel + reduce."""
+"""Timing by elimination inside the nine-tap wave-specialised weight gradient (debug build, PWR_WGRAD9W_DBG; results are WRONG by construction):
+1 the MFMA waves only keep the barriers, 2 no DMA after the prologue, 3 both (the loop skeleton: barriers, waits, the loaders' pass).
+C2 heads shape, kernel + reduce (the reduce is ~12 us at 60 splits, ~5 at 18)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dbglib  # noqa: F401
@@ -17,11 +18,12 @@ def timeit(fn, iters=30):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-res = {}
-for rnd in range(2):
-    for dbg in (0, 1, 2, 3, 4):
-        os.environ["PWR_WGRAD3W_DBG"] = str(dbg)
-        res.setdefault("norm dbg=%d" % dbg, []).append(round(timeit(lambda: K.conv_wgrad(x, dy, 128, 3, 1, norm=st, splits=80)), 1))
-    os.environ["PWR_WGRAD3W_DBG"] = "0"
-    res.setdefault("no norm", []).append(round(timeit(lambda: K.conv_wgrad(x, dy, 128, 3, 1, norm=None, splits=80)), 1))
-print(json.dumps(res))
+for splits in (60, 18):
+    res = {}
+    for rnd in range(2):
+        for norm, nm in ((st, "norm"), (None, "no norm")):
+            for dbg in (0, 1, 2, 3):
+                os.environ["PWR_WGRAD9W_DBG"] = str(dbg)
+                res.setdefault("%s dbg=%d" % (nm, dbg), []).append(round(timeit(lambda: K.conv_wgrad(x, dy, 128, 3, 1, norm=norm, splits=splits)), 1))
+    os.environ["PWR_WGRAD9W_DBG"] = "0"
+    print(json.dumps({"splits": splits, **res}), flush=True)
