@@ -36,7 +36,9 @@ if which in ("all", "wgrad"):
     sweep = len(sys.argv) > 3 and sys.argv[3] == "sweep"
     # (round 4: these layers run on conv_wgrad3w_kernel, the wave-specialised kernel; 24 splits = the engine's count in the train step -- few,
     # long workgroups that leave the other CUs to the chain -- 80 = the one-round-of-the-chip count of the isolated comparison)
-    for splits in ((24, 40, 57, 80, 96, 120, 160) if sweep else (80, 24)):
+    # third argument: `sweep`, or ONE split count (so that a rocprofv3 average covers one configuration); default 80
+    arg3 = sys.argv[3] if len(sys.argv) > 3 else "80"
+    for splits in ((24, 40, 57, 80, 96, 120, 160) if sweep else (int(arg3),)):
         t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=st, splits=splits))
         print(json.dumps({"kernel": "conv_wgrad3w<norm> (wave-specialised, norm + ReLU in LDS) + reduce, splits %d" % splits, "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
         t = timeit(lambda: K.conv_wgrad(x, dy, F_, 3, 1, norm=None, splits=splits))

@@ -8,13 +8,17 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python3 $R/bench.py --steps 25 --warmup 5 --no-cpu-baseline --accuracy-steps 0 > $O/step_bench.json 2> $O/step.err
 PWR_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python3 $R/bench.py --debug-lib --steps 25 --warmup 5 --no-cpu-baseline --accuracy-steps 0 > $O/serial_bench.json 2> $O/serial.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roof -o roof -- python3 $R/bench.py --roofline-only > $O/roofline_only.json 2> $O/roof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso -o iso -- python3 $R/tools/bench_kernels.py all 20 > $O/iso_bench.jsonl 2> $O/iso.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso -o iso -- python3 $R/tools/bench_kernels.py all 20 80 > $O/iso_bench.jsonl 2> $O/iso.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso24 -o iso24 -- python3 $R/tools/bench_kernels.py wgrad 20 24 > $O/iso24_bench.jsonl 2> $O/iso24.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec -o dec -- python3 $R/tools/bench_decoder.py > $O/dec_bench.jsonl 2> $O/dec.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/bench_kernels.py all 3 > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/bench_kernels.py all 3 > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/bench_kernels.py all 3 80 > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/bench_kernels.py all 3 80 > /dev/null 2> $O/pmc_write.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_dec -o f -- python3 $R/tools/bench_decoder.py > /dev/null 2> $O/pmc_fetch_dec.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_dec -o w -- python3 $R/tools/bench_decoder.py > /dev/null 2> $O/pmc_write_dec.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python3 $R/tools/bench_kernels.py all 3 > /dev/null 2> $O/pmc_mfma.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o m -- python3 $R/tools/bench_kernels.py all 3 80 > /dev/null 2> $O/pmc_mfma.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma24 -o m -- python3 $R/tools/bench_kernels.py wgrad 3 24 > /dev/null 2> $O/pmc_mfma24.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch24 -o f -- python3 $R/tools/bench_kernels.py wgrad 3 24 > /dev/null 2> $O/pmc_fetch24.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write24 -o w -- python3 $R/tools/bench_kernels.py wgrad 3 24 > /dev/null 2> $O/pmc_write24.err
 cd $R
 python3 tools/profile_summary.py $O $O/summary r4 > $O/summary.log 2>&1; tail -60 $O/summary.log
 # keep the merge-back small: the raw traces are large
