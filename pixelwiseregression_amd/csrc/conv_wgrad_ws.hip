@@ -41,27 +41,35 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_ws;
 struct WgradPair { WgradParams a, b; };
 
 namespace ws {
-constexpr int KP = 32, XROWS = KP + 2, RB = 256;                 // K step, staged input pixels, bytes per staged pixel (128 ch bf16)
-constexpr int XCH = (XROWS * RB + 1023) / 1024, YCH = KP * RB / 1024, NCH = XCH + YCH;     // 1-KiB DMA pieces: 9 + 8
-constexpr int NLW = 4, NCW = (NCH + NLW - 1) / NLW;              // loader waves; pieces per loader wave and step (5, three of them padding)
-constexpr int XBYTES = XCH * 1024, STAGE = NCH * 1024;
+constexpr int KP = 32, XROWS = KP + 2, NLW = 4;                  // K step, staged input pixels, loader waves
 #ifndef PWR_WS_NS
 #define PWR_WS_NS 7
 #endif
 constexpr int NS = PWR_WS_NS, D = NS - 1;                        // ring stages; a step's pieces are issued D steps ahead
 constexpr int MAXSB = 8;                                         // norm states of at most this many samples per split
-constexpr int STATE_BYTES = MAXSB * 3 * 128 * 4;
-constexpr int LDS_BYTES = NS * STAGE + STATE_BYTES;
+// geometry for an input tile of BMT channels (128: the heads' convs; 64: the stem's 64 -> 128 conv); the dy tile is always 128 channels wide
+template <int BMT> struct Geo {
+  static constexpr int RBX = BMT * 2, RBY = 256;                 // bytes per staged pixel
+  static constexpr int SPR = RBX / 16;                           // 16-byte slots per input pixel
+  static constexpr int XCH = (XROWS * RBX + 1023) / 1024, YCH = KP * RBY / 1024, NCH = XCH + YCH;     // 1-KiB DMA pieces: 9 + 8 / 5 + 8
+  static constexpr int NCW = (NCH + NLW - 1) / NLW;              // pieces of loader wave 0 per step (5 / 4); the other waves issue NCW - 1
+  static constexpr int XBYTES = XCH * 1024, STAGE = NCH * 1024;
+  static constexpr int STATE_BYTES = MAXSB * 3 * BMT * 4;
+  static constexpr int LDS_BYTES = NS * STAGE + STATE_BYTES;
+};
 
-// byte offset of 16-byte slot `slot` of row `row` (256-byte rows)
-__device__ __forceinline__ int swz(int row, int slot) { return row * RB + ((slot ^ ((row & 3) << 2)) << 4); }
+// byte offset of 16-byte slot `slot` of row `row`: 256-byte rows XOR the slot with (row & 3) << 2, 128-byte rows with ((row >> 1) & 1) << 2
+// (conv_wgrad_dma.hip: wswz) -- the four pixel rows of a ds_read_b64_tr_b16 group fall on four different bank quarters either way, and
+// both patterns repeat every 4 rows
+template <int RB> __device__ __forceinline__ int swzbits(int row) { return RB == 256 ? (row & 3) << 2 : ((row >> 1) & 1) << 2; }
+template <int RB> __device__ __forceinline__ int swz(int row, int slot) { return row * RB + ((slot ^ swzbits<RB>(row)) << 4); }
 // lane part of the address of an MFMA 32x32x16 operand fragment read by two ds_read_b64_tr_b16 (rows +0 / +4): 8 K values = pixels
 // k0 + 8 (lane / 32) .. + 7 of channel chb + lane % 32 (conv_wgrad_dma.hip: wfrag_lane)
-__device__ __forceinline__ int frag_lane(int k0, int chb, int lane) {
+template <int RB> __device__ __forceinline__ int frag_lane(int k0, int chb, int lane) {
   const int li = lane & 15, cg = (lane >> 4) & 1, h = lane >> 5, q = li >> 2, pp = li & 3;
-  return swz(k0 + 8 * h + q, (chb >> 3) + 2 * cg + (pp >> 1)) + 8 * (pp & 1);
+  return swz<RB>(k0 + 8 * h + q, (chb >> 3) + 2 * cg + (pp >> 1)) + 8 * (pp & 1);
 }
-__device__ __forceinline__ bf16x8 frag(const char* a) {
+template <int RB> __device__ __forceinline__ bf16x8 frag(const char* a) {
   typedef __attribute__((address_space(3))) bf16x4_ws* lptr;
   const bf16x4_ws lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)a);
   const bf16x4_ws hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(a + 4 * RB));
@@ -72,9 +80,13 @@ __device__ __forceinline__ bf16x8 frag(const char* a) {
 constexpr unsigned vmwait(int n) { return (unsigned)((n & 15) | ((n >> 4) << 14) | 0x0070); }      // s_waitcnt vmcnt(n) lgkmcnt(0)
 }  // namespace ws
 
-template <bool NRM, bool RELU>
+template <bool NRM, bool RELU, int BMT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
   using namespace ws;
+  typedef Geo<BMT> G;
+  constexpr int RBX = G::RBX, RBY = G::RBY, SPR = G::SPR, XCH = G::XCH, NCH = G::NCH, NCW = G::NCW, XBYTES = G::XBYTES, STAGE = G::STAGE;
+  constexpr int LDS_BYTES = G::LDS_BYTES;
+  constexpr int MI = BMT / 64;                                   // 32-channel input blocks per MFMA wave (the wave's tile: 32 MI ci x 64 co x 3 taps)
   typedef bf16_t T;
   typedef bf16x8 V;
   const WgradParams p = blockIdx.z ? g.b : g.a;          // (by value: scalar registers, no kernarg reloads inside the loops)
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
   if (split >= p.S) return;
   const int ntn = p.CoutPad / 128;
   const int mtile = blockIdx.y / ntn, ntile = blockIdx.y - mtile * ntn;
-  const int ci0 = mtile * 128, co0 = ntile * 128;
+  const int ci0 = mtile * BMT, co0 = ntile * 128;
   const int step0 = split * p.steps_per_split;
   const int total_steps = p.M / KP;
   int nsteps = total_steps - step0;
@@ -105,9 +117,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
     const size_t plane = (size_t)p.B * p.Cin;
     float* stl = reinterpret_cast<float*>(smem + NS * STAGE);
     const int lastb = (step0 + (nsteps > 0 ? nsteps - 1 : 0)) / (p.H * tiles_x);
-    const int cnt = (lastb - b0 + 1) * 3 * 128;
+    const int cnt = (lastb - b0 + 1) * 3 * BMT;
     for (int idx = tid; idx < cnt; idx += 512) {
-      const int sb = idx / (3 * 128), k = (idx >> 7) % 3, ch = idx & 127;
+      const int sb = idx / (3 * BMT), k = (idx / BMT) % 3, ch = idx % BMT;
       stl[idx] = p.in_norm[(size_t)(k == 0 ? 0 : k + 1) * plane + (size_t)(b0 + sb) * p.Cin + ci0 + ch];
     }
     __syncthreads();
@@ -120,8 +132,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
     const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
     // per-lane descriptors of this wave's DMA pieces (constant over the steps; only the tile origin moves): loader wave lw issues the
     // pieces lw, lw + 4, ... -- five for wave 0 (it holds the halo pixels 0 and 33, pieces 0 and 8: one clamp delta each), four for the others
-    constexpr int I_R = ((XROWS - 1) * RB / 1024) / NLW;
-    static_assert(((XROWS - 1) * RB / 1024) % NLW == 0 && I_R != 0 && I_R < NCW && NCH == NLW * (NCW - 1) + 1, "wave 0: NCW pieces, the others NCW - 1");
+    constexpr int I_R = ((XROWS - 1) * RBX / 1024) / NLW;
+    static_assert(((XROWS - 1) * RBX / 1024) % NLW == 0 && I_R != 0 && I_R < NCW && NCH == NLW * (NCW - 1) + 1, "wave 0: NCW pieces, the others NCW - 1");
     int d_lds[NCW], d_off[NCW], d_dl = 0, d_dr = 0;
     bool d_isx[NCW];
 #pragma unroll
@@ -132,11 +144,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       d_isx[i] = c < XCH;
       const int cx_ = c < XCH ? c : c - XCH;
       const int q = 64 * cx_ + lane;
-      const int r0 = q >> 4, s1 = q & 15;             // row and physical slot of this lane's 16 bytes
-      const int xr = r0 < XROWS ? r0 : XROWS - 1;     // rows beyond the 34th: nobody reads them
-      const int sl = s1 ^ ((r0 & 3) << 2);            // the channel slot that belongs there
-      const int xoff = (xr - 1) * p.Cin + ci0 + 8 * sl;
-      const int yoff = r0 * p.Cout + co0 + 8 * sl;
+      // row and physical slot of this lane's 16 bytes, and the channel slot that belongs there (input tile: SPR slots per pixel; dy: 16)
+      const int xr0 = q / SPR, xs1 = q % SPR, yr0 = q >> 4, ys1 = q & 15;
+      const int xr = xr0 < XROWS ? xr0 : XROWS - 1;   // rows beyond the 34th: nobody reads them
+      const int xoff = (xr - 1) * p.Cin + ci0 + 8 * (xs1 ^ swzbits<RBX>(xr0));
+      const int yoff = yr0 * p.Cout + co0 + 8 * (ys1 ^ swzbits<RBY>(yr0));
       d_off[i] = d_isx[i] ? xoff : yoff;
       if (i == 0) d_dl = (d_isx[i] && xr == 0) ? p.Cin : 0;              // out-of-image halo: clamped into the row, zeroed in LDS afterwards
       if (i == I_R) d_dr = (d_isx[i] && xr == XROWS - 1) ? -p.Cin : 0;
@@ -172,20 +184,24 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
     typedef __attribute__((address_space(3))) char* lds_ptr;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
     const unsigned nrl = lds0 + lt * 16;
-    const int nr_row = lt >> 4;
-    const int nr_ch = 8 * ((lt & 15) ^ ((nr_row & 3) << 2));      // first of the eight channels (relative to ci0)
-    const bool third = lt >= 192 && lt < 224;                     // (wave 3 only)
-    constexpr int OFF3 = (512 - 192) * 16;                        // byte offset of the third slot from the first
+    // (BMT = 64: the tile has 34 x 8 = 272 slots: slot lt, and the 16 slots of rows 32, 33 for the threads 192 .. 207 = rows 24, 25 + 8)
+    const int nr_row = lt / SPR;
+    const int nr_ch = 8 * ((lt % SPR) ^ swzbits<RBX>(nr_row));     // first of the eight channels (relative to ci0)
+    constexpr int NEXTRA = 2 * SPR;                                // slots of the rows 32 and 33
+    const bool third = lt >= 192 && lt < 192 + NEXTRA;            // (wave 3 only)
+    constexpr int OFF3 = (32 * SPR - 192) * 16;                    // byte offset of the third slot from the first
+    constexpr bool TWO = BMT == 128;                              // a second main slot (lt + 256) exists
     float mu[8], sc[8], be[8];
     int state_b = -1;
     int nb = b0, ny = y0, nx = x0;                                // tile coordinates of the step whose tile is processed next
     auto nr_state = [&]() {                                       // (a change of sample: at most every H * W / 32 steps)
       if (nb != state_b) {
-        const unsigned a = lds0 + NS * STAGE + (nb - b0) * (3 * 128 * 4) + nr_ch * 4;
+        const unsigned a = lds0 + NS * STAGE + (nb - b0) * (3 * BMT * 4) + nr_ch * 4;
         f32x4 q0, q1, q2, q3, q4, q5;
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:512\n\tds_read_b128 %3, %6 offset:528\n\t"
-                     "ds_read_b128 %4, %6 offset:1024\n\tds_read_b128 %5, %6 offset:1040\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(a) : "memory");
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:%7\n\tds_read_b128 %3, %6 offset:%8\n\t"
+                     "ds_read_b128 %4, %6 offset:%9\n\tds_read_b128 %5, %6 offset:%10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5)
+                     : "v"(a), "n"(BMT * 4), "n"(BMT * 4 + 16), "n"(2 * BMT * 4), "n"(2 * BMT * 4 + 16) : "memory");
 #pragma unroll
         for (int e = 0; e < 4; ++e) { mu[e] = q0[e]; mu[4 + e] = q1[e]; sc[e] = q2[e]; sc[4 + e] = q3[e]; be[e] = q4[e]; be[4 + e] = q5[e]; }
         state_b = nb;
@@ -230,9 +246,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
         f32x4 o0, o1;
 #ifdef PWR_DEBUG_BUILD
         if (p.dbg & 1) { o0 = r0; o1 = r1; }                       // elimination: no norm arithmetic (raw values stored back)
-        else { o0 = nr_math(r0); o1 = nr_math(r1); }
+        else { o0 = nr_math(r0); o1 = TWO ? nr_math(r1) : r1; }
 #else
-        o0 = nr_math(r0); o1 = nr_math(r1);
+        o0 = nr_math(r0); o1 = TWO ? nr_math(r1) : r1;
 #endif
         if (rowzero | zl | zr) {                                   // (wave-uniform, rare: image borders)
           if (rowzero || (zl && nr_row == 0)) o0 = zero4;
@@ -244,21 +260,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
 #endif
         {
           asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(o0) : "memory");
-          asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(o1) : "memory");
+          if constexpr (TWO) asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(o1) : "memory");
         }
         if (lw == NLW - 1) {                                       // (wave-uniform: the wave that owns rows 32 and 33)
           f32x4 o2 = nr_math(r2);
-          if (rowzero || (zr && lt >= 208)) o2 = zero4;            // (threads 208 .. 223 hold row 33)
+          if (rowzero || (zr && lt >= 192 + SPR)) o2 = zero4;      // (the upper half of the extra threads holds row 33)
           if (third) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(o2), "n"(OFF3) : "memory");
         }
       } else {
         if (rowzero) {
           asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(zero4) : "memory");
-          asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(zero4) : "memory");
+          if constexpr (TWO) asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(zero4) : "memory");
           if (third) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(zero4), "n"(OFF3) : "memory");
-        } else if (lt < 16) {                                      // one 256-byte pixel row = 16 slots
+        } else if (lt < SPR) {                                     // one pixel row = SPR slots
           if (zl) asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(zero4) : "memory");
-          if (zr) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(zero4), "n"((XROWS - 1) * RB) : "memory");
+          if (zr) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(zero4), "n"((XROWS - 1) * RBX) : "memory");
         }
       }
       if (++nx == tiles_x) { nx = 0; if (++ny == p.H) { ny = 0; ++nb; } }
@@ -342,48 +358,50 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
 
   // ===================================================================== MFMA waves
   const int wm = wid >> 1, wn = wid & 1;
-  f32x16 acc[3][2][2];
+  f32x16 acc[3][MI][2];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
   // lane parts of the fragment addresses: input tile per (tap, 32-channel block), dy tile per 32-channel block
-  const char* xl[3][2];
+  const char* xl[3][MI];
   const char* yl[2];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xl[t][i] = smem + frag_lane(t, wm * 64 + i * 32, lane);
+    for (int i = 0; i < MI; ++i) xl[t][i] = smem + frag_lane<RBX>(t, wm * (BMT / 2) + i * 32, lane);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) yl[j] = smem + XBYTES + frag_lane(0, wn * 64 + j * 32, lane);
+  for (int j = 0; j < 2; ++j) yl[j] = smem + XBYTES + frag_lane<RBY>(0, wn * 64 + j * 32, lane);
 
   // unit u = (K half h = u / 3, tap t = u % 3): two input fragments (the wave's two 32-channel blocks), four MFMAs against the two dy
   // fragments of half h.  Input fragments in a ring of three units (read two units ahead), dy fragments double-buffered by half.
-  V A[3][2], Bf[2][2];
-  auto loadA = [&](V (&a)[2], int soff, int u) {
+  V A[3][MI], Bf[2][2];
+  auto loadA = [&](V (&a)[MI], int soff, int u) {
     const int h = u / 3, t = u - 3 * h;
-    a[0] = frag(xl[t][0] + soff + h * 16 * RB);
-    a[1] = frag(xl[t][1] + soff + h * 16 * RB);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[i] = frag<RBX>(xl[t][i] + soff + h * 16 * RBX);
   };
   auto loadB = [&](V (&b)[2], int soff, int h) {
-    b[0] = frag(yl[0] + soff + h * 16 * RB);
-    b[1] = frag(yl[1] + soff + h * 16 * RB);
+    b[0] = frag<RBY>(yl[0] + soff + h * 16 * RBY);
+    b[1] = frag<RBY>(yl[1] + soff + h * 16 * RBY);
   };
-  auto mma = [&](int t, const V (&a)[2], const V (&b)[2]) {
+  auto mma = [&](int t, const V (&a)[MI], const V (&b)[2]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
   };
-  // interleave: one MFMA, then the next unit's LDS reads behind it
+  // interleave: one MFMA, then the next unit's LDS reads behind it (a unit = 2 MI MFMAs; its reads: 2 MI for the input fragments, + 4 where
+  // a dy pair is read)
+  constexpr int RA = 2 * MI, RAB = 2 * MI + 4, MREST = 2 * MI - 1;
 #define PWR_WS_SCHED(reads)                                  \
   __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
   __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);   \
-  __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, MREST, 0);
 
   __syncthreads();                                                 // (P)
   __syncthreads();                                                 // barrier 0: stages 0 and 1 are complete
@@ -401,13 +419,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
     // for bit, one straight-line loop body; a branch around the MFMAs made the register allocator copy the 192 accumulators between the
     // two paths and spill them)
     loadA(A[2], soff, 2); loadB(Bf[1], soff, 1);
-    mma(0, A[0], Bf[0]); PWR_WS_SCHED(8)
-    loadA(A[0], soff, 3); mma(1, A[1], Bf[0]); PWR_WS_SCHED(4)
-    loadA(A[1], soff, 4); mma(2, A[2], Bf[0]); PWR_WS_SCHED(4)
+    mma(0, A[0], Bf[0]); PWR_WS_SCHED(RAB)
+    loadA(A[0], soff, 3); mma(1, A[1], Bf[0]); PWR_WS_SCHED(RA)
+    loadA(A[1], soff, 4); mma(2, A[2], Bf[0]); PWR_WS_SCHED(RA)
     loadA(A[2], soff, 5); loadB(Bf[0], noff, 0);
-    mma(0, A[0], Bf[1]); PWR_WS_SCHED(8)
-    loadA(A[0], noff, 0); mma(1, A[1], Bf[1]); PWR_WS_SCHED(4)
-    loadA(A[1], noff, 1); mma(2, A[2], Bf[1]); PWR_WS_SCHED(4)
+    mma(0, A[0], Bf[1]); PWR_WS_SCHED(RAB)
+    loadA(A[0], noff, 0); mma(1, A[1], Bf[1]); PWR_WS_SCHED(RA)
+    loadA(A[1], noff, 1); mma(2, A[2], Bf[1]); PWR_WS_SCHED(RA)
     stg = nstg;
     __syncthreads();                                               // barrier s + 1: this wave's reads of stage s have retired; stage s + 2 is complete
   }
@@ -417,22 +435,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
   for (int t = 0; t < 3; ++t) {
     float* __restrict__ out = p.slab + ((size_t)(split * 9 + ky * 3 + t) * p.CinPad) * p.CoutPad;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int ci = ci0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int ci = ci0 + wm * (BMT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const int co = co0 + wn * 64 + j * 32 + r;
           out[(size_t)ci * p.CoutPad + co] = acc[t][i][j][e];
         }
   }
 }
 
-// 3x3 stride 1, 32-pixel row segments, whole 128-channel tiles on both sides; a split spans at most MAXSB samples' norm states
+// 3x3 stride 1, 32-pixel row segments, whole 128-channel output tiles, input channels a multiple of 128 (128-channel input tiles; the
+// kernel is also generic over a 64-channel input tile -- the stem's 64 -> 128 conv, model.py:174 -- which the debug build can select); a
+// split spans at most MAXSB samples' norm states
 bool wgrad3w_applicable(const WgradParams& p) {
-  const bool on = PWR_DBG_ENV("PWR_WGRAD3W", 1) != 0;      // (debug build: read per call, so that one process can A/B the kernels)
-  if (!on || p.ksize != 3 || p.stride != 1 || p.W % 32 || p.M % 32 || p.Cin % 128 || p.Cout % 128 || p.CoutPad != p.Cout || p.CinPad != p.Cin) return false;
+  // (debug build: read per call, so that one process can A/B the kernels; 3 = also the 64-channel input tile -- the stem's 64 -> 128 conv:
+  // measured no gain in the train step, 5.81 - 5.84 ms with 48 - 96 splits against 5.81 - 5.83 on the register-staged kernel, so the
+  // shipped library takes 128-channel input tiles only)
+  const int on = PWR_DBG_ENV("PWR_WGRAD3W", 1);
+  const bool cin_ok = p.Cin % 128 == 0 ? p.CinPad == p.Cin : (p.Cin == 64 && on == 3);
+  if (!on || p.ksize != 3 || p.stride != 1 || p.W % 32 || p.M % 32 || !cin_ok || p.Cout % 128 || p.CoutPad != p.Cout) return false;
   return p.steps_per_split <= (ws::MAXSB - 1) * (p.H * p.W / 32);
 }
 
@@ -443,10 +467,17 @@ int launch_wgrad3w(const WgradParams& a, const WgradParams* b, hipStream_t s) {
     return PWR_EINVAL;
   WgradPair g{a, b ? *b : a};
   g.a.dbg = g.b.dbg = PWR_DBG_ENV("PWR_WGRAD3W_DBG", 0);     // (debug build: timing by elimination, results are WRONG)
-  dim3 grid(24 * ((a.S + 7) / 8), (a.Cin / 128) * (a.Cout / 128), b ? 2 : 1), block(512);
-  if (a.in_norm && a.relu_in) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, true>), grid, block, 0, s, g);
-  else if (a.in_norm) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, false>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((conv_wgrad3w_kernel<false, false>), grid, block, 0, s, g);
+  const int bmt = a.Cin % 128 == 0 ? 128 : 64;
+  dim3 grid(24 * ((a.S + 7) / 8), (a.Cin / bmt) * (a.Cout / 128), b ? 2 : 1), block(512);
+  if (bmt == 128) {
+    if (a.in_norm && a.relu_in) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, true, 128>), grid, block, 0, s, g);
+    else if (a.in_norm) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, false, 128>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad3w_kernel<false, false, 128>), grid, block, 0, s, g);
+  } else {
+    if (a.in_norm && a.relu_in) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, true, 64>), grid, block, 0, s, g);
+    else if (a.in_norm) hipLaunchKernelGGL((conv_wgrad3w_kernel<true, false, 64>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad3w_kernel<false, false, 64>), grid, block, 0, s, g);
+  }
   return (int)hipGetLastError();
 }
 

@@ -308,9 +308,12 @@ struct Engine {
     // and the other CUs stay free for the chain: measured on the train step (same box, profiles/r4_experiments.md): 80 splits (240
     // workgroups: every small chain kernel waits for a CU) 6.28 ms, 48: 6.00, 32: 5.91, 24: 5.82 - 5.87, 16: 5.97, 12: 6.45; the
     // register-staged kernel at its 80 splits: 6.01 - 6.14.  At least one split per six samples (the kernel keeps <= 8 samples' norm states).
-    if (w3 && cin % 128 == 0 && cout % 128 == 0 && PWR_DBG_ENV("PWR_WGRAD3W", 1)) {
+    const int ws_on = PWR_DBG_ENV("PWR_WGRAD3W", 1);
+    if (w3 && (cin % 128 == 0 || (cin == 64 && ws_on == 3)) && cout % 128 == 0 && ws_on) {
       // (nine-tap form: (cin / 64) x (cout / 64) workgroups per split; three-tap form, debug build: 3 x per)
       s = PWR_DBG_ENV("PWR_WGRAD9W", 0) ? PWR_DBG_ENV("PWR_WGRAD9W_WGS", 72) / (4 * per) : PWR_DBG_ENV("PWR_WGRAD3W_SPLITS", 24) / per;
+      // (the stem's 64 -> 128 layer at 128 x 128: four times the K extent of a head layer at half the work per K step: twice the workgroups)
+      if (cin == 64) s = PWR_DBG_ENV("PWR_WGRAD3W_SPLITS64", 48) / per;
       if (s < (B + 5) / 6) s = (B + 5) / 6;
       if (s < 1) s = 1;
     }

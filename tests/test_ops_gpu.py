@@ -708,7 +708,7 @@ def test_conv_dgrad_pair_launch(B, H, W, Cin):
 
 
 @pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 85), (5, 64, 64, 128, 128, 37), (3, 20, 96, 128, 128, 24), (2, 8, 32, 128, 256, 3), (2, 32, 32, 256, 128, 8),
-                                  (32, 64, 64, 128, 128, 85)])
+                                  (32, 64, 64, 128, 128, 85), (2, 128, 128, 64, 128, 40), (3, 20, 96, 64, 128, 12), (5, 8, 32, 64, 256, 3)])
 @pytest.mark.parametrize("prologue", [False, True])
 def test_wgrad3_wave_specialised(case, prologue):
     """conv_wgrad_ws.hip (whole 128-channel tiles: 4 MFMA waves + 4 loader waves per workgroup, the operand's norm + ReLU applied in LDS by
