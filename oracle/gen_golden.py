@@ -27,7 +27,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def import_reference():
     sys.dont_write_bytecode = True
-    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    try:                                # a real OpenCV, where there is one, is used as it is (none in the build image)
+        import cv2                      # noqa: F401
+    except ImportError:
+        sys.modules["cv2"] = types.ModuleType("cv2")
     tv = types.ModuleType("torchvision")
     sys.modules.setdefault("torchvision", tv)
     ray = types.ModuleType("ray")
@@ -326,10 +329,13 @@ def gen_preprocess(ref_utils, ref_datasets):
     import random
     from oracle import preprocess_ref as PR, targets_ref as TR
     cv2 = sys.modules["cv2"]
-    cv2.resize = lambda img, dsize: PR.resize_linear(img, dsize)
-    cv2.getRotationMatrix2D = PR.rotation_matrix
-    cv2.warpAffine = lambda img, M, dsize: PR.warp_affine(img, M, dsize)
-    cv2.GaussianBlur = lambda img, ks, sig: TR.gaussian_blur(np.asarray(img, dtype=np.float64), ks[0], sig)
+    if getattr(cv2, "__file__", None) is None:              # the empty stand-in of import_reference(): cv2 is absent
+        cv2.resize = lambda img, dsize: PR.resize_linear(img, dsize)
+        cv2.getRotationMatrix2D = PR.rotation_matrix
+        cv2.warpAffine = lambda img, M, dsize: PR.warp_affine(img, M, dsize)
+        cv2.GaussianBlur = lambda img, ks, sig: TR.gaussian_blur(np.asarray(img, dtype=np.float64), ks[0], sig)
+    else:
+        print("gen_preprocess: using the installed OpenCV", cv2.__version__, "-- the fixture is pinned to cv2 itself")
     fx, fy, hu, hv = 588.037, 587.075, 320.0, 240.0          # NYU, datasets.py:693
     H, W, J, S, P = 480, 640, 14, 128, 64
 
