@@ -676,14 +676,22 @@ __global__ __launch_bounds__(256, PWR_OCC2(true)) void conv_wgrad_tr_group_kerne
 // ---------------------------------------------------------------------------------------------
 // DBG (only instantiated in the debug build, tools/build_debug.py; PWR_WGRAD3_DBG selects): timing by elimination, results are WRONG --
 // 1 no MFMAs, 2 no fragment reads, 4 no norm / ReLU math in the staging, 16 no staging stores, 32 no global loads in the loop
-template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0>
+// STR = 2 (round 4, second session): the STRIDE-2 3x3 conv (the stem's last layer, model.py:182).  A K tile is still 32 consecutive OUTPUT pixels of
+// one output row oy; tap (ky, kx) reads input pixel (2 oy + ky - 1, 2 ox + kx - 1), so the workgroup of kernel row ky stages the 65
+// consecutive input pixels 2 ox0 - 1 ... 2 ox0 + 63 of input row 2 oy + ky - 1 (norm + ReLU on the way, column -1 = the conv's zero
+// padding) and the fragment of tap kx reads every SECOND staged row starting at row kx -- ds_read_b64_tr_b16 with twice the row pitch.
+// The pitch is 2 C + 32 bytes here, so that the four (double-pitch) pixel rows of a 16-lane group still fall on different banks.  The
+// layer ran on the one-tap-per-workgroup gather kernel before (296 us alone, 540 us at the tail of the train step for the FLOPs of a
+// 44-us head layer: a global round trip and integer divisions per 32-pixel K step).
+template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0, int STR = 1>
 __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wgrad3_kernel(WgradParams p) {
   static_assert(DEPTH >= 2 && DEPTH % 2 == 0, "register stages: even, so that the LDS buffer parity follows the step parity");
+  static_assert(STR == 1 || STR == 2, "stride 1 or 2");
   typedef bf16_t T;
   typedef bf16x8 V;
-  constexpr int KP = 32, EP = 8, AP = KP + 2;
+  constexpr int KP = 32, EP = 8, AP = STR == 1 ? KP + 2 : 2 * KP + 1;
   constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
-  constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;
+  constexpr int PA = BM * 2 + (STR == 1 ? 64 : 32), PB = BN * 2 + 64;
   constexpr int TILE_A = AP * PA, TILE_B = KP * PB;
   constexpr int ACH = BM / EP, BCH = BN / EP;
   constexpr int NA = (AP * ACH + 255) / 256, NBL = (KP * BCH + 255) / 256;
@@ -706,15 +714,16 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
   const int total_steps = p.M / KP;                 // W % 32 == 0 -> M % 32 == 0
   int nsteps = total_steps - step0;
   if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
-  const int tiles_x = p.W / KP;
+  const int OHt = STR == 1 ? p.H : p.Ho;            // rows of the image the K tiles walk (the output)
+  const int tiles_x = (STR == 1 ? p.W : p.Wo) / KP;
   const size_t plane = (size_t)p.B * p.Cin;
 
   // tile coordinates of step `st` (incremental, no divisions in the loop)
   int tb, ty, tx;   // batch, row, x tile of the NEXT tile to be loaded
   {
     const int t0 = step0;
-    tb = t0 / (p.H * tiles_x);
-    const int rem = t0 - tb * p.H * tiles_x;
+    tb = t0 / (OHt * tiles_x);
+    const int rem = t0 - tb * OHt * tiles_x;
     ty = rem / tiles_x; tx = rem - ty * tiles_x;
   }
   // (never past the last tile of this split: the loaders run unconditionally -- a load inside a branch makes the compiler's
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
   // and simply re-read the last tile when there is nothing left to fetch)
   int issued = 0;
   auto advance = [&]() {
-    if (++issued < nsteps) { if (++tx == tiles_x) { tx = 0; if (++ty == p.H) { ty = 0; ++tb; } } }
+    if (++issued < nsteps) { if (++tx == tiles_x) { tx = 0; if (++ty == OHt) { ty = 0; ++tb; } } }
   };
 
   // per-thread NR state for its channel chunk (reloaded when the batch index changes)
@@ -751,7 +760,7 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
     const int pix = c / ACH, cq = c % ACH;     // ACH is a power of two
     const bool chok = ci0 + cq * EP < p.Cin;
     a_in[i] = c < AP * ACH && chok;
-    a_left[i] = pix == 0; a_right[i] = pix == AP - 1;
+    a_left[i] = pix == 0; a_right[i] = STR == 1 && pix == AP - 1;      // (stride 2: the last staged column 2 ox0 + 63 is always inside)
     a_off[i] = a_in[i] ? (pix - 1) * p.Cin + ci0 + cq * EP : 0;
     a_lds[i] = (c < AP * ACH ? pix : 0) * PA + cq * 16;
   }
@@ -766,11 +775,11 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
   struct Stage { V a[NA]; V b[NBL]; unsigned okmask; int bidx; bool rowok; };
   Stage sg[DEPTH];   // tiles st+1 .. st+DEPTH-1 in registers (global latency budget: DEPTH-1 steps), tile st in LDS
   auto load_global = [&](Stage& S) {
-    const int iy = ty + ky - 1;
+    const int iy = STR * ty + ky - 1;
     S.rowok = iy >= 0 && iy < p.H;
     S.bidx = tb;
-    const T* xrow = x + (((long long)tb * p.H + (S.rowok ? iy : ty)) * p.W + tx * KP) * p.Cin;
-    const T* drow = dy + (((long long)tb * p.H + ty) * p.W + tx * KP) * p.Cout;
+    const T* xrow = x + (((long long)tb * p.H + (S.rowok ? iy : STR * ty)) * p.W + STR * tx * KP) * p.Cin;
+    const T* drow = dy + (((long long)tb * OHt + ty) * (tiles_x * KP) + tx * KP) * p.Cout;
     const bool first = tx == 0, last = tx == tiles_x - 1;
     unsigned okm = 0;
 #pragma unroll
@@ -841,7 +850,10 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int i = 0; i < MR; ++i) af[ss][t][i] = (DBG & 2) ? V{(bf16_t)(float)(lane + t)} : frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane);
+          for (int i = 0; i < MR; ++i)
+            af[ss][t][i] = (DBG & 2) ? V{(bf16_t)(float)(lane + t)}
+                                     : (STR == 1 ? frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane)
+                                                 : frag_tr(lA + t * PA, 2 * PA, ss * 16, wm * MR * 32 + i * 32, lane));
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss)
@@ -1038,6 +1050,13 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
     if (wgrad9w_applicable(p)) return launch_wgrad9w(p, s);                  // whole 128-channel tiles: the wave-specialised nine-tap kernel
     if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // (its three-tap predecessor: debug build, PWR_WGRAD9W=0)
     if (wgrad3d_applicable(p)) return launch_wgrad3d(p, s);                  // operands by LDS-DMA (no norm to apply on the way)
+    if (p.ksize == 3 && p.stride == 2 && p.Wo % 32 == 0 && p.H == 2 * p.Ho && p.W == 2 * p.Wo && bn == 128 && p.Cin % 64 == 0 &&
+        PWR_DBG_ENV("PWR_WGRAD3_S2", 1)) {
+      // the stride-2 form of the three-tap kernel (64 (ci) x 128 (co) tile, two workgroups per CU)
+      dim3 g64(24 * ((p.S + 7) / 8), (p.Cin / 64) * (p.CoutPad / bn), 1);
+      hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 0, 2>), g64, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
     if (p.ksize == 3 && p.stride == 1 && p.W % 32 == 0 && p.M % 32 == 0) {   // three taps per workgroup
       dim3 g3(24 * ((p.S + 7) / 8), grid.y, 1);
       // 128 output channels: 64 (ci) x 128 (co) x 3 taps per workgroup = 96 accumulator registers -> TWO workgroups per CU,

@@ -61,6 +61,11 @@ struct Ctx {
   size_t slab_off = 0, slab_stride = 0;   // byte offset of the current stream's slab inside the slab scratch
   bool use_side = true;
   bool attached = false;    // side streams / events taken from the process-wide pool
+  // Side ops held back while `defer` is set (run_on_side appends them here), issued by the op that clears it: the heads' weight gradients
+  // wait until the heads' data-gradient chain -- full-chip kernels -- has been issued and then run beside the hourglass backward, whose
+  // kernels are small (Engine::heads_bwd)
+  std::vector<std::function<int(Ctx&)>> deferred;
+  bool defer = false;
 };
 
 // The side streams, their join events and the pool of fork events are PROCESS-wide (one set per device), shared by every engine:
@@ -142,6 +147,7 @@ static int elim_mask() {
 static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
   if (elim_mask() & 1) return 0;
   if (!c.use_side || c.n_side == 0) return op(c);
+  if (c.defer) { c.deferred.push_back(op); return 0; }
   const int k = c.side_rr;
   c.side_rr = (k + 1) % c.n_side;
   if (!(elim_mask() & 8)) {     // (bit 3, debug build: side ops NOT ordered behind the chain)
@@ -288,7 +294,7 @@ struct Engine {
     if (training) n.sums = alloc((size_t)2 * B * C * 4, "nsums");
     return n;   // (the backward partial slab is sized per tensor in norm_bwd)
   }
-  int splits_for(int M, int cin, int cout, int k) const {
+  int splits_for(int M, int cin, int cout, int k, int stride = 1) const {
     const int KE = dtype == PWR_BF16 ? 32 : 16;
     const int steps = (M + KE - 1) / KE;
     const int per = ((cin + 127) / 128) * (pwr_conv_out_pad(cout) / (cout > 64 ? 128 : (cout > 32 ? 64 : 32)));
@@ -309,7 +315,8 @@ struct Engine {
     // workgroups: every small chain kernel waits for a CU) 6.28 ms, 48: 6.00, 32: 5.91, 24: 5.82 - 5.87, 16: 5.97, 12: 6.45; the
     // register-staged kernel at its 80 splits: 6.01 - 6.14.  At least one split per six samples (the kernel keeps <= 8 samples' norm states).
     const int ws_on = PWR_DBG_ENV("PWR_WGRAD3W", 1);
-    if (w3 && (cin % 128 == 0 || (cin == 64 && ws_on == 3)) && cout % 128 == 0 && ws_on) {
+    // (stride 2 -- the stem's last conv -- runs the three-tap kernel's stride-2 form at the w3 split count: 2 x 3 x 80 workgroups)
+    if (w3 && stride == 1 && (cin % 128 == 0 || (cin == 64 && ws_on == 3)) && cout % 128 == 0 && ws_on) {
       // (nine-tap form: (cin / 64) x (cout / 64) workgroups per split; three-tap form, debug build: 3 x per)
       s = PWR_DBG_ENV("PWR_WGRAD9W", 0) ? PWR_DBG_ENV("PWR_WGRAD9W_WGS", 72) / (4 * per) : PWR_DBG_ENV("PWR_WGRAD3W_SPLITS", 24) / per;
       // (the stem's 64 -> 128 layer at 128 x 128: four times the K extent of a head layer at half the work per K step: twice the workgroups)
@@ -481,7 +488,7 @@ struct Engine {
     const bool has_nr = nr != nullptr;
     const NormL n = has_nr ? *nr : NormL{};
     const int M = B * y.H * y.W;
-    const int splits = splits_for(M, cv.Cin, cv.Cout, cv.k);
+    const int splits = splits_for(M, cv.Cin, cv.Cout, cv.k, cv.stride);
     want_slab(pwr_conv_wgrad_slab_bytes(cv.Cout, cv.Cin, cv.k, splits));
     want_slab((size_t)pwr_colsum_blocks(M) * cv.Cout * 4);
     Engine* E = this;
@@ -818,6 +825,14 @@ struct Engine {
     want_slab(2 * pwr_conv_wgrad_slab_bytes(F, F, ks, splits_pair));
     Engine* E = this;
     const Head P_ = hp, D_ = hd;
+    // The heads' weight gradients are HELD BACK until the heads' data-gradient chain has been issued (Ctx::deferred) and run beside the
+    // hourglass backward, whose kernels are small: issued as their operands became ready, two 72-CU weight-gradient launches at a time
+    // sat beside the heads' full-chip data gradients and norm backwards (paired data gradient 134 us against 92 alone).  Same launches,
+    // same results bit for bit; train step 5.77 -> 5.63 ms (same box, twice; three side streams or more splits on top: slower).
+    // (Rounds 1 and 3 measured the opposite with the full-chip weight-gradient kernels of the time: what changed is round 4's few, long
+    // workgroups.)  PWR_DEFER_HEADS=0 (debug build): the old order.
+    static const int defer_mode = PWR_DBG_ENV("PWR_DEFER_HEADS", 1);
+    if (defer_mode) bwd_cur.push_back([=](Ctx& c) { c.defer = true; return 0; });
     // ---- the heads' last convs (F -> J): output gradients to NHWC, bias sums, the two weight gradients, the paired data gradient
     bwd_cur.push_back([=](Ctx& c) {
       const Head* hs[2] = {&P_, &D_};
@@ -905,6 +920,17 @@ struct Engine {
       return pwr_conv_fwd(c.arena + D_.h1.goff, c.packs + D_.c0.pack_d, nullptr, nullptr, 0, c.arena + f.goff, c.arena + f.goff, nullptr, Bc, Pc, Pc, Fc, Fc, kk, 1, 0, dt,
                           c.stream);
     });
+    if (defer_mode) bwd_cur.push_back(flush_deferred_op());
+  }
+  static Op flush_deferred_op() {
+    return [](Ctx& c) {
+      c.defer = false;
+      std::vector<std::function<int(Ctx&)>> d;
+      d.swap(c.deferred);
+      int rc = 0;
+      for (size_t i = 0; i < d.size() && !rc; ++i) rc = run_on_side(c, d[i]);
+      return rc;
+    };
   }
 
   // ---------------------------------------------------------------- whole network
@@ -1221,6 +1247,7 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
   auto run = [&](void* st) -> int {
     c.stream = st;
     c.side_rr = 0;
+    c.defer = false; c.deferred.clear();
     if (seg == 0) {
       hipError_t er = hipMemsetAsync(c.grads, 0, (size_t)n_grad_floats * 4, (hipStream_t)st);
       if (er != hipSuccess) return (int)er;

@@ -252,6 +252,30 @@ def test_wgrad3_lds_dma_norm_in_lds(case):
     assert_close(outs[0].double().cpu(), w.grad, 1.5e-2, "LDS-DMA wgrad with the norm in LDS %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(2, 128, 128, 128, 128, 16), (3, 64, 64, 64, 128, 7), (2, 24, 64, 128, 128, 5), (5, 64, 128, 128, 128, 37)])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_wgrad3_stride2(case, prologue):
+    """conv_wgrad3_kernel<..., STR = 2>: the weight gradient of the stride-2 3x3 conv (model.py:182, the stem's last layer) on the three-tap
+    kernel -- 65 staged input pixels per 32-pixel K tile, fragments from every second staged row.  Against F.conv2d's float64 weight gradient
+    (image borders: input row / column -1 are the conv's zero padding; splits that straddle samples and leave a ragged last split), and
+    repeatable bit for bit."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, splits = case
+    x = rnd(B, Cin, H, W, seed=21)
+    xin = q(x, torch.bfloat16)
+    st = None
+    if prologue:
+        xin, st = apply_nr(xin, B, Cin, torch.bfloat16)
+    dy = rnd(B, Cout, H // 2, W // 2, seed=22)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w, None, stride=2, padding=1).backward(q(dy, torch.bfloat16))
+    xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
+    dw = K.conv_wgrad(xd, dyd, Cout, 3, 2, norm=st, relu_in=True, splits=splits).clone()
+    assert_close(dw.double().cpu(), w.grad, 1.5e-2, "stride-2 three-tap wgrad %s" % (case,))
+    for _ in range(3):
+        assert torch.equal(dw, K.conv_wgrad(xd, dyd, Cout, 3, 2, norm=st, relu_in=True, splits=splits))
+
+
 def test_grouped_weight_gradients_match_float64():
     """pwr_conv_wgrad_group: the 24 conv layers of one stage's small-map ResBlocks (16x16 .. 2x2, 1x1 128->64, 3x3 64->64, 1x1 64->128,
     norm + ReLU on the operand load) in ONE grouped launch, each against F.conv2d's float64 weight gradient; repeatable bit for bit."""
