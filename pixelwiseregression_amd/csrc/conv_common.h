@@ -27,6 +27,10 @@ struct ConvParams {
   const float* nb_state = nullptr;
   float* nb_partial = nullptr;
   int nb_relu = 1;
+  // slab row of a workgroup's statistics = b * st_nchunks + st_chunk0 + (its tile index inside the image); st_nchunks == 0: the tiles per
+  // image of this launch.  The four parity-class launches of a stride-2 data gradient (conv_patch.hip, GEO 2 - 5) write one slab between
+  // them: 4 x tiles rows per sample, class c at rows c * tiles ...
+  int st_nchunks = 0, st_chunk0 = 0;
   int epi16 = 1;            // (debug build: 0 = the two-pass fp32 epilogue also for the 16x16x32 tile)
 };
 
@@ -201,6 +205,7 @@ bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dt
 int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s);
 bool conv_tr2_applicable(const ConvParams& p, int dtype);   // stride-2 data gradient as four parity-class patch convs
 int launch_conv_tr2(const ConvParams& p, hipStream_t s);
+int conv_tr2_stats_chunks(const ConvParams& p, int dtype);   // slab rows per sample of its norm-backward sums, 0 = unsupported
 void set_debug_stamps(long long* ptr);
 
 // conv_wgrad_dma.hip: 3x3 weight gradient with both operands staged by LDS-DMA (operand already normalised: in_norm == null)

@@ -1063,6 +1063,17 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       // so one's norm/ReLU staging (VALU) and waits overlap the other's MFMAs; the x tile (the operand that needs VALU work)
       // is split between them, not duplicated.  (128 x 128 x 3 = 192 registers allows one wave per SIMD only: 25 % MFMA busy.)
       static const bool bm64 = (PWR_DBG_ENV("PWR_WGRAD3_BM64", 1) != 0);
+#ifdef PWR_DEBUG_BUILD
+      if (bn == 128 && p.Cin <= 64 && PWR_DBG_ENV("PWR_WGRAD3_CO64", 0)) {
+        // (experiment, debug build: the stem's 64 -> 128 conv at 128 x 128 as two 64 x 64 tiles per split = two workgroups per CU instead
+        // of one 64 x 128 tile = one per CU at the engine's 80 splits: 184 - 194 us against 176 - 184, no gain -- the loop is bound by the
+        // per-step round trip, not by the workgroups per CU)
+        dim3 g64(g3.x, p.CoutPad / 64, 1);
+        if (PWR_DBG_ENV("PWR_WGRAD3_DEPTH", 2) == 4) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1, 4>), g64, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1>), g64, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
+#endif
       if (bn == 128 && bm64) {
         dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
 #ifdef PWR_DEBUG_BUILD
@@ -1090,6 +1101,9 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       else if (bn == 64 && p.Cin <= 64 && PWR_DBG_ENV("PWR_WGRAD3_BM64N64", 1)) {
         // <= 64 input channels (the stem's 32 -> 64 conv, model.py:171): a 64 x 64 tile -- the 128-row tile multiplied 96 rows of zeros
         dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
+#ifdef PWR_DEBUG_BUILD
+        if (PWR_DBG_ENV("PWR_WGRAD3_DEPTH", 2) == 4) { hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1, 4>), g64, block, 0, s, p); return (int)hipGetLastError(); }
+#endif
         hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1>), g64, block, 0, s, p);
       }
       else if (bn == 64) hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 2, 1>), g3, block, 0, s, p);
@@ -1170,7 +1184,11 @@ extern "C" int pwr_conv_stats_chunks(int H, int W, int Cin, int Cout, int ksize,
   pwr::ConvParams p;
   if (conv_params_fill(p, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (void*)1, nullptr, 1, H, W, Cin, Cout, ksize, stride, mode, dtype)) return 0;
   static const bool on = (PWR_DBG_ENV("PWR_CONV_STATS", 1) != 0);
-  if (!on || mode != 0) return 0;
+  if (!on) return 0;
+  // mode 1 (the data gradient of a stride-2 conv, H x W = the gradient's map): the four parity-class launches of the patch kernel write the
+  // norm-backward sums of the tensor they produce (round 4; nb_partial only)
+  if (mode == 1) return (pwr::conv_tr2_applicable(p, dtype) && PWR_DBG_ENV("PWR_TR2_STATS", 1)) ? pwr::conv_tr2_stats_chunks(p, dtype) : 0;
+  if (mode != 0) return 0;
   if (pwr::conv_patch_applicable(p, dtype)) return pwr::conv_patch_stats_chunks(p, dtype);
   const int HoWo = p.Ho * p.Wo;
   return HoWo % 128 == 0 ? HoWo / 128 : 0;
@@ -1189,6 +1207,7 @@ extern "C" int pwr_conv_fwd_stats(const void* x, const void* wpack, const float*
   const int rc = conv_params_fill(p, x, wpack, bias, in_norm, relu_in, residual, y, nullptr, B, H, W, Cin, Cout, ksize, stride, mode, dtype);
   if (rc) return rc;
   if ((st_partial != nullptr) == (nb_partial != nullptr) || !y) return PWR_EINVAL;
+  if (mode == 1 && st_partial) return PWR_EUNSUPPORTED;
   if (pwr_conv_stats_chunks(H, W, Cin, Cout, ksize, stride, mode, dtype) == 0) return PWR_EUNSUPPORTED;
   p.st_partial = st_partial;
   p.nb_y = nb_y; p.nb_state = nb_state; p.nb_partial = nb_partial; p.nb_relu = nb_relu;

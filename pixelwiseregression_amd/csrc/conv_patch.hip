@@ -538,7 +538,8 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
 #pragma unroll
           for (int e = 0; e < EP; ++e) { est.s1[e] += __shfl_xor(est.s1[e], o, 64); est.s2[e] += __shfl_xor(est.s2[e], o, 64); }
         if (li == 0) {
-          float* out = est.kind == 1 ? p.st_partial + ((size_t)(b * tiles_img + tr) * 3) * p.Cout : p.nb_partial + ((size_t)(b * tiles_img + tr) * 2) * p.Cout;
+          const size_t srow = (size_t)b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
+          float* out = est.kind == 1 ? p.st_partial + (srow * 3) * p.Cout : p.nb_partial + (srow * 2) * p.Cout;
 #pragma unroll
           for (int e = 0; e < EP; ++e) {
             out[n + e] = est.s1[e];
@@ -690,7 +691,7 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
     }
     __syncthreads();
   }
-  if constexpr (TW == 32) est.template finish<CPRS, NT>(p, E, b, tr, tiles_img, n0);
+  if constexpr (TW == 32) est.template finish<CPRS, NT>(p, E, b, p.st_chunk0 + tr, p.st_nchunks ? p.st_nchunks : tiles_img, n0);
   stamp(p, 4);
 }
 
@@ -834,10 +835,16 @@ static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
 }
 
 // data gradient of a stride-2 3x3 conv (ConvParams::mode 1: x = dy [B,H,W,Cin], output [B,2H,2W,Cout]) as four parity-class launches
+int conv_tr2_stats_chunks(const ConvParams& p, int dtype);
 bool conv_tr2_applicable(const ConvParams& p, int dtype) {
   static const bool on = (PWR_DBG_ENV("PWR_PATCH_TR2", 1) != 0);
   return on && dtype == PWR_BF16 && p.mode == 1 && p.ksize == 3 && p.Cin == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr &&
-         !p.y_nchw && !p.st_partial && !p.nb_partial && !p.in_norm;
+         !p.y_nchw && !p.st_partial && !p.in_norm && (!p.nb_partial || conv_tr2_stats_chunks(p, dtype) > 0);
+}
+// norm-backward sums from the four class launches' epilogues (the 128-channel one-pass epilogue): slab rows per sample, 0 = not offered
+int conv_tr2_stats_chunks(const ConvParams& p, int dtype) {
+  if (dtype != PWR_BF16 || p.mode != 1 || p.ksize != 3 || p.Cin != 128 || p.W % 32 || p.H % 4 || p.Cout % 128 || p.residual) return 0;
+  return 4 * (p.H / 4) * (p.W / 32);
 }
 
 template <int GEO>
@@ -859,10 +866,12 @@ static void launch_tr2_class(const ConvParams& p, hipStream_t s) {
 int launch_conv_tr2(const ConvParams& p0, hipStream_t s) {
   ConvParams p = p0;
   p.stamps = nullptr;
-  launch_tr2_class<5>(p, s);     // (the four-tap class first: the longest)
-  launch_tr2_class<4>(p, s);
-  launch_tr2_class<3>(p, s);
-  launch_tr2_class<2>(p, s);
+  const int tiles = (p.H / 4) * (p.W / 32);
+  p.st_nchunks = 4 * tiles;      // (norm-backward sums: one slab, class c at rows c * tiles ... of every sample)
+  p.st_chunk0 = 3 * tiles; launch_tr2_class<5>(p, s);     // (the four-tap class first: the longest)
+  p.st_chunk0 = 2 * tiles; launch_tr2_class<4>(p, s);
+  p.st_chunk0 = 1 * tiles; launch_tr2_class<3>(p, s);
+  p.st_chunk0 = 0; launch_tr2_class<2>(p, s);
   return (int)hipGetLastError();
 }
 

@@ -305,7 +305,11 @@ struct Engine {
     static const int w3_target = PWR_DBG_ENV("PWR_WGRAD3_SLOTS", 256);
     // w3: one wave of workgroups, whole XCD groups (no tail).  The <= 64-channel kernels fit two workgroups per CU; on the big
     // stem maps (>= 2^18 pixels: 205 K steps per workgroup otherwise, at the tail of the step) they get two waves of them.
-    const int target = (w3 && cout <= 64 && M >= (1 << 18)) ? 2 * w3_target : w3_target;
+    // (PWR_STEM_SPLITS2X=1, debug build: also the stem's 64 -> 128 layer -- its 64 x 128 tile holds 96 accumulators, two workgroups fit a
+    // CU and 80 splits are ONE per CU: 180 us alone against 117 at 160 splits, and NOTHING in the train step, 5.57 ms either way: at the
+    // tail of the step the kernel shares the chip with the stem's data gradients whatever its split count)
+    const bool two_rounds = PWR_DBG_ENV("PWR_STEM_SPLITS2X", 0) ? (cin <= 64 || cout <= 64) : cout <= 64;
+    const int target = (w3 && two_rounds && M >= (1 << 18)) ? 2 * w3_target : w3_target;
     static const int tr_target = PWR_DBG_ENV("PWR_WGRAD_TR_SLOTS", 512);
     int s = w3 ? (target / tiles) / 8 * 8 : (tr_target + tiles - 1) / tiles;
     if (w3 && s < 8) s = 8;
@@ -479,8 +483,8 @@ struct Engine {
   // Returns the slab rows per sample of the norm-backward reductions that the data-gradient launch wrote for `nr`
   // (to be passed to norm_bwd), 0 if it did not.
   int dgrad_stats_chunks(const NormL* nr, const ConvL& cv, const Tn& y, bool accumulate_dx) const {
-    if (!nr || accumulate_dx || cv.stride != 1 || !(stats_mask() & 2)) return 0;
-    return pwr_conv_stats_chunks(y.H, y.W, cv.Cout, cv.Cin, cv.k, 1, 0, dtype);
+    if (!nr || accumulate_dx || cv.stride > 2 || !(stats_mask() & 2)) return 0;
+    return pwr_conv_stats_chunks(y.H, y.W, cv.Cout, cv.Cin, cv.k, 1, cv.stride == 2 ? 1 : 0, dtype);
   }
   int conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx,
                bool handoff = false) {
@@ -518,9 +522,9 @@ struct Engine {
         const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
         if (mode == 2)
           return pwr_conv_fwd(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, nullptr, Bc, y.H, y.W,
-                              cv.Cout, cv.Cin, cv.k, 1, 0, dt, c.stream);
+                              cv.Cout, cv.Cin, cv.k, 1, cv.stride == 2 ? 1 : 0, dt, c.stream);
         return pwr_conv_fwd_stats(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, Bc, y.H, y.W,
-                                  cv.Cout, cv.Cin, cv.k, 1, 0, nullptr, c.arena + x.off, (float*)(c.arena + n.state),
+                                  cv.Cout, cv.Cin, cv.k, 1, cv.stride == 2 ? 1 : 0, nullptr, c.arena + x.off, (float*)(c.arena + n.state),
                                   (float*)(c.arena + E->*cpart), 1, dt, c.stream);
       });
       return chunks;

@@ -337,21 +337,23 @@ def conv_stats_chunks(H, W, Cin, Cout, ksize, stride=1, mode=0, dtype=BF16):
 
 
 def conv_fwd_stats(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_in=True, residual=None, nb_y=None, nb_state=None,
-                   nb_relu=True):
+                   nb_relu=True, mode=0):
     """conv_fwd + column statistics from the epilogue.  nb_y is None: forward statistics of the output (for the norm that
     follows); else: the norm-backward sums of the produced gradient w.r.t. (nb_y, nb_state).  Returns y, partial, chunks."""
     l = _lib.lib()
     B, H, W, Cin = x.shape
     pad = ksize // 2
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
-    chunks = l.pwr_conv_stats_chunks(H, W, Cin, cout, ksize, stride, 0, _dt(x))
+    if mode == 1:       # the data gradient of a stride-2 conv: x is the gradient map, the output has twice its size
+        Ho, Wo = 2 * H, 2 * W
+    chunks = l.pwr_conv_stats_chunks(H, W, Cin, cout, ksize, stride, mode, _dt(x))
     if chunks <= 0:
         raise _lib.PwrError("conv shape does not support epilogue statistics")
     y = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
     partial = torch.full((B * chunks, 3 if nb_y is None else 2, cout), float("nan"), dtype=torch.float32, device=x.device)
     st, nbp = (partial, None) if nb_y is None else (None, partial)
     _lib.check(l.pwr_conv_fwd_stats(_p(x), _p(wpack), _p(bias), _p(norm), int(relu_in), _p(residual), _p(y), B, H, W, Cin, cout, ksize,
-                                    stride, 0, _p(st), _p(nb_y), _p(nb_state), _p(nbp), int(nb_relu), _dt(x), _s(x)), "pwr_conv_fwd_stats")
+                                    stride, mode, _p(st), _p(nb_y), _p(nb_state), _p(nbp), int(nb_relu), _dt(x), _s(x)), "pwr_conv_fwd_stats")
     return y, partial, chunks
 
 

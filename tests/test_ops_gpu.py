@@ -659,6 +659,32 @@ def test_conv_epilogue_norm_backward_sums(case, dtype):
         assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 8, 64), (2, 64, 64)])
+def test_stride2_dgrad_norm_backward_sums(B, H, W):
+    """The data gradient of the stride-2 3x3 conv (four parity-class launches) + the norm-backward sums of the tensor it produces from
+    the class launches' epilogues (one slab, 4 x tiles rows per sample) == the same data gradient, then the three-launch norm backward."""
+    from pixelwiseregression_amd import kernels as K
+    C, dtype = 128, torch.bfloat16
+    dyn = nhwc(rnd(B, C, H, W, seed=1), dtype)                      # gradient of the stride-2 conv's output (H x W)
+    w = rnd(C, C, 3, 3, seed=2, scale=(C * 9) ** -0.5)
+    pack_d = K.pack_conv(w.float().to(DEV), 2, K.BF16)
+    y = nhwc(rnd(B, C, 2 * H, 2 * W, seed=3), dtype)                # pre-norm tensor the conv read (2H x 2W)
+    gamma, beta = (1 + 0.2 * rnd(C, seed=4)).float().to(DEV), (0.2 * rnd(C, seed=5)).float().to(DEV)
+    state = K.norm_stats(y, gamma, beta, mode=0)
+    g0, _ = K.conv_fwd(dyn, pack_d, C, 3, 1, mode=1)
+    dy0, dg0, db0 = K.norm_bwd(g0, y, state, mode=0)
+    g1, partial, chunks = K.conv_fwd_stats(dyn, pack_d, C, 3, 1, nb_y=y, nb_state=state, mode=1)
+    assert chunks == 4 * (H // 4) * (W // 32)
+    assert torch.equal(g0, g1)
+    assert not torch.isnan(partial).any()
+    dy1, dg1, db1 = K.norm_bwd_from_partial(g1, y, state, partial, chunks, mode=0)
+    assert_close(dy1.double().cpu(), dy0.double().cpu(), 1e-2, "dy")
+    assert_close(dg1.double().cpu(), dg0.double().cpu(), 1e-4, "dgamma")
+    assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
+    g2, partial2, _ = K.conv_fwd_stats(dyn, pack_d, C, 3, 1, nb_y=y, nb_state=state, mode=1)
+    assert torch.equal(partial, partial2) and torch.equal(g1, g2)
+
+
 @pytest.mark.parametrize("B,H,xmode", [(3, 2, 1), (2, 4, 1), (5, 8, 1), (2, 16, 1), (33, 4, 1), (2, 4, 2), (5, 8, 2), (3, 16, 2)])
 def test_resblock_small_fused_input(B, H, xmode):
     """pwr_resblock_fwd_small_x: the one-launch ResBlock computing its input on the fly -- xmode 1: x = maxpool2x2(a) (model.py:40),

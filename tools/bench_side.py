@@ -49,8 +49,10 @@ if which & {"all", "s2"}:
 if which & {"all", "last"}:
     wg("heads' last conv 3x3 128->16 (J = 14 padded) @64x64", 64, 128, 16, 3, 1, 80, cout_real=14)
 if which & {"all", "stem"}:
-    wg("stem 3x3 64->128 @128x128", 128, 64, 128, 3, 1, 80)
-    wg("stem 3x3 32->64 @128x128", 128, 32, 64, 3, 1, 168)
+    for sp in [int(v) for v in os.environ.get("STEM_SPLITS", "80").split(",")]:
+        wg("stem 3x3 64->128 @128x128", 128, 64, 128, 3, 1, sp)
+    for sp in [int(v) for v in os.environ.get("STEM_SPLITS2", "168").split(",")]:
+        wg("stem 3x3 32->64 @128x128", 128, 32, 64, 3, 1, sp)
 if which & {"all", "pw"}:
     wg("ResBlock 1x1 128->64 @64x64", 64, 128, 64, 1, 1, 512)
     wg("ResBlock 1x1 64->128 @64x64", 64, 64, 128, 1, 1, 512)
