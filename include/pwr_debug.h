@@ -11,6 +11,8 @@ extern "C" {
 int pwr_debug_copy_if(const int* flag, const void* src, void* dst, size_t bytes, void* stream);
 /* per-workgroup phase time stamps of the 3x3 patch conv (8 x int64 each); NULL = off */
 void pwr_debug_set_stamps(void* stamps);
+/* phase experiment of the 3x3 patch conv: workgroups in an odd wave slot sleep ~cycles before staging their patch; 0 = off */
+void pwr_debug_set_delay(int cycles);
 /* arena layout as text lines "offset bytes tag"; returns the size needed */
 size_t pwr_engine_layout(void* engine, char* buf, size_t cap);
 /* 0 (the product's mode since round 4): the caller's stream waits for the side streams after the last segment only; 1: after every

@@ -15,6 +15,7 @@ struct ConvParams {
   int B, H, W, Cin, Ho, Wo, Cout, CoutPad;
   int ksize, stride, pad, mode, relu_in, KCH, M;
   long long* stamps = nullptr;   // debugging aid (pwr_debug_set_stamps): 8 x int64 per workgroup = phase time stamps + HW ids
+  int dbg_delay = 0;             // debug build (pwr_debug_set_delay): workgroups in an odd wave slot sleep ~dbg_delay cycles before staging
   // ---- optional per-channel column statistics of the OUTPUT tile, written by the epilogue (one slab entry per workgroup;
   // a workgroup's 128 output pixels lie in one sample).  nb_partial: [(b*chunks + chunk)*2 + {0,1}][Cout] fp32.
   // st_partial: [(b*chunks + chunk)*3 + {0,1,2}][Cout] = sum (v - k), sum (v - k)^2, k of the stored output v, with the shift
@@ -207,6 +208,7 @@ bool conv_tr2_applicable(const ConvParams& p, int dtype);   // stride-2 data gra
 int launch_conv_tr2(const ConvParams& p, hipStream_t s);
 int conv_tr2_stats_chunks(const ConvParams& p, int dtype);   // slab rows per sample of its norm-backward sums, 0 = unsupported
 void set_debug_stamps(long long* ptr);
+void set_debug_delay(int d);
 
 // conv_wgrad_dma.hip: 3x3 weight gradient with both operands staged by LDS-DMA (operand already normalised: in_norm == null)
 bool wgrad3d_applicable(const WgradParams& p);

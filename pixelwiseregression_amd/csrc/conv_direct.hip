@@ -122,6 +122,15 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   if (i >= n) return;
   float s = 0.f;
   int k = 0;
+  // (32 loads in flight first: the stem's weight gradient sums 512 slabs on 2 blocks at the very end of the train step -- 64 dependent
+  // L2 round trips = 22 us with 8 in flight; same ascending order of additions, so the same bits)
+  for (; k + 32 <= S; k += 32) {
+    float a[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a[u] = slab[(size_t)(k + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += a[u];
+  }
   for (; k + 8 <= S; k += 8) {      // 8 loads in flight, fixed summation order
     float a[8];
 #pragma unroll

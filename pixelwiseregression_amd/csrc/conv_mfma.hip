@@ -1175,6 +1175,7 @@ extern "C" int pwr_conv_fwd(const void* x, const void* wpack, const float* bias,
 // K loop done / end, -, HW_ID, XCC_ID) to stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8].  NULL switches it off.
 #ifdef PWR_DEBUG_BUILD
 extern "C" void pwr_debug_set_stamps(void* stamps) { pwr::set_debug_stamps((long long*)stamps); }
+extern "C" void pwr_debug_set_delay(int d) { pwr::set_debug_delay(d); }
 #endif
 // Debugging aid: 1 / 0 forces the ping-pong form of the 3x3 128->128 conv on / off (where it applies), -1 = the default (env PWR_PINGPONG)
 

@@ -20,6 +20,7 @@
 namespace pwr {
 
 static long long* g_stamps = nullptr;     // (debug build: pwr_debug_set_stamps; always null in the shipped library)
+static int g_delay = PWR_DBG_ENV("PWR_PATCH_DELAY", 0);      // (debug build: pwr_debug_set_delay / the environment)
 __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 #ifdef PWR_DEBUG_BUILD
   if (p.stamps && threadIdx.x == 0) {
@@ -119,6 +120,13 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
   stamp(p, 0);
+#ifdef PWR_DEBUG_BUILD
+  // phase experiment: the two workgroups of a CU start together and stay in phase (staging beside staging, K loop beside K loop);
+  // hold the one in the odd wave slots back by ~dbg_delay cycles so that its memory phases fall beside the other's K loop
+  if (p.dbg_delay > 0 && (__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1)) {      // HW_ID[3:0] = wave slot
+    for (int i = 0; i < p.dbg_delay; i += 1024) __builtin_amdgcn_s_sleep(16);      // (s_sleep n = 64 n cycles)
+  }
+#endif
 
   // ---- weights of iteration 0 in flight while the patch is staged
   V rb[NB];
@@ -774,7 +782,7 @@ static int launch_patch_cin(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   dim3 grid(p.B * (p.H / 4) * (p.W / 32), p.CoutPad / bn), block(256);
   static const bool dma = (PWR_DBG_ENV("PWR_PATCH_DMA", 1) != 0);
-  const_cast<ConvParams&>(p).stamps = g_stamps;
+  const_cast<ConvParams&>(p).stamps = g_stamps; const_cast<ConvParams&>(p).dbg_delay = g_delay;
   // fp32 (parity mode) patches leave no room for a third weight stage next to a second workgroup: register staging
   if (dma && sizeof(T) == 2) {
     static const bool big = (PWR_DBG_ENV("PWR_PATCH_BIG", 0) != 0);   // measured: 61 us vs 59 us for the 4x32 tile -> off
@@ -823,6 +831,7 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
 }
 
 void set_debug_stamps(long long* ptr) { g_stamps = ptr; }
+void set_debug_delay(int d) { g_delay = d; }
 
 template <int CIN>
 static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
@@ -908,6 +917,7 @@ int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t
   ConvPair g{a, b};
   g.a.epi16 = g.b.epi16 = 1;
   g.a.stamps = g.b.stamps = nullptr;
+  g.a.dbg_delay = g.b.dbg_delay = PWR_DBG_ENV("PWR_PAIR_DELAY", 0);
   dim3 grid(a.B * (a.H / 4) * (a.W / 32), a.CoutPad / 128, 2), block(256);
   if (a.Cin == 128) hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, g);
   else if (a.Cin == 64) hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 64, 2, 2, 2, 2, true>), grid, block, 0, s, g);
@@ -917,13 +927,13 @@ int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t
 
 int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
   if (conv_s2_applicable(p, dtype)) {
-    const_cast<ConvParams&>(p).stamps = g_stamps;
+    const_cast<ConvParams&>(p).stamps = g_stamps; const_cast<ConvParams&>(p).dbg_delay = g_delay;
     if (p.Cin == 128) return launch_patch_s2<128>(p, s);
     if (p.Cin == 64) return launch_patch_s2<64>(p, s);
     return launch_patch_s2<32>(p, s);
   }
   if (conv1x1_applicable(p, dtype)) {
-    const_cast<ConvParams&>(p).stamps = g_stamps;
+    const_cast<ConvParams&>(p).stamps = g_stamps; const_cast<ConvParams&>(p).dbg_delay = g_delay;
     if (p.Cin == 128) return launch_patch_1x1<128>(p, s);
     if (p.Cin == 64) return launch_patch_1x1<64>(p, s);
     return launch_patch_1x1<32>(p, s);
