@@ -221,6 +221,14 @@ int pwr_resblock_bwd_small(const void* gout, const void* x, const void* t1, cons
                            const void* wc_d, const void* wb_d, const void* wa_d, const float* state_a, const float* state_b,
                            const float* state_c, float* sums_a, float* sums_b, float* sums_c, float* bias_sums, int B, int H, int W,
                            int C, int dtype, void* stream);
+/* pwr_resblock_bwd_small with its neighbours in the hourglass backward fused in (model.py:40-47), like pwr_resblock_fwd_small_x:
+ * up_src != NULL: gout (WRITTEN) = the 2x2 block sums of up_src [B,2H,2W,C] -- pwr_upsample_bwd in the load;
+ * pool_dst != NULL: pool_dst [B,2H,2W,C] = pool_addend + dx routed to the first maximum of each 2x2 window of pool_a (x = maxpool2x2(pool_a))
+ * -- pwr_maxpool_bwd in the store.  Bit-identical to the separate launches. */
+int pwr_resblock_bwd_small_x(const void* up_src, const void* pool_a, const void* pool_addend, void* pool_dst, void* gout, const void* x,
+                             const void* t1, const void* t2, void* dx, void* dt1, void* dt2, const void* wc_d, const void* wb_d,
+                             const void* wa_d, const float* state_a, const float* state_b, const float* state_c, float* sums_a,
+                             float* sums_b, float* sums_c, float* bias_sums, int B, int H, int W, int C, int dtype, void* stream);
 /* batch reduction of the per-sample sums of pwr_resblock_bwd_small in one launch: dgamma / dbeta of the three norms and, from
  * bias_sums [B][C] (per-sample column sums of g_out; NULL to skip), the bias gradient of conv c */
 int pwr_resblock_param_grads(const float* sums_a, const float* sums_b, const float* sums_c, const float* bias_sums, float* dgamma_a,

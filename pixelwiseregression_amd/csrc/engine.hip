@@ -212,6 +212,14 @@ struct Engine {
   // a tensor whose producer (max-pool / up-sample + add) was left to the one-launch ResBlock that consumes it (resblock_fused)
   struct LazyX { bool valid = false; int mode = 0; size_t x_off = 0, a_off = 0, h_off = 0; };
   LazyX lazy_x;
+  // the same for the backward pass (round 4): the gradient of the up-sample is summed by the one-launch ResBlock backward that consumes it
+  // while it loads (pend_up: the level's `out` gradient), the max-pool's gradient is routed by the one that produces it while it stores
+  // (pend_pool: x_off = the pooled tensor the block must read, a / addend / dst = the level's input-block output, its `out` gradient and
+  // the gradient buffer of that output); hourglass() registers them, resblock_fused() consumes them
+  struct PendUp { bool valid = false; size_t src_goff = 0; };
+  struct PendPool { bool valid = false; size_t x_off = 0, a_off = 0, addend_goff = 0, dst_goff = 0; };
+  PendUp pend_up;
+  PendPool pend_pool;
   int hg_depth = 0;
   // The ONE producer/consumer pair of such statistics that spans two backward segments (two C ABI calls, with the all-reduce and
   // Python in between): stage 0's input-conv data gradient writes the norm-backward reductions of the stem's last norm, the stem
@@ -624,21 +632,31 @@ struct Engine {
       std::vector<Op> blk;
       std::swap(blk, bwd_cur);
       const size_t bsum = alloc((size_t)B * x.C * 4);           // per-sample column sums of out.g (bias gradient of conv c)
+      // neighbours of the block in the hourglass backward left to this launch (hourglass())
+      const bool has_up = pend_up.valid;
+      const size_t up_goff = pend_up.src_goff;
+      pend_up.valid = false;
+      PendPool pl{};
+      if (pend_pool.valid && pend_pool.x_off == x.off) { pl = pend_pool; pend_pool.valid = false; }
+      else if (pend_pool.valid) err = "internal: a fused max-pool backward was not consumed by the block it was registered for";
       if (small_jobs) {
         small_jobs->push_back(SmallJob{r.t2.off, out.goff, r.nc.state, r.cc.w, x.H, x.W, Fh, x.C, 1});
         small_jobs->push_back(SmallJob{r.t1.off, r.t2.goff, r.nb.state, r.cb.w, x.H, x.W, Fh, Fh, 3});
         small_jobs->push_back(SmallJob{x.off, r.t1.goff, r.na.state, r.ca.w, x.H, x.W, x.C, Fh, 1});
-      } else {
+      } else if (!has_up) {
         conv_bwd(r.t2, &r.nc, r.cc, out, false, false, false);    // side stream: dW_c (needs only out.g)
       }
       bwd_cur.push_back([=](Ctx& c) {
         if (elim_mask() & 4) return 0;
-        return pwr_resblock_bwd_small(c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
-                                      c.arena + rb.t1.goff, c.arena + rb.t2.goff, c.packs + rb.cc.pack_d, c.packs + rb.cb.pack_d,
-                                      c.packs + rb.ca.pack_d, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
-                                      (float*)(c.arena + rb.nc.state), (float*)(c.arena + rb.na.sums), (float*)(c.arena + rb.nb.sums),
-                                      (float*)(c.arena + rb.nc.sums), (float*)(c.arena + bsum), Bc, x.H, x.W, x.C, dt, c.stream);
+        return pwr_resblock_bwd_small_x(has_up ? c.arena + up_goff : nullptr, pl.valid ? c.arena + pl.a_off : nullptr,
+                                        pl.valid ? c.arena + pl.addend_goff : nullptr, pl.valid ? c.arena + pl.dst_goff : nullptr,
+                                        c.arena + out.goff, c.arena + x.off, c.arena + rb.t1.off, c.arena + rb.t2.off, c.arena + x.goff,
+                                        c.arena + rb.t1.goff, c.arena + rb.t2.goff, c.packs + rb.cc.pack_d, c.packs + rb.cb.pack_d,
+                                        c.packs + rb.ca.pack_d, (float*)(c.arena + rb.na.state), (float*)(c.arena + rb.nb.state),
+                                        (float*)(c.arena + rb.nc.state), (float*)(c.arena + rb.na.sums), (float*)(c.arena + rb.nb.sums),
+                                        (float*)(c.arena + rb.nc.sums), (float*)(c.arena + bsum), Bc, x.H, x.W, x.C, dt, c.stream);
       });
+      if (!small_jobs && has_up) conv_bwd(r.t2, &r.nc, r.cc, out, false, false, false);    // (out.g is written by the launch above)
       if (!small_jobs) {
         conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, false, false);   // side stream: dW_b from t2.g
         conv_bwd(x, &r.na, r.ca, r.t1, false, false, false);      // side stream: dW_a from t1.g
@@ -689,14 +707,27 @@ struct Engine {
     std::vector<SmallJob> jobs;
     const bool own = tr && !small_jobs && PWR_DBG_ENV("PWR_WGRAD_GROUP", 1) != 0 && h0.H <= 16 && pwr_resblock_small_supported(h0.H, h0.W, h0.C, norm_mode, dtype);
     if (own) small_jobs = &jobs;
+    Tn out = tensor(a.H, a.W, a.C, tr);
+    // backward counterparts of the two fusions: max-pool backward in the store of the block that produces h0's gradient, up-sample
+    // backward in the load of the block that consumes h2's (8 launches of 6 - 8 us less on the chain per stage)
+    static const bool fuse_bwd = PWR_DBG_ENV("PWR_RESBLOCK_FUSE_BWD", 1) != 0;
+    const bool small_inner = tr && fuse_bwd && pwr_resblock_small_supported(h0.H, h0.W, h0.C, norm_mode, dtype);
+    if (small_inner) {
+      if (pend_pool.valid) err = "unconsumed fused max-pool backward";
+      pend_pool = PendPool{true, h0.off, a.off, out.goff, a.goff};
+    }
     Tn h1 = lvl > 0 ? hourglass(h0, lvl - 1) : resblock(h0);
+    const bool pool_fused = small_inner && !pend_pool.valid;
+    if (pend_pool.valid) { err = "internal: fused max-pool backward left pending"; pend_pool.valid = false; }
     std::vector<Op> after_inner;
     std::swap(after_inner, bwd_cur);
+    if (small_inner) pend_up = PendUp{true, out.goff};
     Tn h2 = resblock(h1);
+    const bool up_fused = small_inner && !pend_up.valid;
+    if (pend_up.valid) { err = "internal: fused up-sample backward left pending"; pend_up.valid = false; }
     std::vector<Op> after_h2;
     std::swap(after_h2, bwd_cur);
     if (own) small_jobs = nullptr;
-    Tn out = tensor(a.H, a.W, a.C, tr);
     // `out` of an inner level is consumed by the outer level's output ResBlock only: the same fusion (not for the outermost level --
     // hg_depth == 1 here -- whose result goes to the heads, nor for the big maps)
     if (fuse_in && hg_depth > 1 && a.H >= 4 && pwr_resblock_small_supported(a.H, a.W, a.C, norm_mode, dtype)) {
@@ -708,14 +739,16 @@ struct Engine {
       });
     }
     if (tr) {
-      bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
+      if (!up_fused)
+        bwd_cur.push_back([=](Ctx& c) { return pwr_upsample_bwd(c.arena + out.goff, c.arena + h2.goff, Bc, h2.H, h2.W, a.H, a.W, a.C, dt, c.stream); });
       bwd_cur.insert(bwd_cur.end(), after_h2.begin(), after_h2.end());        // resblock h1 -> h2
       bwd_cur.insert(bwd_cur.end(), after_inner.begin(), after_inner.end());  // inner
       for (size_t j0 = 0; own && j0 < jobs.size(); j0 += 24)                  // (<= 24 layers per grouped launch)
         bwd_cur.push_back(small_group_op(std::vector<SmallJob>(jobs.begin() + j0, jobs.begin() + std::min(jobs.size(), j0 + 24))));
-      bwd_cur.push_back([=](Ctx& c) {
-        return pwr_maxpool_bwd(c.arena + a.off, c.arena + h0.goff, c.arena + out.goff, c.arena + a.goff, Bc, a.H, a.W, a.C, dt, c.stream);
-      });
+      if (!pool_fused)
+        bwd_cur.push_back([=](Ctx& c) {
+          return pwr_maxpool_bwd(c.arena + a.off, c.arena + h0.goff, c.arena + out.goff, c.arena + a.goff, Bc, a.H, a.W, a.C, dt, c.stream);
+        });
       bwd_cur.insert(bwd_cur.end(), after_a.begin(), after_a.end());          // resblock x -> a
     }
     return out;

@@ -42,6 +42,14 @@ struct RbBwdParams {
   float* sums_a; float* sums_b; float* sums_c;                // [B][2][C] per-sample (sum g, sum g*xhat)
   float* bias_sums;                                           // [B][C] per-sample column sums of g_out (bias gradient of conv c), or null
   int B;
+  // The neighbours of the block in the hourglass backward (model.py:40-47), fused like their forward counterparts (round 4):
+  // up_src != null: g_out = the 2x2 block sums of up_src [B,2W,2W,C] (the gradient of `nearest-upsample(h2) + a` w.r.t. h2: the arithmetic of
+  //   upsample_bwd_kernel, fp32 sums in scan order, one rounding), computed while it is loaded and WRITTEN to gout_w (= gout: the weight
+  //   gradient of conv c reads it; every thread reads back at the end exactly the (pixel, slot) pairs it wrote);
+  // pool_dst != null: the block input is maxpool2x2(pool_a [B,2W,2W,C]); besides dx the kernel writes pool_dst = pool_addend + route(dx)
+  //   (maxpool_bwd_kernel: the gradient goes to the first maximum of each window in scan order).
+  const bf16_t* up_src = nullptr; bf16_t* gout_w = nullptr;
+  const bf16_t* pool_a = nullptr; const bf16_t* pool_addend = nullptr; bf16_t* pool_dst = nullptr;
 };
 
 constexpr int rb_max(int a, int b) { return a > b ? a : b; }
@@ -198,8 +206,22 @@ extern "C" int pwr_resblock_bwd_small(const void* gout, const void* x, const voi
                                       const void* wc_d, const void* wb_d, const void* wa_d, const float* state_a, const float* state_b,
                                       const float* state_c, float* sums_a, float* sums_b, float* sums_c, float* bias_sums, int B, int H,
                                       int W, int C, int dtype, void* stream) {
+  return pwr_resblock_bwd_small_x(nullptr, nullptr, nullptr, nullptr, const_cast<void*>(gout), x, t1, t2, dx, dt1, dt2, wc_d, wb_d, wa_d, state_a,
+                                  state_b, state_c, sums_a, sums_b, sums_c, bias_sums, B, H, W, C, dtype, stream);
+}
+
+// up_src != NULL: gout (WRITTEN) = 2x2 block sums of up_src [B,2H,2W,C] (pwr_upsample_bwd fused into the load).  pool_dst != NULL:
+// pool_dst [B,2H,2W,C] = pool_addend + the block's dx routed to the first maximum of every 2x2 window of pool_a (pwr_maxpool_bwd fused
+// into the store; x = maxpool2x2(pool_a)).  Everything written is bit-identical to the separate launches.
+extern "C" int pwr_resblock_bwd_small_x(const void* up_src, const void* pool_a, const void* pool_addend, void* pool_dst, void* gout, const void* x,
+                                        const void* t1, const void* t2, void* dx, void* dt1, void* dt2, const void* wc_d, const void* wb_d,
+                                        const void* wa_d, const float* state_a, const float* state_b, const float* state_c, float* sums_a,
+                                        float* sums_b, float* sums_c, float* bias_sums, int B, int H, int W, int C, int dtype, void* stream) {
   if (!(dtype == PWR_BF16 && C == 128 && H == W && (W == 2 || W == 4 || W == 8 || W == 16))) return (int)hipErrorInvalidValue;
+  if (pool_dst && (!pool_a || !pool_addend)) return PWR_EINVAL;
   RbBwdParams p;
+  p.up_src = (const bf16_t*)up_src; p.gout_w = (bf16_t*)gout;
+  p.pool_a = (const bf16_t*)pool_a; p.pool_addend = (const bf16_t*)pool_addend; p.pool_dst = (bf16_t*)pool_dst;
   p.gout = (const bf16_t*)gout; p.x = (const bf16_t*)x; p.t1 = (const bf16_t*)t1; p.t2 = (const bf16_t*)t2;
   p.dx = (bf16_t*)dx; p.dt1 = (bf16_t*)dt1; p.dt2 = (bf16_t*)dt2;
   p.wcd = (const char*)wc_d; p.wbd = (const char*)wb_d; p.wad = (const char*)wa_d;

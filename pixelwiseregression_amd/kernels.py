@@ -332,6 +332,25 @@ def resblock_bwd_small(gout, x, t1, t2, packs_d, states):
     return dx, dt1, dt2, sums, pg   # pg = dgamma_a, dbeta_a, dgamma_b, dbeta_b, dgamma_c, dbeta_c, dbias_c
 
 
+def resblock_bwd_small_x(x, t1, t2, packs_d, states, gout=None, up_src=None, pool_a=None, pool_addend=None):
+    """pwr_resblock_bwd_small_x: the one-launch ResBlock backward with the up-sample backward fused into its load (up_src [B,2H,2W,C]: gout is
+    computed and returned) and / or the max-pool backward fused into its store (pool_a, pool_addend [B,2H,2W,C]: returns pool_dst).
+    Returns dx, dt1, dt2, sums, gout, pool_dst, bias_sums."""
+    l = _lib.lib()
+    B, H, W, C = x.shape
+    dev = x.device
+    dx, dt1, dt2 = torch.empty_like(x), torch.empty_like(t1), torch.empty_like(t2)
+    sums = [torch.empty(B, 2, c, dtype=torch.float32, device=dev) for c in (C, C // 2, C // 2)]
+    bsum = torch.empty(B, C, dtype=torch.float32, device=dev)
+    if up_src is not None:
+        gout = torch.full_like(x, float("nan"))
+    pool_dst = torch.full_like(pool_a, float("nan")) if pool_a is not None else None
+    _lib.check(l.pwr_resblock_bwd_small_x(_p(up_src), _p(pool_a), _p(pool_addend), _p(pool_dst), _p(gout), _p(x), _p(t1), _p(t2), _p(dx), _p(dt1),
+                                          _p(dt2), _p(packs_d[2]), _p(packs_d[1]), _p(packs_d[0]), _p(states[0]), _p(states[1]), _p(states[2]),
+                                          _p(sums[0]), _p(sums[1]), _p(sums[2]), _p(bsum), B, H, W, C, _dt(x), _s(x)), "pwr_resblock_bwd_small_x")
+    return dx, dt1, dt2, sums, gout, pool_dst, bsum
+
+
 def conv_stats_chunks(H, W, Cin, Cout, ksize, stride=1, mode=0, dtype=BF16):
     return _lib.lib().pwr_conv_stats_chunks(H, W, Cin, Cout, ksize, stride, mode, dtype)
 

@@ -685,6 +685,45 @@ def test_stride2_dgrad_norm_backward_sums(B, H, W):
     assert torch.equal(partial, partial2) and torch.equal(g1, g2)
 
 
+@pytest.mark.parametrize("B,H", [(3, 2), (2, 4), (5, 8), (2, 16), (33, 4)])
+@pytest.mark.parametrize("which", ["up", "pool", "both"])
+def test_resblock_small_bwd_fused_neighbours(B, H, which):
+    """pwr_resblock_bwd_small_x: the one-launch ResBlock backward summing the up-sample's gradient while it loads (model.py:45) and / or
+    routing the max-pool's gradient while it stores (model.py:40).  Everything it writes -- g_out, dx, dt1, dt2, the norm sums, the bias
+    sums, the pooled tensor's input gradient -- is BIT-identical to pwr_upsample_bwd, pwr_resblock_bwd_small, pwr_maxpool_bwd in sequence."""
+    from pixelwiseregression_amd import kernels as K
+    C, Fh, dt = 128, 64, torch.bfloat16
+    ws = [rnd(Fh, C, 1, 1, seed=2, scale=C ** -0.5), rnd(Fh, Fh, 3, 3, seed=3, scale=(9 * Fh) ** -0.5), rnd(C, Fh, 1, 1, seed=4, scale=Fh ** -0.5)]
+    bs = [rnd(Fh, seed=5, scale=0.1), rnd(Fh, seed=6, scale=0.1), rnd(C, seed=7, scale=0.1)]
+    gs = [1 + 0.2 * rnd(C, seed=8), 1 + 0.2 * rnd(Fh, seed=9), 1 + 0.2 * rnd(Fh, seed=10)]
+    bes = [0.2 * rnd(C, seed=11), 0.2 * rnd(Fh, seed=12), 0.2 * rnd(Fh, seed=13)]
+    dev = lambda t: t.float().to(DEV)
+    wf = [K.pack_conv(dev(w), 0, K.BF16) for w in ws]
+    wd = [K.pack_conv(dev(w), 1, K.BF16) for w in ws]
+    bd, gmd, bed = [dev(t) for t in bs], [dev(t) for t in gs], [dev(t) for t in bes]
+    a = nhwc(rnd(B, C, 2 * H, 2 * H, seed=21), dt)           # the level above: the tensor that was pooled
+    a[:, ::2, ::2] = a[:, 1::2, ::2]                          # (ties inside windows: the FIRST maximum in scan order takes the gradient)
+    x = K.maxpool_fwd(a) if which != "up" else nhwc(rnd(B, C, H, H, seed=22), dt)
+    up = nhwc(rnd(B, C, 2 * H, 2 * H, seed=23), dt)          # gradient of the level above's `out`
+    addend = nhwc(rnd(B, C, 2 * H, 2 * H, seed=24), dt)      # gradient already sitting on the pooled tensor's skip path
+    gout_plain = nhwc(rnd(B, C, H, H, seed=25), dt)
+    _, t1, t2, st = K.resblock_fwd_small(x, wf, bd, gmd, bed)
+    # ---- separate launches
+    gout0 = K.upsample_bwd(up, H, H) if which != "pool" else gout_plain
+    dx0, dt10, dt20, sums0, _ = K.resblock_bwd_small(gout0, x, t1, t2, wd, st)
+    pd0 = K.maxpool_bwd(a, dx0, addend) if which != "up" else None
+    # ---- one launch
+    dx1, dt11, dt21, sums1, gout1, pd1, _ = K.resblock_bwd_small_x(x, t1, t2, wd, st, gout=None if which != "pool" else gout_plain,
+                                                                  up_src=up if which != "pool" else None,
+                                                                  pool_a=a if which != "up" else None, pool_addend=addend if which != "up" else None)
+    assert torch.equal(gout1, gout0)
+    assert torch.equal(dx1, dx0) and torch.equal(dt11, dt10) and torch.equal(dt21, dt20)
+    for s0, s1 in zip(sums0, sums1):
+        assert torch.equal(s0, s1)
+    if which != "up":
+        assert not torch.isnan(pd1.float()).any() and torch.equal(pd1, pd0)
+
+
 @pytest.mark.parametrize("B,H,xmode", [(3, 2, 1), (2, 4, 1), (5, 8, 1), (2, 16, 1), (33, 4, 1), (2, 4, 2), (5, 8, 2), (3, 16, 2)])
 def test_resblock_small_fused_input(B, H, xmode):
     """pwr_resblock_fwd_small_x: the one-launch ResBlock computing its input on the fly -- xmode 1: x = maxpool2x2(a) (model.py:40),
