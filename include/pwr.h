@@ -178,6 +178,12 @@ int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* 
 int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float* state, int B, int HW, int C, int mode, float eps,
                               float momentum, void* stream);
+/* two pwr_norm_bwd_from_partial calls of ONE shape (instance norm, no addend: the two regression heads' norms of one depth, model.py:54-65 /
+ * :103-114) as two launches instead of four; S1 / S2: 2 x B x C floats of scratch.  Bit-identical to the two single calls. */
+int pwr_norm_bwd_from_partial_pair(const void* ga, const void* ya, const float* state_a, const float* partial_a, void* dya, float* dgamma_a,
+                                   float* dbeta_a, const void* gb, const void* yb, const float* state_b, const float* partial_b, void* dyb,
+                                   float* dgamma_b, float* dbeta_b, int chunks, float* S1, float* S2, int accumulate, int relu, int B, int HW,
+                                   int C, int dtype, void* stream);
 /* pwr_norm_bwd given the reductions of pwr_conv_fwd_stats (nb_partial). */
 int pwr_norm_bwd_from_partial(const void* g, const void* y, const float* state, const float* partial, int chunks, float* S1, float* S2,
                               const void* addend, void* dy, float* dgamma, float* dbeta, int accumulate, int relu, int B, int HW,

@@ -390,6 +390,28 @@ struct Engine {
     });
   }
 
+  // the norm backwards of the two heads' tensors of one depth (instance norm, reductions already written by the paired data gradient at
+  // cpartial + 0 / + off_b): two launches instead of four on a stretch where the chain runs alone
+  void norm_bwd_pair(const Tn& ta, const NormL& na, const Tn& tb, const NormL& nb, int chunks, size_t off_b) {
+    static const bool on = PWR_DBG_ENV("PWR_NORM_BWD_PAIR", 1) != 0;
+    if (!on || norm_mode != 0 || chunks <= 0 || ta.H != tb.H || ta.W != tb.W || ta.C != tb.C) {
+      norm_bwd(ta, na, 0, false, chunks, false, 0);
+      norm_bwd(tb, nb, 0, false, chunks, false, off_b);
+      return;
+    }
+    const int HW = ta.H * ta.W, C = ta.C, Bc = B, dt = dtype;
+    Engine* E = this;
+    if ((size_t)2 * B * C * 4 > need_sc) need_sc = (size_t)2 * B * C * 4;
+    bwd_cur.push_back([=](Ctx& c) {
+      if (elim_mask() & 2) return 0;
+      return pwr_norm_bwd_from_partial_pair(c.arena + ta.goff, c.arena + ta.off, (float*)(c.arena + na.state), (float*)(c.arena + E->scr_cpartial),
+                                            c.arena + ta.goff, c.grads + na.gamma, c.grads + na.beta, c.arena + tb.goff, c.arena + tb.off,
+                                            (float*)(c.arena + nb.state), (float*)(c.arena + E->scr_cpartial + off_b), c.arena + tb.goff,
+                                            c.grads + nb.gamma, c.grads + nb.beta, chunks, (float*)(c.arena + E->scr_S1),
+                                            (float*)(c.arena + E->scr_S2), 0, 1, Bc, HW, C, dt, c.stream);
+    });
+  }
+
   // ---- MFMA conv: y = conv(NR(x)) + bias (+ residual)
   // out_norm: the norm that follows the conv in model.py; its statistics come out of the conv's epilogue when the shape
   // allows (otherwise conv, then the standalone statistics kernels)
@@ -857,6 +879,7 @@ struct Engine {
     if (2 * half > need_cpartial) need_cpartial = 2 * half;
     const int splits3 = splits_for(M, F, Jp, ks);
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits3));
+    want_slab((size_t)B * J * 4);
     const bool wpair = PWR_DBG_ENV("PWR_HEAD_WGRAD_PAIR", 0) != 0;      // weight gradients of the two heads in one launch (measured: no gain)
     const int splits_pair = wpair ? std::max(1, splits_for(M, F, F, ks) / 2) : splits_for(M, F, F, ks);
     want_slab(2 * pwr_conv_wgrad_slab_bytes(F, F, ks, splits_pair));
@@ -878,7 +901,13 @@ struct Engine {
       for (int k = 0; k < 2 && !rc; ++k) {
         const Head& h = *hs[k];
         rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + gsrc[k]), c.arena + h.gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
-        if (!rc) rc = pwr_planesum_nchw((const float*)(c.arena + gsrc[k]), (float*)(c.arena + E->scr_S1), c.grads + h.c3.b, Bc, Jc, Pc * Pc, 0, c.stream);
+        // (the last conv's bias gradient feeds the flat gradient only: side stream, with that stream's slab as scratch -- round 4; it was two
+        // launches of 6 us per head on the chain)
+        const size_t src = gsrc[k];
+        const long long bo = h.c3.b;
+        if (!rc) rc = run_on_side(c, [=](Ctx& c2) {
+          return pwr_planesum_nchw((const float*)(c2.arena + src), (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + bo, Bc, Jc, Pc * Pc, 0, c2.stream);
+        });
       }
       for (int k = 0; k < 2 && !rc; ++k) {
         const Head h = *hs[k];
@@ -900,8 +929,7 @@ struct Engine {
       return pwr_conv_fwd_stats(c.arena + D_.gT, c.packs + D_.c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + D_.h3.goff, Bc, Pc, Pc, Jp, Fc, kk, 1, 0,
                                 nullptr, c.arena + D_.h3.off, (float*)(c.arena + D_.n2.state), pb, 1, dt, c.stream);
     });
-    norm_bwd(hp.h3, hp.n2, 0, false, ch, false, 0);
-    norm_bwd(hd.h3, hd.n2, 0, false, ch, false, half);
+    norm_bwd_pair(hp.h3, hp.n2, hd.h3, hd.n2, ch, half);
     // ---- conv depth 2, 1: (x, its norm, conv, y) per head
     struct Lvl { Tn xp, xd, yp, yd; NormL np, nd; ConvL cp, cd; };
     const Lvl lv[2] = {{hp.h2, hd.h2, hp.h3, hd.h3, hp.n1, hd.n1, hp.c2, hd.c2}, {hp.h1, hd.h1, hp.h2, hd.h2, hp.n0, hd.n0, hp.c1, hd.c1}};
@@ -935,8 +963,7 @@ struct Engine {
         return pwr_conv_fwd_stats(c.arena + L.yd.goff, c.packs + L.cd.pack_d, nullptr, nullptr, 0, nullptr, c.arena + L.xd.goff, Bc, Pc, Pc, Fc, Fc, kk, 1, 0,
                                   nullptr, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb, 1, dt, c.stream);
       });
-      norm_bwd(L.xp, L.np, 0, false, ch, false, 0);
-      norm_bwd(L.xd, L.nd, 0, false, ch, false, half);
+      norm_bwd_pair(L.xp, L.np, L.xd, L.nd, ch, half);
     }
     // ---- the heads' first convs read the hourglass output f as it is: paired weight gradient (no norm), then f.g = both data gradients
     bwd_cur.push_back([=](Ctx& c) {
@@ -1082,7 +1109,8 @@ struct Engine {
                               c.out_uvd[s], gH, gD, gU, (float*)(c.arena + Rc.gz), (float*)(c.arena + Rc.gDt),
                               woff >= 0 ? (float*)(c.arena + Rc.gwp) : nullptr, Bc, Jc, Pc, meth, c.stream);
           if (rc || woff < 0) return rc;
-          return pwr_decode_gw_reduce((const float*)(c.arena + Rc.gwp), c.grads + woff, Bc, Jc, 0, c.stream);
+          // (the soft-argmax temperature's gradient: a one-block reduce that only feeds the flat gradient -- side stream)
+          return run_on_side(c, [=](Ctx& c2) { return pwr_decode_gw_reduce((const float*)(c2.arena + Rc.gwp), c2.grads + woff, Bc, Jc, 0, c2.stream); });
         });
         heads_bwd(f, hp, hd, R.gz, R.gDt);
         bwd_cur.insert(bwd_cur.end(), hg_bwd.begin(), hg_bwd.end());

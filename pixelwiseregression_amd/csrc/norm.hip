@@ -289,12 +289,12 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_kernel(const T* __restri
 // One block per 8 channels: thread (b-lane, c) sums the pixel-chunk partials of its (b, c) in a fixed order -> S1,S2[b,c]
 // (divided by HW for instance norm), then the block reduces over b for dgamma / dbeta (and, for batch norm, overwrites
 // S1,S2 with the batch-wide means).  blockDim = 256 = 32 b-lanes x 8 channels.
-__global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restrict__ partial, float* __restrict__ S1,
-                                                           float* __restrict__ S2, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int B, int HW, int C, int nchunks, int batch_mode, int accumulate) {
+__device__ __forceinline__ void norm_bwd_sum_body(const float* __restrict__ partial, float* __restrict__ S1,
+                                                  float* __restrict__ S2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                  int B, int HW, int C, int nchunks, int batch_mode, int accumulate, int bx) {
   __shared__ float r1[32][9], r2[32][9];
   const int cl = threadIdx.x & 7, bl = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  const int c = bx * 8 + cl;
   float t1 = 0.f, t2 = 0.f;
   if (c < C) {
     for (int b = bl; b < B; b += 32) {
@@ -338,19 +338,33 @@ __global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restri
   }
 }
 
+__global__ __launch_bounds__(256) void norm_bwd_sum_kernel(const float* __restrict__ partial, float* __restrict__ S1,
+                                                           float* __restrict__ S2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int B, int HW, int C, int nchunks, int batch_mode, int accumulate) {
+  norm_bwd_sum_body(partial, S1, S2, dgamma, dbeta, B, HW, C, nchunks, batch_mode, accumulate, blockIdx.x);
+}
+// Two norm backwards of ONE shape in one launch each (blockIdx.y / .z picks the job): the two regression heads of a stage are
+// back-propagated in lock-step (model.py:54-65 / :103-114), and on the heads' stretch of the backward pass the chain runs alone -- every
+// launch boundary there is exposed (round 4).  Same bodies, same bits as two single calls.
+struct NormBwdJob { const void* g; const void* y; const float* state; const float* partial; float* S1; float* S2; void* dy; float* dgamma; float* dbeta; };
+struct NormBwdPair { NormBwdJob j[2]; };
+__global__ __launch_bounds__(256) void norm_bwd_sum_pair_kernel(NormBwdPair q, int B, int HW, int C, int nchunks, int accumulate) {
+  const NormBwdJob& j = q.j[blockIdx.y];
+  norm_bwd_sum_body(j.partial, j.S1, j.S2, j.dgamma, j.dbeta, B, HW, C, nchunks, 0, accumulate, blockIdx.x);
+}
+
 // dy = gamma*rstd * (gm - S1 - xn*S2) (+ addend).  Same (chunk, b) decomposition as the partial kernels so that the
 // per-channel constants are loaded once per thread, not once per element.
 // FROM_PARTIAL (instance norm): every block sums the pixel-chunk partials of its sample itself (fixed order, so all
 // blocks of a sample get identical sums) instead of waiting for a separate reduction launch.
 template <typename T, bool FROM_PARTIAL>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
-                                                             const float* __restrict__ state, int B,
-                                                             const float* __restrict__ S1, const float* __restrict__ S2,
-                                                             const T* __restrict__ addend, T* __restrict__ dy, int HW, int C,
-                                                             int nchunks, int relu) {
+__device__ __forceinline__ void norm_bwd_apply_body(const T* __restrict__ g, const T* __restrict__ y,
+                                                    const float* __restrict__ state, int B,
+                                                    const float* __restrict__ S1, const float* __restrict__ S2,
+                                                    const T* __restrict__ addend, T* __restrict__ dy, int HW, int C,
+                                                    int nchunks, int relu, int chunk, int b) {
   constexpr int EP = Elem<T>::kPer16B;
   typedef typename Vec16<T>::type V;
-  const int chunk = blockIdx.x, b = blockIdx.y;
   const int cpp = C / EP, pl = 256 / cpp;
   const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
   if (pj >= pl) return;
@@ -403,6 +417,21 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     }
     *reinterpret_cast<V*>(dy + off) = o;
   }
+}
+
+template <typename T, bool FROM_PARTIAL>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                             const float* __restrict__ state, int B,
+                                                             const float* __restrict__ S1, const float* __restrict__ S2,
+                                                             const T* __restrict__ addend, T* __restrict__ dy, int HW, int C,
+                                                             int nchunks, int relu) {
+  norm_bwd_apply_body<T, FROM_PARTIAL>(g, y, state, B, S1, S2, addend, dy, HW, C, nchunks, relu, blockIdx.x, blockIdx.y);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_pair_kernel(NormBwdPair q, int B, int HW, int C, int nchunks, int relu) {
+  const NormBwdJob& j = q.j[blockIdx.z];
+  norm_bwd_apply_body<T, false>((const T*)j.g, (const T*)j.y, j.state, B, j.S1, j.S2, (const T*)nullptr, (T*)j.dy, HW, C, nchunks, relu, blockIdx.x,
+                                blockIdx.y);
 }
 
 static inline int norm_chunks(int B, int HW) {
@@ -639,6 +668,24 @@ extern "C" int pwr_norm_bwd(const void* g, const void* y, const float* state, fl
 
 // pwr_norm_bwd with the two reductions already done by the epilogue of the data-gradient conv that produced g
 // (pwr_conv_fwd_stats, nb_partial: `chunks` slab rows per sample): 2 launches instead of 3, (g, y) read once instead of twice.
+// Two pwr_norm_bwd_from_partial calls of one shape (instance norm, no addend) as two launches instead of four.  S1 / S2: 2 x B x C floats.
+extern "C" int pwr_norm_bwd_from_partial_pair(const void* ga, const void* ya, const float* state_a, const float* partial_a, void* dya,
+                                              float* dgamma_a, float* dbeta_a, const void* gb, const void* yb, const float* state_b,
+                                              const float* partial_b, void* dyb, float* dgamma_b, float* dbeta_b, int chunks, float* S1,
+                                              float* S2, int accumulate, int relu, int B, int HW, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256) return PWR_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = norm_chunks(B, HW);
+  NormBwdPair q;
+  q.j[0] = NormBwdJob{ga, ya, state_a, partial_a, S1, S2, dya, dgamma_a, dbeta_a};
+  q.j[1] = NormBwdJob{gb, yb, state_b, partial_b, S1 + (size_t)B * C, S2 + (size_t)B * C, dyb, dgamma_b, dbeta_b};
+  hipLaunchKernelGGL(norm_bwd_sum_pair_kernel, dim3((C + 7) / 8, 2), dim3(256), 0, s, q, B, HW, C, chunks, accumulate);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_bwd_apply_pair_kernel<bf16_t>), dim3(nch, B, 2), dim3(256), 0, s, q, B, HW, C, nch, relu);
+  else hipLaunchKernelGGL((norm_bwd_apply_pair_kernel<float>), dim3(nch, B, 2), dim3(256), 0, s, q, B, HW, C, nch, relu);
+  return (int)hipGetLastError();
+}
+
 extern "C" int pwr_norm_bwd_from_partial(const void* g, const void* y, const float* state, const float* partial, int chunks, float* S1,
                                          float* S2, const void* addend, void* dy, float* dgamma, float* dbeta, int accumulate, int relu,
                                          int B, int HW, int C, int mode, int dtype, void* stream) {

@@ -426,6 +426,23 @@ def norm_finalize_partial(partial, chunks, gamma, beta, B, HW, mode=0, running_m
     return state
 
 
+def norm_bwd_from_partial_pair(ga, ya, state_a, partial_a, gb, yb, state_b, partial_b, chunks, relu=True):
+    """Two norm_bwd_from_partial (instance norm, no addend) of one shape as two launches.  Returns (dya, dgamma_a, dbeta_a), (dyb, ...)."""
+    l = _lib.lib()
+    B, H, W, C = ya.shape
+    dev = ya.device
+    S1 = torch.empty(2, B, C, dtype=torch.float32, device=dev)
+    S2 = torch.empty_like(S1)
+    outs = []
+    for y in (ya, yb):
+        outs.append((torch.empty_like(y), torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)))
+    (dya, dga, dba), (dyb, dgb, dbb) = outs
+    _lib.check(l.pwr_norm_bwd_from_partial_pair(_p(ga), _p(ya), _p(state_a), _p(partial_a), _p(dya), _p(dga), _p(dba), _p(gb), _p(yb), _p(state_b),
+                                                _p(partial_b), _p(dyb), _p(dgb), _p(dbb), chunks, _p(S1), _p(S2), 0, int(relu), B, H * W, C, _dt(ya),
+                                                _s(ya)), "pwr_norm_bwd_from_partial_pair")
+    return outs
+
+
 def norm_bwd_from_partial(g, y, state, partial, chunks, relu=True, addend=None, mode=0):
     l = _lib.lib()
     B, H, W, C = y.shape

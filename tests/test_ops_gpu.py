@@ -659,6 +659,30 @@ def test_conv_epilogue_norm_backward_sums(case, dtype):
         assert_close(db1.double().cpu(), db0.double().cpu(), 1e-4, "dbeta")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 32, 32, 128), (3, 8, 64, 64), (5, 64, 64, 128)])
+def test_norm_backward_pair_launch(B, H, W, C):
+    """pwr_norm_bwd_from_partial_pair: the norm backwards of two tensors of one shape (the two heads' norms of one depth) as two launches
+    instead of four, bit-identical to two single calls."""
+    from pixelwiseregression_amd import kernels as K
+    dt = torch.bfloat16
+    jobs = []
+    for sd in (0, 50):
+        dyn = nhwc(rnd(B, C, H, W, seed=1 + sd), dt)
+        w = rnd(C, C, 3, 3, seed=2 + sd, scale=(C * 9) ** -0.5)
+        pack_d = K.pack_conv(w.float().to(DEV), 1, K.BF16)
+        y = nhwc(rnd(B, C, H, W, seed=3 + sd), dt)
+        gamma, beta = (1 + 0.2 * rnd(C, seed=4 + sd)).float().to(DEV), (0.2 * rnd(C, seed=5 + sd)).float().to(DEV)
+        state = K.norm_stats(y, gamma, beta, mode=0)
+        g, partial, chunks = K.conv_fwd_stats(dyn, pack_d, C, 3, 1, nb_y=y, nb_state=state)
+        jobs.append((g, y, state, partial, chunks))
+    singles = [K.norm_bwd_from_partial(g, y, st, pa, ch, mode=0) for (g, y, st, pa, ch) in jobs]
+    (ga, ya, sa, pa, ch), (gb, yb, sb, pb, _) = jobs
+    pair = K.norm_bwd_from_partial_pair(ga, ya, sa, pa, gb, yb, sb, pb, ch)
+    for one, two in zip(singles, pair):
+        for a, b_ in zip(one, two):
+            assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 8, 64), (2, 64, 64)])
 def test_stride2_dgrad_norm_backward_sums(B, H, W):
     """The data gradient of the stride-2 3x3 conv (four parity-class launches) + the norm-backward sums of the tensor it produces from
