@@ -965,6 +965,8 @@ struct Engine {
       });
       norm_bwd_pair(L.xp, L.np, L.xd, L.nd, ch, half);
     }
+    // (PWR_DEFER_FLUSH=1, debug build: release the held-back side work one op earlier, beside the two first-conv data gradients)
+    if (defer_mode && PWR_DBG_ENV("PWR_DEFER_FLUSH", 0) == 1) bwd_cur.push_back(flush_deferred_op());
     // ---- the heads' first convs read the hourglass output f as it is: paired weight gradient (no norm), then f.g = both data gradients
     bwd_cur.push_back([=](Ctx& c) {
       int rc = run_on_side(c, [=](Ctx& c2) {

@@ -21,6 +21,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch24 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write24 -o w -- python3 $R/tools/bench_kernels.py wgrad 3 24 > /dev/null 2> $O/pmc_write24.err
 cd $R
 python3 tools/profile_summary.py $O $O/summary r4 > $O/summary.log 2>&1; tail -60 $O/summary.log
+# one step's kernel timeline (queue, start, duration, workgroups, kernel) out of the step trace; host issue time; the side-stream layers alone
+python3 tools/step_timeline.py $O/step $O/summary/r4_step_timeline.tsv 5 > $O/summary/r4_step_timeline.txt 2>&1; cat $O/summary/r4_step_timeline.txt
+python3 tools/host_issue.py > $O/summary/r4_host_issue.json 2>/dev/null; cat $O/summary/r4_host_issue.json
+python3 tools/bench_side.py all 20 2>/dev/null | grep layer > $O/summary/r4_side_layers.jsonl; cat $O/summary/r4_side_layers.jsonl
 # keep the merge-back small: the raw traces are large
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 du -sh $O
