@@ -29,7 +29,7 @@ python3 tools/bench_side.py all 20 2>/dev/null | grep layer > $O/summary/r4_side
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete
 du -sh $O
 # the GPU suite, the default bench line (accuracy block and CPU baseline included) and the smoke test of the same build, on the same lease
-python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/summary/r4_pytest_gpu.txt; cat $O/summary/r4_pytest_gpu.txt
+python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 > $O/summary/r4_pytest_gpu.txt; cat $O/summary/r4_pytest_gpu.txt
 python bench.py 2>/dev/null > $O/summary/r4_bench.json; cut -c1-330 $O/summary/r4_bench.json
 python -c "
 import __graft_entry__ as g
