@@ -1,0 +1,55 @@
+"""Is this box computing what the other boxes compute?  (1) 220 AdamW train steps of the BASELINE C2 bench configuration: the final loss must
+be the known value (bit-identical on every healthy lease of round 4); (2) the 300-step lr-0 bitwise screen at B = 16.  On a mismatch and
+with --bisect: the same two checks under the debug build's switches, one at a time, to find the component that disagrees.
+   python tools/lease_check.py [--debug-lib] [--bisect]"""
+import os, sys, json, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+KNOWN = 0.014110531657934189     # (220 AdamW steps of this script; bench.py runs 230 and ends at 0.012000063434243202)
+
+
+def run_checks():
+    if "--debug-lib" in sys.argv:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import dbglib  # noqa: F401
+    import torch
+    from pixelwiseregression_amd import PixelwiseRegression
+    from pixelwiseregression_amd.synthetic import make_batch
+    from pixelwiseregression_amd.train import TrainStep
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    m = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, norm_method="instance").to(dev).set_precision("bf16").train()
+    tr = TrainStep(m, opt="adam", lr=1e-4, beta1=0.9, beta2=0.999, weight_decay=0.0, alpha=1.0, lambda_h=1.0, lambda_d=0.01)
+    b = make_batch(32, 14, S=128, seed=1234, device=dev, dense_targets=True)
+    for _ in range(220):
+        loss = tr(b["img"], b["label_img"], b["mask"], b["uvd"], b["heatmaps"], b["depthmaps"])
+    final = float(loss.item())
+    torch.manual_seed(0)
+    m2 = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, norm_method="instance").to(dev).set_precision("bf16").train()
+    b2 = make_batch(16, 14, S=128, seed=5, device=dev)
+    ts = TrainStep(m2, opt="sgd", lr=0.0)
+    a2 = (b2["img"], b2["label_img"], b2["mask"], b2["uvd"])
+    ts(*a2)
+    g0 = m2.flat_grad().clone(); l0 = ts.loss.clone()
+    bad = torch.zeros((), device=dev)
+    for _ in range(300):
+        ts(*a2)
+        bad += (m2.flat_grad() != g0).any().float() + (ts.loss != l0).any().float()
+    return {"final_loss": final, "matches_known": final == KNOWN, "bitwise_bad_steps": int(bad.item())}
+
+
+if __name__ == "__main__":
+    if "--child" in sys.argv:
+        print(json.dumps(run_checks()))
+        sys.exit(0)
+    base = subprocess.run([sys.executable, __file__, "--child"], capture_output=True, text=True)
+    line = base.stdout.strip().splitlines()[-1] if base.stdout.strip() else base.stderr[-300:]
+    print("product library:", line, flush=True)
+    ok = '"matches_known": true' in line and '"bitwise_bad_steps": 0' in line
+    if ok or "--bisect" not in sys.argv:
+        sys.exit(0 if ok else 1)
+    for env in ({}, {"PWR_DEFER_HEADS": "0"}, {"PWR_NORM_BWD_PAIR": "0"}, {"PWR_RESBLOCK_FUSE_BWD": "0"}, {"PWR_TR2_STATS": "0"}, {"PWR_WGRAD3_S2": "0"},
+                {"PWR_WGRAD3W": "0"}, {"PWR_SIDE_STREAM": "0"}, {"PWR_HEAD_BWD_PAIR": "0"}, {"PWR_PATCH_MF16": "0"}, {"PWR_RESBLOCK_FUSED": "0"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, __file__, "--child", "--debug-lib"], capture_output=True, text=True, env=e)
+        print("debug library", env, ":", (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
+    sys.exit(1)
