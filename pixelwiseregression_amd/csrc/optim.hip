@@ -12,8 +12,11 @@
 namespace pwr {
 
 // partial[block] = sum of squared differences of this block's elements; g = coef * (a - t)   (g may be null)
+// (loss != null: a one-block launch finishes the term itself -- loss[0] (+)= scale * its sum, the arithmetic of loss_finish_kernel on one
+// partial -- instead of a second launch; the uvd term of train.py:199 is 3 B J numbers)
 __global__ __launch_bounds__(256) void sqdiff_grad_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ g,
-                                                          float coef, float* __restrict__ partial, long long n) {
+                                                          float coef, float* __restrict__ partial, long long n, float scale = 0.f,
+                                                          float* __restrict__ loss = nullptr, int accumulate = 0) {
   __shared__ float red[4];
   float s = 0.f;
   for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
@@ -27,7 +30,10 @@ __global__ __launch_bounds__(256) void sqdiff_grad_kernel(const float* __restric
     }
   }
   s = block_sum1(s, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s;
+    if (loss) { const float tot = 0.f + s; loss[0] = accumulate ? loss[0] + scale * tot : scale * tot; }
+  }
 }
 
 // loss[0] (+)= scale * sum_k partial[k]
@@ -88,7 +94,11 @@ extern "C" int pwr_loss_sqdiff(const float* a, const float* t, float* g, float s
                                long long n, void* stream) {
   const int nb = pwr_loss_blocks(n);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(nb), dim3(256), 0, s, a, t, g, 2.f * scale, partial, n);
+  if (nb == 1) {
+    hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(1), dim3(256), 0, s, a, t, g, 2.f * scale, partial, n, scale, loss, accumulate);
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(nb), dim3(256), 0, s, a, t, g, 2.f * scale, partial, n, 0.f, (float*)nullptr, 0);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, partial, nb, scale, loss, accumulate);
   return (int)hipGetLastError();
 }
