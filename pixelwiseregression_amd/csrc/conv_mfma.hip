@@ -683,13 +683,17 @@ __global__ __launch_bounds__(256, PWR_OCC2(true)) void conv_wgrad_tr_group_kerne
 // The pitch is 2 C + 32 bytes here, so that the four (double-pitch) pixel rows of a 16-lane group still fall on different banks.  The
 // layer ran on the one-tap-per-workgroup gather kernel before (296 us alone, 540 us at the tail of the train step for the FLOPs of a
 // 44-us head layer: a global round trip and integer divisions per 32-pixel K step).
-template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0, int STR = 1>
+// KPX = 64 (round 4, second session): a K step of 64 output pixels instead of 32 -- the narrow layers (the heads' 128 -> J conv, the
+// 64-channel tiles) spend ~1 us per K step whatever the tile holds (barrier, staging round trip, 6 - 12 MFMAs per wave); half the steps.
+// Same pixel order inside a step (four 16-pixel MFMA K blocks instead of two), one staged row segment of 66 pixels; needs W % 64 == 0.
+template <int WM, int WN, int MR, int NR, int DEPTH = 2, int DBG = 0, int STR = 1, int KPX = 32>
 __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wgrad3_kernel(WgradParams p) {
   static_assert(DEPTH >= 2 && DEPTH % 2 == 0, "register stages: even, so that the LDS buffer parity follows the step parity");
   static_assert(STR == 1 || STR == 2, "stride 1 or 2");
+  static_assert(KPX == 32 || (KPX == 64 && STR == 1), "K step: 32 pixels, or 64 (stride 1)");
   typedef bf16_t T;
   typedef bf16x8 V;
-  constexpr int KP = 32, EP = 8, AP = STR == 1 ? KP + 2 : 2 * KP + 1;
+  constexpr int KP = KPX, EP = 8, AP = STR == 1 ? KP + 2 : 2 * KP + 1;
   constexpr int BM = WM * MR * 32, BN = WN * NR * 32;
   constexpr int PA = BM * 2 + (STR == 1 ? 64 : 32), PB = BN * 2 + 64;
   constexpr int TILE_A = AP * PA, TILE_B = KP * PB;
@@ -710,10 +714,14 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
   const int ci0 = mtile * BM, co0 = ntile * BN;
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
-  const int step0 = split * p.steps_per_split;
-  const int total_steps = p.M / KP;                 // W % 32 == 0 -> M % 32 == 0
+  // (the host counts K steps of 32 pixels; a 64-pixel step covers two of them: ceil(steps / 2) per split still covers everything, and a
+  // split beyond the end writes zeros)
+  const int sps = KP == 32 ? p.steps_per_split : (p.steps_per_split * 32 + KP - 1) / KP;
+  const int step0 = split * sps;
+  const int total_steps = p.M / KP;                 // W % KP == 0 -> M % KP == 0
   int nsteps = total_steps - step0;
-  if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+  if (nsteps > sps) nsteps = sps;
+  if (nsteps < 0) nsteps = 0;
   const int OHt = STR == 1 ? p.H : p.Ho;            // rows of the image the K tiles walk (the output)
   const int tiles_x = (STR == 1 ? p.W : p.Wo) / KP;
   const size_t plane = (size_t)p.B * p.Cin;
@@ -840,32 +848,36 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
     if (rowok_cur) {
       const char* lA = smem + buf * (TILE_A + TILE_B);
       const char* lB = lA + TILE_A;
-      // all fragment reads of the step are issued first (16 fragments, 64 VGPRs): the MFMAs then start as their operands
+      // all fragment reads of a 32-pixel half step are issued first (16 fragments, 64 VGPRs): the MFMAs then start as their operands
       // arrive instead of exposing one LDS round trip per group
-      V bf[2][NR], af[2][3][MR];
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
+      for (int hh = 0; hh < KP / 32; ++hh) {
+        V bf[2][NR], af[2][3][MR];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) bf[ss][j] = (DBG & 2) ? V{(bf16_t)(float)lane} : frag_tr(lB, PB, ss * 16, wn * NR * 32 + j * 32, lane);
+        for (int ss = 0; ss < 2; ++ss) {
+          const int k0 = hh * 32 + ss * 16;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+          for (int j = 0; j < NR; ++j) bf[ss][j] = (DBG & 2) ? V{(bf16_t)(float)lane} : frag_tr(lB, PB, k0, wn * NR * 32 + j * 32, lane);
 #pragma unroll
-          for (int i = 0; i < MR; ++i)
-            af[ss][t][i] = (DBG & 2) ? V{(bf16_t)(float)(lane + t)}
-                                     : (STR == 1 ? frag_tr(lA, PA, ss * 16 + t, wm * MR * 32 + i * 32, lane)
-                                                 : frag_tr(lA + t * PA, 2 * PA, ss * 16, wm * MR * 32 + i * 32, lane));
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+              af[ss][t][i] = (DBG & 2) ? V{(bf16_t)(float)(lane + t)}
+                                       : (STR == 1 ? frag_tr(lA, PA, k0 + t, wm * MR * 32 + i * 32, lane)
+                                                   : frag_tr(lA + t * PA, 2 * PA, k0, wm * MR * 32 + i * 32, lane));
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+              for (int j = 0; j < NR; ++j) {
+                if (DBG & 1) asm volatile("" ::"v"(af[ss][t][i]), "v"(bf[ss][j]));
+                else acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ss][t][i], bf[ss][j], acc[t][i][j], 0, 0, 0);
+              }
       }
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-              if (DBG & 1) asm volatile("" ::"v"(af[ss][t][i]), "v"(bf[ss][j]));
-              else acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ss][t][i], bf[ss][j], acc[t][i][j], 0, 0, 0);
-            }
     }
     store_lds(sg[(kk + 1) % DEPTH], buf ^ 1);        // (after the last step: a tile nobody reads)
     __syncthreads();
@@ -1069,6 +1081,17 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (wgrad9w_applicable(p)) return launch_wgrad9w(p, s);                  // whole 128-channel tiles: the wave-specialised nine-tap kernel
     if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // (its three-tap predecessor: debug build, PWR_WGRAD9W=0)
+    // K steps of 64 pixels for the narrow three-tap layers on maps whose width is a multiple of 64 (round 4; PWR_WGRAD3_KP64 bits, debug
+    // build: 1 = <= 32 output channels -- the heads' 128 -> J conv --, 2 = 64 x 64 tiles, 4 = the 64 x 128 tile of <= 64 input channels,
+    // 8 = also the norm-fed 64 -> 64 layers that the LDS-DMA kernel would take).  Isolated at the engine's splits: 61.5 -> 46.4 us,
+    // 95 -> 78, 175 -> 141, 51.3 -> 37.9; train step 5.523 -> 5.464 ms with all four (5.505 / 5.494 / 5.482 with bits 1 / 6 / 9).
+    static const int kp64 = PWR_DBG_ENV("PWR_WGRAD3_KP64", 15);
+    const bool w64 = p.ksize == 3 && p.stride == 1 && p.W % 64 == 0 && p.M % 64 == 0;
+    if (w64 && (kp64 & 8) && bn == 64 && p.Cin <= 64) {
+      dim3 g64(24 * ((p.S + 7) / 8), ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
+      hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1, 2, 0, 1, 64>), g64, block, 0, s, p);
+      return (int)hipGetLastError();
+    }
     if (wgrad3d_applicable(p)) return launch_wgrad3d(p, s);                  // operands by LDS-DMA (no norm to apply on the way)
     if (p.ksize == 3 && p.stride == 2 && p.Wo % 32 == 0 && p.H == 2 * p.Ho && p.W == 2 * p.Wo && bn == 128 && p.Cin % 64 == 0 &&
         PWR_DBG_ENV("PWR_WGRAD3_S2", 1)) {
@@ -1082,6 +1105,17 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       // 128 output channels: 64 (ci) x 128 (co) x 3 taps per workgroup = 96 accumulator registers -> TWO workgroups per CU,
       // so one's norm/ReLU staging (VALU) and waits overlap the other's MFMAs; the x tile (the operand that needs VALU work)
       // is split between them, not duplicated.  (128 x 128 x 3 = 192 registers allows one wave per SIMD only: 25 % MFMA busy.)
+      if (w64 && (kp64 & 1) && bn == 32) { hipLaunchKernelGGL((conv_wgrad3_kernel<4, 1, 1, 1, 2, 0, 1, 64>), g3, block, 0, s, p); return (int)hipGetLastError(); }
+      if (w64 && (kp64 & 2) && bn == 64 && p.Cin <= 64) {
+        dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
+        hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 1, 2, 0, 1, 64>), g64, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
+      if (w64 && (kp64 & 4) && bn == 128 && p.Cin <= 64) {
+        dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
+        hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 0, 1, 64>), g64, block, 0, s, p);
+        return (int)hipGetLastError();
+      }
       static const bool bm64 = (PWR_DBG_ENV("PWR_WGRAD3_BM64", 1) != 0);
 #ifdef PWR_DEBUG_BUILD
       if (bn == 128 && p.Cin <= 64 && PWR_DBG_ENV("PWR_WGRAD3_CO64", 0)) {

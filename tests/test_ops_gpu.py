@@ -276,6 +276,31 @@ def test_wgrad3_stride2(case, prologue):
         assert torch.equal(dw, K.conv_wgrad(xd, dyd, Cout, 3, 2, norm=st, relu_in=True, splits=splits))
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 16, 14, 7), (3, 8, 128, 32, 64, 64, 5), (2, 64, 64, 64, 64, 64, 9), (2, 16, 64, 64, 128, 128, 3),
+                                  (5, 64, 64, 128, 32, 21, 80), (3, 12, 192, 64, 64, 64, 11)])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_wgrad3_64_pixel_steps(case, prologue):
+    """conv_wgrad3_kernel<..., KPX = 64>: the narrow three-tap layers (<= 32 output channels: the heads' 128 -> J conv; 64-channel tiles) on
+    maps whose width is a multiple of 64 take K steps of 64 pixels.  Against F.conv2d's float64 weight gradient (zero-padded output
+    channels, splits with an odd number of 32-pixel steps -- the 64-pixel steps then cut the K range elsewhere --, splits that straddle
+    samples), repeatable bit for bit."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin, Cout, cr, splits = case
+    x, dy = rnd(B, Cin, H, W, seed=31), rnd(B, Cout, H, W, seed=32)
+    dy[:, cr:] = 0
+    xin = q(x, torch.bfloat16)
+    st = None
+    if prologue:
+        xin, st = apply_nr(xin, B, Cin, torch.bfloat16)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w, None, padding=1).backward(q(dy, torch.bfloat16))
+    xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
+    dw = K.conv_wgrad(xd, dyd, cr, 3, 1, norm=st, relu_in=True, splits=splits).clone()
+    assert_close(dw.double().cpu(), w.grad[:cr], 1.5e-2, "three-tap wgrad, 64-pixel steps %s" % (case,))
+    for _ in range(3):
+        assert torch.equal(dw, K.conv_wgrad(xd, dyd, cr, 3, 1, norm=st, relu_in=True, splits=splits))
+
+
 def test_grouped_weight_gradients_match_float64():
     """pwr_conv_wgrad_group: the 24 conv layers of one stage's small-map ResBlocks (16x16 .. 2x2, 1x1 128->64, 3x3 64->64, 1x1 64->128,
     norm + ReLU on the operand load) in ONE grouped launch, each against F.conv2d's float64 weight gradient; repeatable bit for bit."""

@@ -4,7 +4,7 @@ with --bisect: the same two checks under the debug build's switches, one at a ti
    python tools/lease_check.py [--debug-lib] [--bisect]"""
 import os, sys, json, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-KNOWN = 0.014110531657934189     # (220 AdamW steps of this script; bench.py runs 230 and ends at 0.012000063434243202)
+KNOWN = 0.014317275024950504     # (220 AdamW steps of this script with the final build; the value changes whenever the arithmetic of a kernel does)
 
 
 def run_checks():
