@@ -1131,6 +1131,8 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
       if (bn == 128 && bm64) {
         dim3 g64(g3.x, ((p.Cin + 63) / 64) * (p.CoutPad / bn), 1);
 #ifdef PWR_DEBUG_BUILD
+        // (experiment: the 64 x 128 tile with 64-pixel K steps for the 128-channel layers as well -- reached with PWR_WGRAD3W=0)
+        if (w64 && (kp64 & 16)) { hipLaunchKernelGGL((conv_wgrad3_kernel<2, 2, 1, 2, 2, 0, 1, 64>), g64, block, 0, s, p); return (int)hipGetLastError(); }
         // (experiments, debug build only: register prefetch depth 4 -- measured 82.6 vs 81.7 us, not latency-bound -- and the
         // timing-by-elimination variants)
         static const int depth = PWR_DBG_ENV("PWR_WGRAD3_DEPTH", 2);

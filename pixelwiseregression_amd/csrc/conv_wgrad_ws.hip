@@ -457,6 +457,7 @@ bool wgrad3w_applicable(const WgradParams& p) {
   const int on = PWR_DBG_ENV("PWR_WGRAD3W", 1);
   const bool cin_ok = p.Cin % 128 == 0 ? p.CinPad == p.Cin : (p.Cin == 64 && on == 3);
   if (!on || p.ksize != 3 || p.stride != 1 || p.W % 32 || p.M % 32 || !cin_ok || p.Cout % 128 || p.CoutPad != p.Cout) return false;
+  if (on == 2 && p.in_norm) return false;      // (2: only the layers whose operand carries no norm; the norm-fed ones take the register-staged kernel)
   return p.steps_per_split <= (ws::MAXSB - 1) * (p.H * p.W / 32);
 }
 
