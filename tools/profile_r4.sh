@@ -31,6 +31,7 @@ du -sh $O
 # the GPU suite, the default bench line (accuracy block and CPU baseline included) and the smoke test of the same build, on the same lease
 python -m pytest tests -m gpu -q -rf 2>&1 | tail -40 > $O/summary/r4_pytest_gpu.txt; cat $O/summary/r4_pytest_gpu.txt
 python bench.py 2>/dev/null > $O/summary/r4_bench.json; cut -c1-330 $O/summary/r4_bench.json
+python tools/lease_check.py 2>&1 | grep "product library" > $O/summary/r4_lease_check.txt; cat $O/summary/r4_lease_check.txt
 python -c "
 import __graft_entry__ as g
 g.smoke(); print('smoke ok')" 2>&1 | tail -2
