@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 4   /* 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 4   /* 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
