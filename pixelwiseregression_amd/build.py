@@ -26,8 +26,16 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.
          "-Wno-unused-result", "-ffp-contract=off", "-fno-slp-vectorize"]
 
 
+DEBUG_SRC = os.path.join(ROOT, "tools", "csrc_debug")   # experiments that only the debug build compiles (never part of the product)
+_debug_sources = False
+
+
 def _sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    """source paths: csrc/*.hip, and in the debug build tools/csrc_debug/*.hip as well"""
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
+    if _debug_sources and os.path.isdir(DEBUG_SRC):
+        out += [os.path.join(DEBUG_SRC, f) for f in sorted(os.listdir(DEBUG_SRC)) if f.endswith((".hip", ".cpp"))]
+    return out
 
 
 def _digest(paths):
@@ -46,7 +54,7 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
     debugging entry points of include/pwr_debug.h exist), into tools/_build/libpwr_hip_dbg.so -- never into the package directory;
     tools/dbglib.py loads it for the measurement scripts.  extra_flags: further -D / -f flags for a debug variant.
     Every freshly linked library is scanned for the packed-f32 instruction form of DESIGN.md section 2 (codeobj_scan)."""
-    global FLAGS, LIB, OBJ
+    global FLAGS, LIB, OBJ, _debug_sources
     if debug or extra_flags:
         if not debug:
             raise ValueError("extra_flags only with debug=True: the product library has one configuration")
@@ -55,18 +63,19 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
         tag = "".join(c if c.isalnum() else "_" for c in "".join(extra_flags))        # a variant per set of extra flags
         FLAGS, LIB, OBJ = (FLAGS + ["-DPWR_DEBUG_BUILD"] + list(extra_flags), os.path.join(bdir, "libpwr_hip_dbg%s.so" % tag),
                            os.path.join(bdir, "obj" + tag))
+        _debug_sources = True
         try:
             return build(force, verbose)
         finally:
             FLAGS, LIB, OBJ = saved
+            _debug_sources = False
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
     headers += [os.path.join(ROOT, "include", "pwr.h"), os.path.join(ROOT, "include", "pwr_debug.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs = []
-    for src in _sources():
-        sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src + ".o")
+    for sp in _sources():
+        op = os.path.join(OBJ, os.path.basename(sp) + ".o")
         stamp = op + ".sha"
         dig = _digest([sp] + headers)
         if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
@@ -87,7 +96,7 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s_ + ".o") for s_ in _sources()]
+    objs = [os.path.join(OBJ, os.path.basename(s_) + ".o") for s_ in _sources()]
     if jobs or not os.path.exists(LIB) or force:
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -105,12 +114,12 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
             ok = rec.get("sha256") == codeobj_scan.lib_digest(LIB)
         except (OSError, ValueError):
             pass
-        if not ok:                       # an up-to-date library without a matching scan record: scan it now
-            _scan_gate(LIB, verbose)
+        if not ok:                       # an up-to-date library without a matching scan record: scan it now (never delete it for a
+            _scan_gate(LIB, verbose, keep=True)      # missing toolchain: tests/test_boundary_cpu.py flags a library without a record)
     return LIB
 
 
-def _scan_gate(lib, verbose=True):
+def _scan_gate(lib, verbose=True, keep=False):
     """No packed f32 instruction with a cross-half op_sel may ship, and no instruction may touch the
     destination of an inline-asm LDS read before its wait (conv_wgrad_dma.hip, the loader waves of conv_wgrad_ws.hip): checked on every
     link, with the LLVM tools of the hipcc that built the library.  The result is written beside the library (<lib>.scan.json, keyed by
@@ -121,7 +130,8 @@ def _scan_gate(lib, verbose=True):
     from . import codeobj_scan
     if not codeobj_scan.available():
         if os.environ.get("PWR_ALLOW_UNSCANNED") != "1":
-            os.remove(lib)
+            if not keep:
+                os.remove(lib)
             raise RuntimeError("llvm-objdump / llvm-objcopy not found next to %s: the code-object scan cannot run.  Point HIPCC at a ROCm "
                                "prefix that has lib/llvm/bin, or set PWR_ALLOW_UNSCANNED=1 to build an UNSCANNED library (tests will flag it)"
                                % os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))

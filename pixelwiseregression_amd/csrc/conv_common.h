@@ -207,8 +207,10 @@ int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t
 bool conv_tr2_applicable(const ConvParams& p, int dtype);   // stride-2 data gradient as four parity-class patch convs
 int launch_conv_tr2(const ConvParams& p, hipStream_t s);
 int conv_tr2_stats_chunks(const ConvParams& p, int dtype);   // slab rows per sample of its norm-backward sums, 0 = unsupported
+#ifdef PWR_DEBUG_BUILD
 void set_debug_stamps(long long* ptr);
 void set_debug_delay(int d);
+#endif
 
 // conv_wgrad_dma.hip: 3x3 weight gradient with both operands staged by LDS-DMA (operand already normalised: in_norm == null)
 bool wgrad3d_applicable(const WgradParams& p);
@@ -216,9 +218,11 @@ int launch_wgrad3d(const WgradParams& p, hipStream_t s);
 
 // conv_wgrad_ws.hip: 3x3 weight gradient of whole 128-channel tiles, wave-specialised (4 MFMA waves + 4 loader waves per workgroup);
 // one job or two jobs of one geometry per launch
-// conv_wgrad_ws9.hip: the same layers with all nine taps per workgroup (64 x 64-channel tiles, the K walk down the image columns)
+#ifdef PWR_DEBUG_BUILD
+// tools/csrc_debug/conv_wgrad_ws9.hip (debug build only; measured slower): the same layers with all nine taps per workgroup
 bool wgrad9w_applicable(const WgradParams& p);
 int launch_wgrad9w(const WgradParams& p, hipStream_t s);
+#endif
 bool wgrad3w_applicable(const WgradParams& p);
 int launch_wgrad3w(const WgradParams& a, const WgradParams* b, hipStream_t s);
 

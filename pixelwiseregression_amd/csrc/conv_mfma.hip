@@ -729,7 +729,9 @@ __global__ __launch_bounds__(256, PWR_OCC2(3 * MR * NR * 16 <= 96)) void conv_wg
   // tile coordinates of step `st` (incremental, no divisions in the loop)
   int tb, ty, tx;   // batch, row, x tile of the NEXT tile to be loaded
   {
-    const int t0 = step0;
+    // (an empty split -- the 64-pixel re-cut of an odd steps_per_split leaves trailing splits past the end -- starts on the last valid tile:
+    // nothing below may ever form an address from tb >= B)
+    const int t0 = step0 < total_steps ? step0 : total_steps - 1;
     tb = t0 / (OHt * tiles_x);
     const int rem = t0 - tb * OHt * tiles_x;
     ty = rem / tiles_x; tx = rem - ty * tiles_x;
@@ -1079,8 +1081,10 @@ static int launch_wgrad(const WgradParams& p, hipStream_t s) {
   const int taps = p.ksize * p.ksize;
   dim3 grid(taps, (p.CinPad / 128) * (p.CoutPad / bn), p.S), block(256);
   if constexpr (sizeof(T) == 2) {
-    if (wgrad9w_applicable(p)) return launch_wgrad9w(p, s);                  // whole 128-channel tiles: the wave-specialised nine-tap kernel
-    if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // (its three-tap predecessor: debug build, PWR_WGRAD9W=0)
+#ifdef PWR_DEBUG_BUILD
+    if (wgrad9w_applicable(p)) return launch_wgrad9w(p, s);                  // (debug build, PWR_WGRAD9W=1: the nine-tap experiment, measured slower)
+#endif
+    if (wgrad3w_applicable(p)) return launch_wgrad3w(p, nullptr, s);         // whole 128-channel tiles: the wave-specialised three-tap kernel (the product path)
     // K steps of 64 pixels for the narrow three-tap layers on maps whose width is a multiple of 64 (round 4; PWR_WGRAD3_KP64 bits, debug
     // build: 1 = <= 32 output channels -- the heads' 128 -> J conv --, 2 = 64 x 64 tiles, 4 = the 64 x 128 tile of <= 64 input channels,
     // 8 = also the norm-fed 64 -> 64 layers that the LDS-DMA kernel would take).  Isolated at the engine's splits: 61.5 -> 46.4 us,

@@ -19,8 +19,13 @@
 
 namespace pwr {
 
-static long long* g_stamps = nullptr;     // (debug build: pwr_debug_set_stamps; always null in the shipped library)
-static int g_delay = PWR_DBG_ENV("PWR_PATCH_DELAY", 0);      // (debug build: pwr_debug_set_delay / the environment)
+#ifdef PWR_DEBUG_BUILD
+static long long* g_stamps = nullptr;     // (pwr_debug_set_stamps)
+static int g_delay = PWR_DBG_ENV("PWR_PATCH_DELAY", 0);      // (pwr_debug_set_delay / the environment)
+#else
+static constexpr long long* g_stamps = nullptr;     // the shipped library has neither the stamps nor the delay, nor their setters
+static constexpr int g_delay = 0;
+#endif
 __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 #ifdef PWR_DEBUG_BUILD
   if (p.stamps && threadIdx.x == 0) {
@@ -830,8 +835,10 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
   return launch_patch_cin<T, 32>(p, s);
 }
 
+#ifdef PWR_DEBUG_BUILD
 void set_debug_stamps(long long* ptr) { g_stamps = ptr; }
 void set_debug_delay(int d) { g_delay = d; }
+#endif
 
 template <int CIN>
 static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {

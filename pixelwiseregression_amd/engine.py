@@ -194,6 +194,22 @@ class _EngineFn(torch.autograd.Function):
         return (None,) * 6
 
 
+_warned_fp16 = False
+
+
+def _warn_fp16_autocast():
+    """/root/reference/train.py:170-189 runs `torch.cuda.amp.autocast()` -- float16 -- with a GradScaler.  This engine has ONE reduced
+    precision, bfloat16 (BASELINE config: "Adam, bf16"): same 16-bit storage and the same MFMA rate on gfx950, 8 exponent bits instead of
+    5, so nothing overflows and the caller's GradScaler never has to skip a step.  The substitution is not silent: say so, once."""
+    global _warned_fp16
+    if not _warned_fp16:
+        _warned_fp16 = True
+        import warnings
+        warnings.warn("pixelwiseregression_amd: float16 autocast requested; the engine computes convolutions in bfloat16 instead "
+                      "(fp32 accumulation, fp32 decoder).  A GradScaler around it is harmless and never sees an overflow.  Use "
+                      "torch.autocast('cuda', dtype=torch.bfloat16) or model.set_precision('bf16') to silence this.", UserWarning, stacklevel=3)
+
+
 def engine_forward(model, img, label_img, mask):
     B = img.shape[0]
     S, P = 2 * model.label_size, model.label_size
@@ -203,7 +219,10 @@ def engine_forward(model, img, label_img, mask):
                            (S, S, P, P, tuple(img.shape), tuple(label_img.shape), tuple(mask.shape)))
     model._check_flat()
     img, label_img, mask = (t.contiguous().float() for t in (img, label_img, mask))
-    dtype = BF16 if (model._precision == "bf16" or torch.is_autocast_enabled()) else F32
+    autocast = torch.is_autocast_enabled()
+    if autocast and torch.get_autocast_dtype("cuda") == torch.float16:
+        _warn_fp16_autocast()
+    dtype = BF16 if (model._precision == "bf16" or autocast) else F32
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model._param_list)
     plan = _get_plan(model, B, dtype, need_grad)
     if need_grad:

@@ -260,6 +260,11 @@ def test_shipped_library_has_one_configuration():
     exported = {l.split()[-1] for l in nm if " T " in l}
     assert "getenv" not in undefined and "secure_getenv" not in undefined
     assert not [e for e in exported if e.startswith("pwr_debug")] and "pwr_engine_set_join" not in exported and "pwr_engine_layout" not in exported
+    # ... and no C++ (mangled) debugging setter or debug-only experiment either: pwr::set_debug_*, the nine-tap weight-gradient experiment
+    allsyms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    dem = subprocess.run(["c++filt"], input=allsyms, capture_output=True, text=True, check=True).stdout
+    assert not [l for l in dem.splitlines() if "debug" in l.lower() or "wgrad9w" in l], [l for l in dem.splitlines() if "debug" in l.lower() or "wgrad9w" in l][:5]
+    assert not os.path.exists(os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "conv_wgrad_ws9.hip"))
     assert set(_lib.SIGNATURES) <= exported
     assert glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "*.so")) == [_lib.LIB_PATH]
 

@@ -277,7 +277,9 @@ def test_wgrad3_stride2(case, prologue):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 128, 16, 14, 7), (3, 8, 128, 32, 64, 64, 5), (2, 64, 64, 64, 64, 64, 9), (2, 16, 64, 64, 128, 128, 3),
-                                  (5, 64, 64, 128, 32, 21, 80), (3, 12, 192, 64, 64, 64, 11)])
+                                  (5, 64, 64, 128, 32, 21, 80), (3, 12, 192, 64, 64, 64, 11),
+                                  # odd steps_per_split with many splits: the 64-pixel re-cut leaves EMPTY trailing splits (exact-size tensors)
+                                  (18, 64, 64, 128, 16, 14, 256), (6, 64, 64, 64, 64, 64, 256)])
 @pytest.mark.parametrize("prologue", [False, True])
 def test_wgrad3_64_pixel_steps(case, prologue):
     """conv_wgrad3_kernel<..., KPX = 64>: the narrow three-tap layers (<= 32 output channels: the heads' 128 -> J conv; 64-channel tiles) on

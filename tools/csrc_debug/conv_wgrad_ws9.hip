@@ -25,18 +25,15 @@
 // MEASURED SLOWER than conv_wgrad_ws.hip (profiles/r4_experiments.md section 7: 2.36 MFLOP per barrier interval is too little -- the
 // interval has a floor of ~0.3 us of barrier + loop control that the three-tap kernel spreads over 3.1 MFLOP -- isolated 67 against 56 us
 // without a norm, in the train step 5.75 against 5.70 ms at its best workgroup count).  It is an EXPERIMENT: compiled into the DEBUG build
-// only (tools/build_debug.py, PWR_WGRAD9W=1 selects it); the shipped library contains a stub that never applies.
+// only (tools/build_debug.py picks up tools/csrc_debug/*.hip, PWR_WGRAD9W=1 selects it); the shipped library does not contain it.
 #include <cstdlib>
 
 #include "conv_common.h"
 #include "pwr.h"
 
 #ifndef PWR_DEBUG_BUILD
-namespace pwr {
-bool wgrad9w_applicable(const WgradParams&) { return false; }
-int launch_wgrad9w(const WgradParams&, hipStream_t) { return PWR_EUNSUPPORTED; }
-}  // namespace pwr
-#else
+#error "debug-build source (tools/build_debug.py): not part of the product library"
+#endif
 
 namespace pwr {
 
@@ -413,4 +410,4 @@ int launch_wgrad9w(const WgradParams& p0, hipStream_t s) {
 }
 
 }  // namespace pwr
-#endif   // PWR_DEBUG_BUILD
+   // PWR_DEBUG_BUILD
