@@ -26,6 +26,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.
          "-Wno-unused-result", "-ffp-contract=off", "-fno-slp-vectorize"]
 
 
+# per-source flags.  conv_wstat.hip: its K loop (36 steps x 8 slots, every register index a compile-time constant) must unroll completely;
+# the default cap on a pragma-requested unroll (16384 IR instructions, counted BEFORE the per-slot constants fold) stops it silently otherwise
+# (a warning, and a kernel whose register arrays live in scratch)
+PER_FILE_FLAGS = {"conv_wstat.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Werror=pass-failed"]}
 DEBUG_SRC = os.path.join(ROOT, "tools", "csrc_debug")   # experiments that only the debug build compiles (never part of the product)
 _debug_sources = False
 
@@ -77,14 +81,14 @@ def build(force=False, verbose=True, debug=False, extra_flags=()):
     for sp in _sources():
         op = os.path.join(OBJ, os.path.basename(sp) + ".o")
         stamp = op + ".sha"
-        dig = _digest([sp] + headers)
+        dig = _digest([sp] + headers) + "|" + " ".join(PER_FILE_FLAGS.get(os.path.basename(sp), []))
         if not force and os.path.exists(op) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue
         jobs.append((sp, op, stamp, dig))
 
     def run(job):
         sp, op, stamp, dig = job
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", sp, "-o", op]
+        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(sp), []) + ["-x", "hip", "-c", sp, "-o", op]
         if verbose:
             print("[pwr build]", os.path.basename(sp), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

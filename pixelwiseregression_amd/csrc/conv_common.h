@@ -212,6 +212,12 @@ void set_debug_stamps(long long* ptr);
 void set_debug_delay(int d);
 #endif
 
+// conv_wstat.hip (round 5): the 128 -> 128 3x3 stride-1 bf16 conv with the weights stationary in registers, persistent workgroups;
+// one job (b == nullptr) or two jobs of one geometry per launch
+bool conv_wstat_applicable(const ConvParams& p, int dtype);
+bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype);
+int launch_conv_wstat(const ConvParams& a, const ConvParams* b, hipStream_t s);
+
 // conv_wgrad_dma.hip: 3x3 weight gradient with both operands staged by LDS-DMA (operand already normalised: in_norm == null)
 bool wgrad3d_applicable(const WgradParams& p);
 int launch_wgrad3d(const WgradParams& p, hipStream_t s);

@@ -921,6 +921,7 @@ bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dt
   return on && ok(a) && ok(b) && a.B == b.B && a.H == b.H && a.W == b.W && a.Cin == b.Cin && PWR_DBG_ENV("PWR_PATCH_MF16", 1) == 1 && PWR_DBG_ENV("PWR_PATCH_BIG", 0) == 0;
 }
 int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s) {
+  if (conv_wstat_pair_applicable(a, b, PWR_BF16)) return launch_conv_wstat(a, &b, s);
   ConvPair g{a, b};
   g.a.epi16 = g.b.epi16 = 1;
   g.a.stamps = g.b.stamps = nullptr;
@@ -946,6 +947,7 @@ int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
     return launch_patch_1x1<32>(p, s);
   }
   if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);
+  if (conv_wstat_applicable(p, dtype)) return launch_conv_wstat(p, nullptr, s);
   return dtype == PWR_BF16 ? launch_patch_t<bf16_t>(p, s) : launch_patch_t<float>(p, s);
 }
 

@@ -1,0 +1,356 @@
+// 3x3 stride-1 convolution 128 -> 128 channels, bf16, WEIGHT-STATIONARY and persistent (round 5): the heads' convs and their data gradients,
+// 72 % of the conv FLOPs of /root/reference/model.py:54-65 / :103-114.
+//
+// Why another form.  conv3x3_patch_kernel (conv_patch.hip) spends 30 % of a workgroup's life staging its input patch, 53 % in the K loop and
+// 17 % in the epilogue, the two workgroups of a CU run in phase, and it streams all 288 KiB of weights through LDS for every 128-pixel tile
+// (a 3-stage LDS-DMA ring with a barrier per 32-channel K step): 0.355 of the bf16 MFMA peak for two rounds.  Here:
+//   * ONE workgroup of 4 waves per CU, ONE wave per SIMD, all 512 registers of the SIMD; the workgroup is PERSISTENT and walks tiles.
+//   * The WEIGHTS live in REGISTERS for the whole launch: wave w owns output channels 32 w ... 32 w + 31 for the whole K extent
+//     (9 taps x 128 input channels = 36 K steps x 2 row blocks x 4 registers = 288 VGPRs), loaded once from L2.  No weight traffic through LDS,
+//     no weight ring, NO barrier inside the K loop.  LDS read traffic per MFMA halves (only the pixel operand is read from LDS).
+//   * MFMA operands are swapped against conv_patch.hip: A = weights (rows = output channels), B = pixels (columns), v_mfma_f32_16x16x32_bf16.
+//     The accumulator of a lane is then 4 consecutive channels of ONE pixel per row block; with the channel <-> MFMA-row assignment
+//     ch = 8 (row / 4) + 4 block + row % 4 a lane holds 8 CONSECUTIVE channels of a pixel: the epilogue is bias + round + ONE 16-byte NHWC store
+//     per pixel block straight from registers (no LDS round trip), and the column statistics fall out in exactly the per-thread order of the
+//     one-pass epilogue of conv_patch.hip (same K-step order, same MFMA shape, same operands => outputs AND statistics bit-identical to it;
+//     tests/test_00_kat_gpu.py holds both kernels to the same digests).
+//   * The input patch (6 x 34 pixels x 128 channels, norm + ReLU applied on the way, pixel pitch padded by 16 B like conv_patch.hip) is DOUBLE
+//     buffered in LDS (2 x 54 KiB): the patch of tile n + 1 is loaded, normalised and written while the MFMAs of tile n issue -- the wave's own
+//     software pipeline, since a second wave per SIMD does not fit beside 288 weight registers.  One barrier per tile.
+// Work per tile and wave: 576 MFMAs (9216 matrix-pipe cycles), 288 ds_read_b128, 13 global loads + 13 ds_write_b128 + ~550 VALU of staging,
+// ~500 VALU of epilogue: the vector work has to ride in the issue shadow of the MFMAs (sched_group_barrier pipelines below).
+#include "conv_common.h"
+#include "pwr.h"
+
+namespace pwr {
+
+struct WstatArgs {
+  ConvParams job[2];
+  int njobs, wgs_per_job;
+};
+
+namespace wst {
+constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN * 2 + 16;
+constexpr int NITP = 13;                 // staging vectors per thread: 204 pixels x 16 slots / 256 threads ...
+constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 208 pixels: the last round's 4 surplus pixels are written (never read), no branch
+// Staging schedule inside the K loop.  A SLOT is an MFMA pair (8 per K step, 288 per tile = 32 matrix-pipe cycles each); the vector ALU can
+// issue about two instructions per MFMA without delaying the next one, so a slot carries ONE micro-op (two vector instructions) of the
+// next patch's staging: vector k's 21 micro-ops run in slots S0(k) ... S0(k) + 20, its global load is issued LEAD slots earlier.
+constexpr int SLOTS = ITERS * 8, MICRO = 21, SLOT0 = 12, LEAD = 40;
+__host__ __device__ constexpr int slot0(int k) { return SLOT0 + MICRO * k; }
+__host__ __device__ constexpr int load_slot(int k) { return slot0(k) - LEAD > k ? slot0(k) - LEAD : k; }
+// the vector whose load is issued in slot g, or -1 (closed form: a search loop here keeps the K loop from unrolling)
+__host__ __device__ constexpr int load_of(int g) {
+  const int kk = (g + LEAD - SLOT0) / MICRO;
+  return (g + LEAD - SLOT0 >= 0 && (g + LEAD - SLOT0) % MICRO == 0 && kk < NITP && load_slot(kk) == g) ? kk : ((g < NITP && load_slot(g) == g) ? g : -1);
+}
+static_assert(slot0(NITP) <= SLOTS, "staging schedule");
+static_assert(load_of(0) == 0 && load_of(1) == 1 && load_of(load_slot(2)) == 2 && load_of(load_slot(12)) == 12 && load_of(load_slot(5) + 1) == -1, "staging schedule");
+}  // namespace wst
+
+// NRM: the input carries a pending norm + ReLU (forward); KIND: 0 no statistics, 1 forward statistics, 2 norm-backward sums (data gradient)
+template <bool NRM, int KIND>
+__global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a) {
+  using namespace wst;
+  typedef bf16_t T;
+  typedef bf16x8 V;
+  constexpr int EP = 8;
+  __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = 32-channel group
+  const int px = lane & 15, rg = lane >> 4;                     // MFMA column (pixel of a 16-pixel block) / K group (B) = row group (D)
+  const int job = blockIdx.x % a.njobs, wgj = blockIdx.x / a.njobs;
+  const ConvParams& p = a.job[job];
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const int HW = p.H * p.W;
+  const int tiles_x = p.W >> 5, tiles_img = tiles_x * (p.H >> 2), ntiles = p.B * tiles_img;
+  // this workgroup's tiles: a contiguous range (consecutive tiles share halo rows: L2 / L1 hits), ranges of one XCD's workgroups adjacent
+  int t, t_end;
+  {
+    const int NW = a.wgs_per_job, nx = 8 / a.njobs;              // workgroups of one job sit on `nx` XCD labels (blockIdx % 8: speed only)
+    const int q = NW / nx, r = NW % nx, xl = wgj % nx;
+    const int c = (xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q) + wgj / nx;
+    t = (int)((long long)c * ntiles / NW);
+    t_end = (int)((long long)(c + 1) * ntiles / NW);
+  }
+  if (t >= t_end) return;
+
+  // ---- the weights of this wave: A fragments of all 36 K steps x 2 row blocks (lane = row % 16 + 16 * (K / 8))
+  V wreg[ITERS][2];
+  {
+    const int row = lane & 15, kg = lane >> 4;
+    const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int ch = 32 * wn + 8 * (row >> 2) + 4 * jb + (row & 3);
+        wreg[it][jb] = *reinterpret_cast<const V*>(w + ((size_t)it * p.CoutPad + ch) * 32 + kg * 8);
+      }
+    // Register files: the vector ALU only reaches the 256 architectural VGPRs, the MFMA reads its operands from either file.  Left alone the
+    // allocator puts most weights into VGPRs, runs out of them where the staging arithmetic lives and shuffles weights through AGPR spill
+    // slots (4 v_accvgpr_mov per MFMA operand, in the middle of the K loop).  So: the weights of taps 0 .. 7 are DEFINED in AGPRs (all 256
+    // of them) and stay there; tap 8, the accumulators and everything the vector ALU touches share the VGPRs.
+#pragma unroll
+    for (int it = 0; it < 32; ++it)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+a"(wreg[it][jb]));
+  }
+
+  // ---- staging of a patch.  Thread -> 16-byte channel slot st_slot of 13 patch pixels: vectors k = 0 .. 11 are patch row k / 2, columns
+  // 16 (k % 2) + st_pl (the 32 left columns of the 6 rows); vector 12 is the two right columns: row st_pl / 2, column 32 + st_pl % 2
+  // (st_pl < 12; the other threads write 4 surplus pixels behind the patch).  So a vector's global address is a SCALAR row base plus a
+  // per-thread column offset, its LDS address a per-thread base plus a constant, its validity a scalar row test and a per-thread column
+  // test: next to no vector arithmetic per load (the norm arithmetic is what has to ride beside the MFMAs).
+  const int H = p.H, W = p.W;
+  const int st_pl = tid >> 4, st_slot = tid & 15;
+  const int r12 = st_pl >> 1, c12 = 32 + (st_pl & 1);                      // vector 12's patch pixel
+  const int lds_st = (st_pl * PITCH) + st_slot * 16;                       // + (row * PW + 16 (k % 2)) * PITCH
+  const int lds_st12 = (st_pl < 12 ? (r12 * PW + c12) : (PP + st_pl - 12)) * PITCH + st_slot * 16;
+  V sv[NITP];
+  float mu[EP], sc[EP], be[EP];
+  struct TileCo { int b, y0, x0; };
+  struct StageCo {                 // per tile: scalar row bases (bytes from x), per-thread column byte offsets and validity masks
+    long long rowbase[6];          // clamped row (y0 + r - 1) of sample b
+    unsigned rowok;                // bit r: row y0 + r - 1 is inside the image
+    unsigned voff0, voff1, voff12; // byte offset of this thread's vector inside a row, for even k / odd k / k = 12 (clamped into the row)
+    long long rowbase12;           // (per thread) row base of vector 12
+    unsigned keep0, keep12;        // all-ones or zero: even k (odd k: always inside), k = 12
+  };
+  auto stage_co = [&](const TileCo& c) __attribute__((always_inline)) {
+    StageCo q;
+    q.rowok = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int iy = c.y0 + r - 1;
+      const bool ok = iy >= 0 && iy < H;
+      q.rowok |= (ok ? 1u : 0u) << r;
+      q.rowbase[r] = ((long long)c.b * HW + (long long)min(max(iy, 0), H - 1) * W) * (CIN * 2);
+    }
+    const int ix0 = c.x0 + st_pl - 1;                                      // even k: columns x0 - 1 ... x0 + 14
+    q.voff0 = (unsigned)(max(ix0, 0) * (CIN * 2) + st_slot * 16);
+    q.keep0 = ix0 >= 0 ? ~0u : 0u;
+    q.voff1 = (unsigned)((c.x0 + 15 + st_pl) * (CIN * 2) + st_slot * 16);  // odd k: columns x0 + 15 ... x0 + 30, always inside
+    const int ix12 = c.x0 + c12 - 1, iy12 = c.y0 + r12 - 1;
+    q.voff12 = (unsigned)(min(ix12, W - 1) * (CIN * 2) + st_slot * 16);
+    q.rowbase12 = ((long long)c.b * HW + (long long)min(max(iy12, 0), H - 1) * W) * (CIN * 2);
+    q.keep12 = (st_pl < 12 && ix12 < W && iy12 >= 0 && iy12 < H) ? ~0u : 0u;
+    return q;
+  };
+  auto stage_load = [&](const int k, const StageCo& q) __attribute__((always_inline)) {
+    const char* xb = reinterpret_cast<const char*>(x);
+    if (k < 12) sv[k] = *reinterpret_cast<const V*>(xb + q.rowbase[k >> 1] + ((k & 1) ? q.voff1 : q.voff0));
+    else sv[k] = *reinterpret_cast<const V*>(xb + q.rowbase12 + q.voff12);
+  };
+  auto stage_norm_load = [&](const TileCo& c) __attribute__((always_inline)) {
+    if constexpr (NRM) {
+      const size_t plane = (size_t)p.B * CIN;
+      const float* st = p.in_norm + (size_t)c.b * CIN + st_slot * EP;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
+    }
+  };
+  // A vector's way into LDS as a sequence of MICRO-OPS (compile-time index `op`), so that the K loop can hand them out two or three at a
+  // time behind each MFMA: with one wave per SIMD the vector work only costs nothing while it rides in the issue shadow of the matrix
+  // pipe, and left to itself the scheduler emits a vector's ~45 instructions as one lump (the pipe drains for ~200 cycles, 13 x per tile).
+  // Per channel pair j (10 ops): unpack lo / hi, - mean x 2, fma x 2, ReLU x 2, round + pack, mask; then op NOPS - 1: the 16-byte LDS store.
+  // Same arithmetic and rounding as conv_patch.hip's stage_patch (fmaf(x - mu, sc, be), max 0, one rounding to bf16).
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 so;
+  float t0 = 0.f, t1 = 0.f;
+  auto keep_of = [&](const int k, const StageCo& q) __attribute__((always_inline)) {
+    // (an arithmetic mask, not a select that hipcc turns into an exec-masked branch -- that would cut the K loop's scheduling region in
+    // two; row validity is a scalar)
+    if (k < 12) return (((k & 1) ? ~0u : q.keep0)) & (0u - ((q.rowok >> (k >> 1)) & 1u));
+    return q.keep12;
+  };
+  // micro-op u = 0 .. 20 of vector k: per channel pair j = u / 5: {unpack lo, unpack hi} {- mean, - mean} {fma, ReLU} {fma, ReLU} {round + pack,
+  // mask}; u = 20: the 16-byte LDS store.  (No norm: the pair's micro-op 4 masks the raw dword, the others are empty.)
+  auto stage_micro = [&](const int k, const int u, const StageCo& q, char* patch) __attribute__((always_inline)) {
+    if (u == MICRO - 1) {
+      const int off = k < 12 ? lds_st + ((k >> 1) * PW + 16 * (k & 1)) * PITCH : lds_st12;
+      *reinterpret_cast<u32x4*>(patch + off) = so;
+      return;
+    }
+    const int j = u / 5, o = u - 5 * j;
+    if constexpr (!NRM) {
+      if (o == 4) so[j] = __builtin_bit_cast(u32x4, sv[k])[j] & keep_of(k, q);
+    } else {
+      if (o == 0) { t0 = (float)sv[k][2 * j]; t1 = (float)sv[k][2 * j + 1]; }
+      else if (o == 1) { t0 = t0 - mu[2 * j]; t1 = t1 - mu[2 * j + 1]; }
+      else if (o == 2) t0 = fmaxf(fmaf(t0, sc[2 * j], be[2 * j]), 0.f);
+      else if (o == 3) t1 = fmaxf(fmaf(t1, sc[2 * j + 1], be[2 * j + 1]), 0.f);
+      else { bf16x2 pk; pk[0] = (bf16_t)t0; pk[1] = (bf16_t)t1; so[j] = __builtin_bit_cast(unsigned, pk) & keep_of(k, q); }
+    }
+  };
+  // tile coordinates walk incrementally (no division in the loop)
+  auto tile_next = [&](TileCo c) {
+    c.x0 += 32;
+    if (c.x0 == W) { c.x0 = 0; c.y0 += 4; if (c.y0 == H) { c.y0 = 0; ++c.b; } }
+    return c;
+  };
+
+  // ---- first patch: nothing to overlap with yet (the weight loads above are still landing)
+  TileCo cur;
+  {
+    cur.b = t / tiles_img;
+    const int tr = t - cur.b * tiles_img, tyi = tr / tiles_x;
+    cur.y0 = tyi * 4; cur.x0 = (tr - tyi * tiles_x) * 32;
+    const StageCo q = stage_co(cur);
+    stage_norm_load(cur);
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) stage_load(k, q);
+#pragma unroll
+    for (int k = 0; k < NITP; ++k)
+#pragma unroll
+      for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q, smem);
+  }
+  __syncthreads();
+
+  f32x4 acc[8][2];
+  const char* fbase = smem + px * PITCH + rg * 16;               // per-lane part of every B-fragment address (+ buffer, tap, K chunk: constants)
+  // ONE set of fragments: fragment i of step it + 1 is read into the registers of fragment i of step it right behind the two MFMAs that
+  // consume it (16 MFMAs = 256 matrix-pipe cycles ahead of its own use) -- a second set would cost 32 of the 512 registers
+  V pf[8];
+  auto frag_load1 = [&](const int it, const int i, const char* base) __attribute__((always_inline)) {
+    const int tap = it / KCH, kch = it - tap * KCH;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    pf[i] = *reinterpret_cast<const V*>(base + (((i >> 1) + ky) * PW + (i & 1) * 16 + kx) * PITCH + kch * 64);
+  };
+
+  int buf = 0;
+  for (; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    const TileCo nxt = more ? tile_next(cur) : cur;              // (the last tile re-stages itself into the other buffer: branch-free K loop)
+    const StageCo q = stage_co(nxt);
+    const char* pb = fbase + buf * PATCH_BYTES;
+    char* nb = smem + (buf ^ 1) * PATCH_BYTES;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) acc[i][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) frag_load1(0, i, pb);
+    stage_norm_load(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // a slot: the two MFMAs of pixel block i, the read that refills their fragment for the next step, this slot's share of the staging
+        // work (wst::slot0 / load_slot), a full scheduling barrier: the emitted order IS this order
+        const int g = it * 8 + i;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+          acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[it][jb], pf[i], acc[i][jb], 0, 0, 0);
+        if (it + 1 < ITERS) frag_load1(it + 1, i, pb);
+        if (load_of(g) >= 0) stage_load(load_of(g), q);
+        if (g >= SLOT0 && g < slot0(NITP)) {
+          const int k = (g - SLOT0) / MICRO, u = (g - SLOT0) - k * MICRO;
+          stage_micro(k, u, q, nb);
+          // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
+          // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
+          if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- epilogue straight from the accumulators: lane (px, rg) holds channels n .. n + 7 of tile pixel 16 i + px, i = 0 .. 7
+    {
+      const int n = 32 * wn + 8 * rg;
+      float bias_r[EP];
+      {
+        const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
+      }
+      T* __restrict__ y = reinterpret_cast<T*>(p.y);
+      const size_t m0 = (size_t)cur.b * HW + (size_t)cur.y0 * W + cur.x0 + px;          // tile pixel px of row 0
+      EpiStats<T> est;
+      if constexpr (KIND != 0) est.init(p, cur.b, n);
+      V o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[i][4 * jb + e] = (bf16_t)(acc[i][jb][e] + bias_r[4 * jb + e]);
+      if constexpr (KIND == 1) {      // shift of the forward statistics: the tile's first pixel (lane px = 0 of the row group)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) est.a0[e] = __shfl((float)o[0][e], lane & 48, 64);
+      }
+      const T* __restrict__ nby = reinterpret_cast<const T*>(KIND == 2 ? p.nb_y : p.w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const size_t m = m0 + (size_t)(i >> 1) * W + (i & 1) * 16;
+        V yv = V{};
+        if constexpr (KIND == 2) yv = *reinterpret_cast<const V*>(nby + m * CIN + n);
+        *reinterpret_cast<V*>(y + m * CIN + n) = o[i];
+        if constexpr (KIND != 0) est.add_pre(p, o[i], yv);
+      }
+      if constexpr (KIND != 0) {      // the 16 lanes of a row group share the slot: fixed-order butterfly, lane px = 0 writes
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+          for (int e = 0; e < EP; ++e) { est.s1[e] += __shfl_xor(est.s1[e], d, 64); est.s2[e] += __shfl_xor(est.s2[e], d, 64); }
+        if (px == 0) {
+          const int tr = (cur.y0 >> 2) * tiles_x + (cur.x0 >> 5);
+          const size_t srow = (size_t)cur.b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
+          float* out = KIND == 1 ? p.st_partial + (srow * 3) * CIN : p.nb_partial + (srow * 2) * CIN;
+#pragma unroll
+          for (int e = 0; e < EP; ++e) {
+            out[n + e] = est.s1[e];
+            out[(size_t)CIN + n + e] = est.s2[e];
+            if (KIND == 1) out[(size_t)2 * CIN + n + e] = est.a0[e];
+          }
+        }
+      }
+    }
+    __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loop
+    cur = nxt;
+    buf ^= 1;
+  }
+}
+
+bool conv_wstat_applicable(const ConvParams& p, int dtype) {
+  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0);            // (debug build: read on every call, so one process can A/B the two kernels)
+  const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
+  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
+         p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
+         !(p.st_partial && p.nb_partial) && (!p.nb_partial || PWR_DBG_ENV("PWR_WSTAT_NB", 0)) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
+}
+
+template <bool NRM>
+static void launch_kind(const WstatArgs& a, int kind, dim3 grid, hipStream_t s) {
+  if (kind == 0) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 0>), grid, dim3(256), 0, s, a);
+  else if (kind == 1) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 1>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 2>), grid, dim3(256), 0, s, a);
+}
+
+// one job (b == nullptr) or two jobs of one geometry, one norm / statistics form
+int launch_conv_wstat(const ConvParams& pa, const ConvParams* pb, hipStream_t s) {
+  const int ncu = PWR_DBG_ENV("PWR_WSTAT_WGS", 256);
+  WstatArgs a;
+  a.job[0] = pa;
+  a.job[1] = pb ? *pb : pa;
+  a.njobs = pb ? 2 : 1;
+  const int tiles = pa.B * (pa.H / 4) * (pa.W / 32);
+  int per = ncu / a.njobs;
+  if (per > tiles) per = tiles;
+  a.wgs_per_job = per;
+  const int kind = pa.st_partial ? 1 : (pa.nb_partial ? 2 : 0);
+  dim3 grid(per * a.njobs);
+  if (pa.in_norm) launch_kind<true>(a, kind, grid, s);
+  else launch_kind<false>(a, kind, grid, s);
+  return (int)hipGetLastError();
+}
+
+bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype) {
+  return conv_wstat_applicable(a, dtype) && conv_wstat_applicable(b, dtype) && a.B == b.B && a.H == b.H && a.W == b.W &&
+         (a.in_norm != nullptr) == (b.in_norm != nullptr) && (a.st_partial != nullptr) == (b.st_partial != nullptr) &&
+         (a.nb_partial != nullptr) == (b.nb_partial != nullptr) && a.relu_in == b.relu_in;
+}
+
+}  // namespace pwr
