@@ -29,7 +29,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.
 # per-source flags.  conv_wstat.hip: its K loop (36 steps x 8 slots, every register index a compile-time constant) must unroll completely;
 # the default cap on a pragma-requested unroll (16384 IR instructions, counted BEFORE the per-slot constants fold) stops it silently otherwise
 # (a warning, and a kernel whose register arrays live in scratch)
-PER_FILE_FLAGS = {"conv_wstat.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-Werror=pass-failed"]}
+# -amdgpu-mfma-vgpr-form: its accumulators live in VGPRs (the epilogue reads them with vector instructions; the AGPR file holds weights)
+PER_FILE_FLAGS = {"conv_wstat.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Werror=pass-failed"]}
 DEBUG_SRC = os.path.join(ROOT, "tools", "csrc_debug")   # experiments that only the debug build compiles (never part of the product)
 _debug_sources = False
 

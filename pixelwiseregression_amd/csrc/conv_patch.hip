@@ -836,6 +836,7 @@ static int launch_patch_t(const ConvParams& p, hipStream_t s) {
 }
 
 #ifdef PWR_DEBUG_BUILD
+long long* wstat_stamps() { return g_stamps; }
 void set_debug_stamps(long long* ptr) { g_stamps = ptr; }
 void set_debug_delay(int d) { g_delay = d; }
 #endif

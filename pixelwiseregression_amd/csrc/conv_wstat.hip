@@ -29,6 +29,19 @@ struct WstatArgs {
   int njobs, wgs_per_job;
 };
 
+#ifdef PWR_DEBUG_BUILD
+long long* wstat_stamps();        // conv_patch.hip: the buffer of pwr_debug_set_stamps
+#endif
+
+// (debug build variants, tools/build_debug.py -DWST_DBG=bits: timing by elimination, results WRONG -- 1 no staging in the K loops, 2 no epilogue
+// in the K loops, 4 no fragment reads in the K loops, 8 no MFMAs)
+#ifndef WST_DBG
+#define WST_DBG 0
+#endif
+#ifndef WST_AGPR_STEPS
+#define WST_AGPR_STEPS 32
+#endif
+
 namespace wst {
 constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN * 2 + 16;
 constexpr int NITP = 13;                 // staging vectors per thread: 204 pixels x 16 slots / 256 threads ...
@@ -36,7 +49,7 @@ constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 20
 // Staging schedule inside the K loop.  A SLOT is an MFMA pair (8 per K step, 288 per tile = 32 matrix-pipe cycles each); the vector ALU can
 // issue about two instructions per MFMA without delaying the next one, so a slot carries ONE micro-op (two vector instructions) of the
 // next patch's staging: vector k's 21 micro-ops run in slots S0(k) ... S0(k) + 20, its global load is issued LEAD slots earlier.
-constexpr int SLOTS = ITERS * 8, MICRO = 21, SLOT0 = 12, LEAD = 40;
+constexpr int SLOTS = ITERS * 8, MICRO = 21, SLOT0 = 12, LEAD = 40;      // (slots are counted over both half-tile K loops: 2 x 36 x 4)
 __host__ __device__ constexpr int slot0(int k) { return SLOT0 + MICRO * k; }
 __host__ __device__ constexpr int load_slot(int k) { return slot0(k) - LEAD > k ? slot0(k) - LEAD : k; }
 // the vector whose load is issued in slot g, or -1 (closed form: a search loop here keeps the K loop from unrolling)
@@ -60,6 +73,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = 32-channel group
   const int px = lane & 15, rg = lane >> 4;                     // MFMA column (pixel of a 16-pixel block) / K group (B) = row group (D)
+  // LDS image of the patch: pixel pitch 272 B, and inside a pixel the 16-byte channel slot c = 4 * kch + rg sits at position
+  // tau(c) = rg / 2 + 2 (kch % 2) + 4 (rg % 2) + 8 (kch / 2); MFMA column px handles pixel column pcol = (px / 4) + 4 (px % 4) of its block.
+  // With the plain image (position c, column px) every 16-lane group of a fragment's ds_read_b128 hit one bank slot twice -- 8 LDS cycles
+  // per read instead of 4, which made the K loop LDS-bound with one wave per SIMD (288 reads x 4 waves x 8 = the 9216 matrix cycles of a
+  // tile); a search over bit permutations of (column, slot) found this one: reads AND the staging's ds_write_b128 conflict-free.
+  const int pcol = (px >> 2) | ((px & 3) << 2);
+  auto tau = [](int c) { const int kch = c >> 2, g = c & 3; return (g >> 1) + 2 * (kch & 1) + 4 * (g & 1) + 8 * (kch >> 1); };
   const int job = blockIdx.x % a.njobs, wgj = blockIdx.x / a.njobs;
   const ConvParams& p = a.job[job];
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
@@ -75,6 +95,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     t_end = (int)((long long)(c + 1) * ntiles / NW);
   }
   if (t >= t_end) return;
+  // (debug build: s_memtime stamps of thread 0, 32 x int64 per workgroup: 0 start, 1 first patch staged, then per tile: half A done, half B
+  // done, barrier passed; 31: end)
+  auto stamp = [&](int slot) __attribute__((always_inline)) {
+#ifdef PWR_DEBUG_BUILD
+    if (p.stamps && tid == 0 && slot < 29) p.stamps[(size_t)blockIdx.x * 32 + slot] = (long long)__builtin_amdgcn_s_memtime();
+    if (p.stamps && tid == 0 && (slot == 0 || slot == 31)) {     // start / end also by the constant 100 MHz clock: the shader clock the chip held
+      p.stamps[(size_t)blockIdx.x * 32 + (slot ? 30 : 29)] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (slot) p.stamps[(size_t)blockIdx.x * 32 + 31] = (long long)__builtin_amdgcn_s_memtime();
+    }
+#endif
+  };
+  stamp(0);
 
   // ---- the weights of this wave: A fragments of all 36 K steps x 2 row blocks (lane = row % 16 + 16 * (K / 8))
   V wreg[ITERS][2];
@@ -91,9 +123,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     // Register files: the vector ALU only reaches the 256 architectural VGPRs, the MFMA reads its operands from either file.  Left alone the
     // allocator puts most weights into VGPRs, runs out of them where the staging arithmetic lives and shuffles weights through AGPR spill
     // slots (4 v_accvgpr_mov per MFMA operand, in the middle of the K loop).  So: the weights of taps 0 .. 7 are DEFINED in AGPRs (all 256
-    // of them) and stay there; tap 8, the accumulators and everything the vector ALU touches share the VGPRs.
+    // of them) and stay there; tap 8, the ACCUMULATORS (the file is built with -amdgpu-mfma-vgpr-form: the epilogue's vector instructions
+    // read them directly, no v_accvgpr_read per value) and everything else the vector ALU touches share the VGPRs.
 #pragma unroll
-    for (int it = 0; it < 32; ++it)
+    for (int it = 0; it < WST_AGPR_STEPS; ++it)
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+a"(wreg[it][jb]));
   }
@@ -106,8 +139,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   const int H = p.H, W = p.W;
   const int st_pl = tid >> 4, st_slot = tid & 15;
   const int r12 = st_pl >> 1, c12 = 32 + (st_pl & 1);                      // vector 12's patch pixel
-  const int lds_st = (st_pl * PITCH) + st_slot * 16;                       // + (row * PW + 16 (k % 2)) * PITCH
-  const int lds_st12 = (st_pl < 12 ? (r12 * PW + c12) : (PP + st_pl - 12)) * PITCH + st_slot * 16;
+  const int lds_st = (st_pl * PITCH) + tau(st_slot) * 16;                  // + (row * PW + 16 (k % 2)) * PITCH
+  const int lds_st12 = (st_pl < 12 ? (r12 * PW + c12) : (PP + st_pl - 12)) * PITCH + tau(st_slot) * 16;
   V sv[NITP];
   float mu[EP], sc[EP], be[EP];
   struct TileCo { int b, y0, x0; };
@@ -165,23 +198,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     if (k < 12) return (((k & 1) ? ~0u : q.keep0)) & (0u - ((q.rowok >> (k >> 1)) & 1u));
     return q.keep12;
   };
-  // micro-op u = 0 .. 20 of vector k: per channel pair j = u / 5: {unpack lo, unpack hi} {- mean, - mean} {fma, ReLU} {fma, ReLU} {round + pack,
-  // mask}; u = 20: the 16-byte LDS store.  (No norm: the pair's micro-op 4 masks the raw dword, the others are empty.)
+  // micro-op u = 0 .. 20 of vector k.  The two vector instructions of a micro-op never depend on each other (a dependent pair waits out the
+  // first one's latency in the slot it was supposed to hide in): per channel pair j = u / 5: {unpack lo, unpack hi} {- mean, - mean} {fma, fma}
+  // {ReLU, ReLU} {round + pack of pair j, mask of pair j - 1}; u = 20: mask of pair 3, then the 16-byte LDS store.  (No norm: the mask ops only.)
   auto stage_micro = [&](const int k, const int u, const StageCo& q, char* patch) __attribute__((always_inline)) {
     if (u == MICRO - 1) {
+      so[3] = so[3] & keep_of(k, q);
       const int off = k < 12 ? lds_st + ((k >> 1) * PW + 16 * (k & 1)) * PITCH : lds_st12;
       *reinterpret_cast<u32x4*>(patch + off) = so;
       return;
     }
     const int j = u / 5, o = u - 5 * j;
     if constexpr (!NRM) {
-      if (o == 4) so[j] = __builtin_bit_cast(u32x4, sv[k])[j] & keep_of(k, q);
+      if (o == 4) { so[j] = __builtin_bit_cast(u32x4, sv[k])[j]; if (j > 0) so[j - 1] = so[j - 1] & keep_of(k, q); }
     } else {
       if (o == 0) { t0 = (float)sv[k][2 * j]; t1 = (float)sv[k][2 * j + 1]; }
       else if (o == 1) { t0 = t0 - mu[2 * j]; t1 = t1 - mu[2 * j + 1]; }
-      else if (o == 2) t0 = fmaxf(fmaf(t0, sc[2 * j], be[2 * j]), 0.f);
-      else if (o == 3) t1 = fmaxf(fmaf(t1, sc[2 * j + 1], be[2 * j + 1]), 0.f);
-      else { bf16x2 pk; pk[0] = (bf16_t)t0; pk[1] = (bf16_t)t1; so[j] = __builtin_bit_cast(unsigned, pk) & keep_of(k, q); }
+      else if (o == 2) { t0 = fmaf(t0, sc[2 * j], be[2 * j]); t1 = fmaf(t1, sc[2 * j + 1], be[2 * j + 1]); }
+      else if (o == 3) {      // (as asm: behind the pin of the previous micro-op hipcc no longer knows the fma result is canonical and would put a
+        // canonicalising v_max_f32 x, x, x in front of each fmaxf; v_max_f32 quiets a signalling NaN by itself)
+        asm("v_max_f32 %0, 0, %0" : "+v"(t0));
+        asm("v_max_f32 %0, 0, %0" : "+v"(t1));
+      }
+      else {
+        bf16x2 pk; pk[0] = (bf16_t)t0; pk[1] = (bf16_t)t1;
+        so[j] = __builtin_bit_cast(unsigned, pk);
+        if (j > 0) so[j - 1] = so[j - 1] & keep_of(k, q);
+      }
     }
   };
   // tile coordinates walk incrementally (no division in the loop)
@@ -199,27 +242,69 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     cur.y0 = tyi * 4; cur.x0 = (tr - tyi * tiles_x) * 32;
     const StageCo q = stage_co(cur);
     stage_norm_load(cur);
+    // (four vectors at a time: all thirteen in flight next to the 288 weight registers would spill)
 #pragma unroll
-    for (int k = 0; k < NITP; ++k) stage_load(k, q);
+    for (int k0 = 0; k0 < NITP; k0 += 4) {
 #pragma unroll
-    for (int k = 0; k < NITP; ++k)
+      for (int k = k0; k < k0 + 4 && k < NITP; ++k) stage_load(k, q);
 #pragma unroll
-      for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q, smem);
+      for (int k = k0; k < k0 + 4 && k < NITP; ++k)
+#pragma unroll
+        for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q, smem);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   __syncthreads();
+  stamp(1);
+  int tile_no = 0;
 
   f32x4 acc[8][2];
-  const char* fbase = smem + px * PITCH + rg * 16;               // per-lane part of every B-fragment address (+ buffer, tap, K chunk: constants)
-  // ONE set of fragments: fragment i of step it + 1 is read into the registers of fragment i of step it right behind the two MFMAs that
-  // consume it (16 MFMAs = 256 matrix-pipe cycles ahead of its own use) -- a second set would cost 32 of the 512 registers
+  const char* fbase = smem + pcol * PITCH + tau(rg) * 16;        // per-lane part of every B-fragment address (+ buffer, tap, K chunk: constants)
+  // A tile is computed as two HALVES of 64 pixels (blocks 0 - 3, then 4 - 7), each a K loop of 36 steps x 4 MFMA pairs: while a half
+  // accumulates, the EPILOGUE of the half finished before it (the other 32 accumulator registers) rides in the MFMAs' issue shadow next to the
+  // staging -- during half A of tile n the blocks 4 - 7 of tile n - 1, during half B the blocks 0 - 3 of tile n.  Nothing of the epilogue
+  // is exposed but the last half of a workgroup's last tile.
+  // Fragments: two sets of four (K steps of even / odd parity); fragment ii of logical step s + 2 is read into the registers of fragment ii of
+  // step s right behind the two MFMAs that consume it (16 MFMAs = 256 matrix-pipe cycles ahead of its own use).
   V pf[8];
-  auto frag_load1 = [&](const int it, const int i, const char* base) __attribute__((always_inline)) {
+  auto frag_load1 = [&](const int s, const int ii, const char* base) __attribute__((always_inline)) {      // s = 36 * half + K step
+    const int half = s / ITERS, it = s - half * ITERS, i = half * 4 + ii;
     const int tap = it / KCH, kch = it - tap * KCH;
     const int ky = tap / 3, kx = tap - ky * 3;
-    pf[i] = *reinterpret_cast<const V*>(base + (((i >> 1) + ky) * PW + (i & 1) * 16 + kx) * PITCH + kch * 64);
+    pf[(s & 1) * 4 + ii] = *reinterpret_cast<const V*>(base + (((i >> 1) + ky) * PW + (i & 1) * 16 + kx) * PITCH + (2 * (kch & 1) + 8 * (kch >> 1)) * 16);
+  };
+
+  // ---- epilogue: lane (px, rg) holds channels n .. n + 7 of tile pixel 16 i + px, i = 0 .. 7: bias, one rounding, ONE 16-byte NHWC store
+  // per block, as micro-ops of two vector instructions (E_BLOCK per block).  The store address is a scalar base (tile, block) plus a per-lane
+  // constant offset: no vector arithmetic.
+  const int n = 32 * wn + 8 * rg;
+  float bias_r[EP];
+  {
+    const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
+  }
+  const unsigned yoff = (unsigned)(pcol * CIN + n) * 2u;
+  constexpr int E_BLOCK = 7, E_HALF = 4 * E_BLOCK;
+  float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+  u32x4 eo;
+  auto pk2 = [](float lo, float hi) __attribute__((always_inline)) { bf16x2 v; v[0] = (bf16_t)lo; v[1] = (bf16_t)hi; return __builtin_bit_cast(unsigned, v); };
+  // (again no dependent pair inside a micro-op)
+  auto epi_micro = [&](const int i, const int u, const TileCo& c) __attribute__((always_inline)) {
+    if (u == 0) { f0 = acc[i][0][0] + bias_r[0]; f1 = acc[i][0][1] + bias_r[1]; }
+    else if (u == 1) { f2 = acc[i][0][2] + bias_r[2]; f3 = acc[i][0][3] + bias_r[3]; }
+    else if (u == 2) { eo[0] = pk2(f0, f1); eo[1] = pk2(f2, f3); }
+    else if (u == 3) { f0 = acc[i][1][0] + bias_r[4]; f1 = acc[i][1][1] + bias_r[5]; }
+    else if (u == 4) { f2 = acc[i][1][2] + bias_r[6]; f3 = acc[i][1][3] + bias_r[7]; }
+    else if (u == 5) { eo[2] = pk2(f0, f1); eo[3] = pk2(f2, f3); }
+    else {
+      char* yb = reinterpret_cast<char*>(p.y) + ((size_t)c.b * HW + (size_t)(c.y0 + (i >> 1)) * W + c.x0 + (i & 1) * 16) * (CIN * 2);
+      *reinterpret_cast<u32x4*>(yb + yoff) = eo;
+    }
   };
 
   int buf = 0;
+  TileCo prev = cur;            // (first tile: the "previous tile's" half epilogue stores garbage where this tile's own epilogue writes later)
   for (; t < t_end; ++t) {
     const bool more = t + 1 < t_end;
     const TileCo nxt = more ? tile_next(cur) : cur;              // (the last tile re-stages itself into the other buffer: branch-free K loop)
@@ -227,91 +312,56 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const char* pb = fbase + buf * PATCH_BYTES;
     char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) acc[i][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) frag_load1(0, i, pb);
+    for (int ii = 0; ii < 4; ++ii) { frag_load1(0, ii, pb); frag_load1(1, ii, pb); }
     stage_norm_load(nxt);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        // a slot: the two MFMAs of pixel block i, the read that refills their fragment for the next step, this slot's share of the staging
-        // work (wst::slot0 / load_slot), a full scheduling barrier: the emitted order IS this order
-        const int g = it * 8 + i;
+      for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-          acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[it][jb], pf[i], acc[i][jb], 0, 0, 0);
-        if (it + 1 < ITERS) frag_load1(it + 1, i, pb);
-        if (load_of(g) >= 0) stage_load(load_of(g), q);
-        if (g >= SLOT0 && g < slot0(NITP)) {
-          const int k = (g - SLOT0) / MICRO, u = (g - SLOT0) - k * MICRO;
-          stage_micro(k, u, q, nb);
-          // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
-          // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
-          if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    // ---- epilogue straight from the accumulators: lane (px, rg) holds channels n .. n + 7 of tile pixel 16 i + px, i = 0 .. 7
-    {
-      const int n = 32 * wn + 8 * rg;
-      float bias_r[EP];
-      {
-        const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
+        for (int ii = 0; ii < 4; ++ii) {
+          // a slot: the two MFMAs of pixel block i, the read that refills their fragment two steps ahead, this slot's share of the staging
+          // (wst::slot0 / load_of) and of the other half's epilogue, a full scheduling barrier: the emitted order IS this order
+          const int s = half * ITERS + it, g = s * 4 + ii, i = half * 4 + ii;
 #pragma unroll
-        for (int e = 0; e < EP; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
-      }
-      T* __restrict__ y = reinterpret_cast<T*>(p.y);
-      const size_t m0 = (size_t)cur.b * HW + (size_t)cur.y0 * W + cur.x0 + px;          // tile pixel px of row 0
-      EpiStats<T> est;
-      if constexpr (KIND != 0) est.init(p, cur.b, n);
-      V o[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[i][4 * jb + e] = (bf16_t)(acc[i][jb][e] + bias_r[4 * jb + e]);
-      if constexpr (KIND == 1) {      // shift of the forward statistics: the tile's first pixel (lane px = 0 of the row group)
-#pragma unroll
-        for (int e = 0; e < EP; ++e) est.a0[e] = __shfl((float)o[0][e], lane & 48, 64);
-      }
-      const T* __restrict__ nby = reinterpret_cast<const T*>(KIND == 2 ? p.nb_y : p.w);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const size_t m = m0 + (size_t)(i >> 1) * W + (i & 1) * 16;
-        V yv = V{};
-        if constexpr (KIND == 2) yv = *reinterpret_cast<const V*>(nby + m * CIN + n);
-        *reinterpret_cast<V*>(y + m * CIN + n) = o[i];
-        if constexpr (KIND != 0) est.add_pre(p, o[i], yv);
-      }
-      if constexpr (KIND != 0) {      // the 16 lanes of a row group share the slot: fixed-order butterfly, lane px = 0 writes
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1)
-#pragma unroll
-          for (int e = 0; e < EP; ++e) { est.s1[e] += __shfl_xor(est.s1[e], d, 64); est.s2[e] += __shfl_xor(est.s2[e], d, 64); }
-        if (px == 0) {
-          const int tr = (cur.y0 >> 2) * tiles_x + (cur.x0 >> 5);
-          const size_t srow = (size_t)cur.b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
-          float* out = KIND == 1 ? p.st_partial + (srow * 3) * CIN : p.nb_partial + (srow * 2) * CIN;
-#pragma unroll
-          for (int e = 0; e < EP; ++e) {
-            out[n + e] = est.s1[e];
-            out[(size_t)CIN + n + e] = est.s2[e];
-            if (KIND == 1) out[(size_t)2 * CIN + n + e] = est.a0[e];
+          for (int jb = 0; jb < 2; ++jb) {
+            if (WST_DBG & 8) { asm volatile("" : "+v"(pf[(s & 1) * 4 + ii])); continue; }
+            if (it == 0) acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[it][jb], pf[(s & 1) * 4 + ii], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[it][jb], pf[(s & 1) * 4 + ii], acc[i][jb], 0, 0, 0);
           }
+          if (s + 2 < 2 * ITERS && !(WST_DBG & 4)) frag_load1(s + 2, ii, pb);
+          if (load_of(g) >= 0 && !(WST_DBG & 1)) stage_load(load_of(g), q);
+          if (g >= SLOT0 && g < slot0(NITP) && !(WST_DBG & 1)) {
+            const int k = (g - SLOT0) / MICRO, u = (g - SLOT0) - k * MICRO;
+            stage_micro(k, u, q, nb);
+            // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
+            // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
+            if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
+          }
+          {
+            const int gl = it * 4 + ii;
+#pragma unroll
+            for (int eu = gl * E_HALF / (ITERS * 4); eu < (gl + 1) * E_HALF / (ITERS * 4) && !(WST_DBG & 2); ++eu) {
+              epi_micro((half ? 0 : 4) + eu / E_BLOCK, eu % E_BLOCK, half ? cur : prev);
+              asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(eo));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      stamp(2 + 3 * tile_no + half);
     }
-    __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loop
+    __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loops
+    stamp(4 + 3 * tile_no); ++tile_no;
+    prev = cur;
     cur = nxt;
     buf ^= 1;
   }
+  // the last tile's second half
+#pragma unroll
+  for (int eu = 0; eu < E_HALF; ++eu) epi_micro(4 + eu / E_BLOCK, eu % E_BLOCK, prev);
+  stamp(31);
 }
 
 bool conv_wstat_applicable(const ConvParams& p, int dtype) {
@@ -319,7 +369,7 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
          p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
-         !(p.st_partial && p.nb_partial) && (!p.nb_partial || PWR_DBG_ENV("PWR_WSTAT_NB", 0)) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
+         !(p.st_partial && p.nb_partial) && !p.nb_partial && !p.st_partial && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
 }
 
 template <bool NRM>
@@ -335,6 +385,9 @@ int launch_conv_wstat(const ConvParams& pa, const ConvParams* pb, hipStream_t s)
   WstatArgs a;
   a.job[0] = pa;
   a.job[1] = pb ? *pb : pa;
+#ifdef PWR_DEBUG_BUILD
+  a.job[0].stamps = a.job[1].stamps = wstat_stamps();
+#endif
   a.njobs = pb ? 2 : 1;
   const int tiles = pa.B * (pa.H / 4) * (pa.W / 32);
   int per = ncu / a.njobs;
