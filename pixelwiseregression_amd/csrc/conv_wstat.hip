@@ -46,10 +46,10 @@ namespace wst {
 constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN * 2 + 16;
 constexpr int NITP = 13;                 // staging vectors per thread: 204 pixels x 16 slots / 256 threads ...
 constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 208 pixels: the last round's 4 surplus pixels are written (never read), no branch
-// Staging schedule inside the K loop.  A SLOT is an MFMA pair (8 per K step, 288 per tile = 32 matrix-pipe cycles each); the vector ALU can
-// issue about two instructions per MFMA without delaying the next one, so a slot carries ONE micro-op (two vector instructions) of the
-// next patch's staging: vector k's 21 micro-ops run in slots S0(k) ... S0(k) + 20, its global load is issued LEAD slots earlier.
-constexpr int SLOTS = ITERS * 8, MICRO = 21, SLOT0 = 12, LEAD = 40;      // (slots are counted over both half-tile K loops: 2 x 36 x 4)
+// Staging schedule inside the K loops.  A SLOT is one v_mfma_f32_32x32x16_bf16 (288 per tile, 32 matrix-pipe cycles each, 24 of them open to
+// the vector ALU); a slot carries ONE micro-op (two independent vector instructions) of the next patch's staging: vector k's 21 micro-ops run
+// in slots S0(k) ... S0(k) + 20, its global load is issued LEAD slots earlier.
+constexpr int SLOTS = ITERS * 8, MICRO = 21, SLOT0 = 12, LEAD = 40;      // (slots are counted over both half-tile K loops: 2 x 36 x 4 MFMAs)
 __host__ __device__ constexpr int slot0(int k) { return SLOT0 + MICRO * k; }
 __host__ __device__ constexpr int load_slot(int k) { return slot0(k) - LEAD > k ? slot0(k) - LEAD : k; }
 // the vector whose load is issued in slot g, or -1 (closed form: a search loop here keeps the K loop from unrolling)
@@ -72,14 +72,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = 32-channel group
-  const int px = lane & 15, rg = lane >> 4;                     // MFMA column (pixel of a 16-pixel block) / K group (B) = row group (D)
-  // LDS image of the patch: pixel pitch 272 B, and inside a pixel the 16-byte channel slot c = 4 * kch + rg sits at position
-  // tau(c) = rg / 2 + 2 (kch % 2) + 4 (rg % 2) + 8 (kch / 2); MFMA column px handles pixel column pcol = (px / 4) + 4 (px % 4) of its block.
-  // With the plain image (position c, column px) every 16-lane group of a fragment's ds_read_b128 hit one bank slot twice -- 8 LDS cycles
-  // per read instead of 4, which made the K loop LDS-bound with one wave per SIMD (288 reads x 4 waves x 8 = the 9216 matrix cycles of a
-  // tile); a search over bit permutations of (column, slot) found this one: reads AND the staging's ds_write_b128 conflict-free.
-  const int pcol = (px >> 2) | ((px & 3) << 2);
-  auto tau = [](int c) { const int kch = c >> 2, g = c & 3; return (g >> 1) + 2 * (kch & 1) + 4 * (g & 1) + 8 * (kch >> 1); };
+  // v_mfma_f32_32x32x16_bf16, A = weights (32 rows = this wave's channels), B = pixels (32 columns = one tile row): lane = column + 32 h,
+  // h = the 8-channel half of the 16-channel K step.  (The 16x16x32 form leaves the vector ALU 8 issue cycles per 16-cycle MFMA, this one
+  // 24 per 32: with ONE wave per SIMD the staging and epilogue arithmetic has to fit into exactly that shadow -- measured by elimination,
+  // the 16x16x32 build ran its K loops at 1.36x the matrix-pipe time.)  The plain LDS image (pixel pitch 272 B, channel slot c at 16 c)
+  // is conflict-free for these reads: the 32 lanes of a half read ONE slot of 32 consecutive pixels.
+  const int pc = lane & 31, hh = lane >> 5;
+  auto tau = [](int c) { return c; };
   const int job = blockIdx.x % a.njobs, wgj = blockIdx.x / a.njobs;
   const ConvParams& p = a.job[job];
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
@@ -107,29 +106,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
 #endif
   };
   stamp(0);
-
-  // ---- the weights of this wave: A fragments of all 36 K steps x 2 row blocks (lane = row % 16 + 16 * (K / 8))
-  V wreg[ITERS][2];
-  {
-    const int row = lane & 15, kg = lane >> 4;
-    const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        const int ch = 32 * wn + 8 * (row >> 2) + 4 * jb + (row & 3);
-        wreg[it][jb] = *reinterpret_cast<const V*>(w + ((size_t)it * p.CoutPad + ch) * 32 + kg * 8);
-      }
-    // Register files: the vector ALU only reaches the 256 architectural VGPRs, the MFMA reads its operands from either file.  Left alone the
-    // allocator puts most weights into VGPRs, runs out of them where the staging arithmetic lives and shuffles weights through AGPR spill
-    // slots (4 v_accvgpr_mov per MFMA operand, in the middle of the K loop).  So: the weights of taps 0 .. 7 are DEFINED in AGPRs (all 256
-    // of them) and stay there; tap 8, the ACCUMULATORS (the file is built with -amdgpu-mfma-vgpr-form: the epilogue's vector instructions
-    // read them directly, no v_accvgpr_read per value) and everything else the vector ALU touches share the VGPRs.
-#pragma unroll
-    for (int it = 0; it < WST_AGPR_STEPS; ++it)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) asm volatile("" : "+a"(wreg[it][jb]));
-  }
 
   // ---- staging of a patch.  Thread -> 16-byte channel slot st_slot of 13 patch pixels: vectors k = 0 .. 11 are patch row k / 2, columns
   // 16 (k % 2) + st_pl (the 32 left columns of the 6 rows); vector 12 is the two right columns: row st_pl / 2, column 32 + st_pl % 2
@@ -234,74 +210,161 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     return c;
   };
 
-  // ---- first patch: nothing to overlap with yet (the weight loads above are still landing)
+  // ---- prologue: the first patch's loads go out FIRST, the 72 weight loads behind them; the patch is normalised and written while the
+  // weights are still landing (vmcnt counts in order: its wait does not cover them), and only then does anything wait for the weights.
   TileCo cur;
+  cur.b = t / tiles_img;
   {
-    cur.b = t / tiles_img;
     const int tr = t - cur.b * tiles_img, tyi = tr / tiles_x;
     cur.y0 = tyi * 4; cur.x0 = (tr - tyi * tiles_x) * 32;
-    const StageCo q = stage_co(cur);
-    stage_norm_load(cur);
-    // (four vectors at a time: all thirteen in flight next to the 288 weight registers would spill)
-#pragma unroll
-    for (int k0 = 0; k0 < NITP; k0 += 4) {
-#pragma unroll
-      for (int k = k0; k < k0 + 4 && k < NITP; ++k) stage_load(k, q);
-#pragma unroll
-      for (int k = k0; k < k0 + 4 && k < NITP; ++k)
-#pragma unroll
-        for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q, smem);
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
+  const StageCo q0 = stage_co(cur);
+  stage_norm_load(cur);
+#pragma unroll
+  for (int k = 0; k < NITP; ++k) stage_load(k, q0);
+  __builtin_amdgcn_sched_barrier(0);
+  stamp(25);
+  // ---- the weights of this wave: A fragments of all 72 K steps of 16 channels (lane = row + 32 h: weight row `row`, channels 8 h .. 8 h + 7
+  // of the step).  MFMA row -> output channel: the accumulator of lane (col, h) holds rows (r % 4) + 8 (r / 4) + 4 h, r = 0 .. 15; with
+  // channel = 16 (row / 4 % 2) + 4 (row / 8) + row % 4 those are the 16 CONSECUTIVE channels 16 h .. 16 h + 15 of the wave's 32: two
+  // 16-byte NHWC stores per pixel straight from registers.
+  V wreg[2 * ITERS];
+  {
+    const int row = lane & 31;
+    const int ch = 32 * wn + 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3);
+    const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+    for (int q = 0; q < 2 * ITERS; ++q)
+      wreg[q] = *reinterpret_cast<const V*>(w + ((size_t)(q >> 1) * p.CoutPad + ch) * 32 + (2 * (q & 1) + hh) * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NITP; ++k)
+#pragma unroll
+    for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q0, smem);
+  stamp(26);
   __syncthreads();
+  stamp(27);
+  {
+    // Register files: the vector ALU only reaches the 256 architectural VGPRs, the MFMA reads its operands from either file.  Left alone the
+    // allocator puts most weights into VGPRs, runs out of them where the staging arithmetic lives and shuffles weights through AGPR spill
+    // slots (4 v_accvgpr_mov per MFMA operand, in the middle of the K loop).  So: the weights of taps 0 .. 7 are DEFINED in AGPRs (all 256
+    // of them) and stay there; tap 8, the ACCUMULATORS (the file is built with -amdgpu-mfma-vgpr-form: the epilogue's vector instructions
+    // read them directly, no v_accvgpr_read per value) and everything else the vector ALU touches share the VGPRs.
+#pragma unroll
+    for (int q = 0; q < 2 * WST_AGPR_STEPS; ++q) asm volatile("" : "+a"(wreg[q]));
+  }
   stamp(1);
   int tile_no = 0;
 
-  f32x4 acc[8][2];
-  const char* fbase = smem + pcol * PITCH + tau(rg) * 16;        // per-lane part of every B-fragment address (+ buffer, tap, K chunk: constants)
-  // A tile is computed as two HALVES of 64 pixels (blocks 0 - 3, then 4 - 7), each a K loop of 36 steps x 4 MFMA pairs: while a half
-  // accumulates, the EPILOGUE of the half finished before it (the other 32 accumulator registers) rides in the MFMAs' issue shadow next to the
-  // staging -- during half A of tile n the blocks 4 - 7 of tile n - 1, during half B the blocks 0 - 3 of tile n.  Nothing of the epilogue
-  // is exposed but the last half of a workgroup's last tile.
-  // Fragments: two sets of four (K steps of even / odd parity); fragment ii of logical step s + 2 is read into the registers of fragment ii of
-  // step s right behind the two MFMAs that consume it (16 MFMAs = 256 matrix-pipe cycles ahead of its own use).
+  f32x16 acc[4];                                                 // one per tile row (32 pixels x this wave's 32 channels)
+  const char* fbase = smem + pc * PITCH + hh * 16;               // per-lane part of every B-fragment address (+ buffer, tap, K step: constants)
+  // A tile is computed as two HALVES (tile rows 0 - 1, then 2 - 3), each a K loop of 36 steps x 4 MFMAs: while a half accumulates, the
+  // EPILOGUE of the half finished before it (the other 32 accumulator registers) rides in the MFMAs' issue shadow next to the staging --
+  // during half A of tile n the rows 2 - 3 of tile n - 1, during half B the rows 0 - 1 of tile n.  Nothing of the epilogue is exposed but the
+  // last half of a workgroup's last tile.
+  // A SLOT is one MFMA (32 matrix-pipe cycles): slot sl = 4 * step + 2 * ss + blk of a half multiplies the 16-channel half ss of K step `step`
+  // into tile row 2 * half + blk.  Fragments: a ring of eight; the fragment of slot g + 8 is read into the registers of slot g's right
+  // behind the MFMA that consumed them (256 matrix-pipe cycles ahead of its own use).
   V pf[8];
-  auto frag_load1 = [&](const int s, const int ii, const char* base) __attribute__((always_inline)) {      // s = 36 * half + K step
-    const int half = s / ITERS, it = s - half * ITERS, i = half * 4 + ii;
+  auto frag_load1 = [&](const int g, const char* base) __attribute__((always_inline)) {      // g = 144 * half + slot
+    const int half = g / (ITERS * 4), sl = g - half * ITERS * 4, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
     const int tap = it / KCH, kch = it - tap * KCH;
     const int ky = tap / 3, kx = tap - ky * 3;
-    pf[(s & 1) * 4 + ii] = *reinterpret_cast<const V*>(base + (((i >> 1) + ky) * PW + (i & 1) * 16 + kx) * PITCH + (2 * (kch & 1) + 8 * (kch >> 1)) * 16);
+    pf[g & 7] = *reinterpret_cast<const V*>(base + ((row + ky) * PW + kx) * PITCH + (4 * kch + 2 * ss) * 16);
   };
 
-  // ---- epilogue: lane (px, rg) holds channels n .. n + 7 of tile pixel 16 i + px, i = 0 .. 7: bias, one rounding, ONE 16-byte NHWC store
-  // per block, as micro-ops of two vector instructions (E_BLOCK per block).  The store address is a scalar base (tile, block) plus a per-lane
-  // constant offset: no vector arithmetic.
-  const int n = 32 * wn + 8 * rg;
-  float bias_r[EP];
+  // ---- epilogue: lane (col, h) holds channels n .. n + 15 of the pixels (row, col) of the tile: bias, one rounding, two 16-byte NHWC stores
+  // per row, as micro-ops of two independent vector instructions (E_ROW per tile row).  A store's address is a scalar base (tile, row) plus a
+  // per-lane constant offset.
+  const int n = 32 * wn + 16 * hh;
+  float bias_r[16];
   {
     const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
 #pragma unroll
-    for (int e = 0; e < EP; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
+    for (int e = 0; e < 16; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
   }
-  const unsigned yoff = (unsigned)(pcol * CIN + n) * 2u;
-  constexpr int E_BLOCK = 7, E_HALF = 4 * E_BLOCK;
+  const unsigned yoff = (unsigned)(pc * CIN + n) * 2u;
+  // KIND 1 (forward statistics of the norm that follows, conv_common.h EpiStats): per 8-channel slot and pixel column li = col % 16 the old
+  // kernel's thread adds the pixels (it, li), it = 0 .. 7 (= tile row it / 2, column 16 (it % 2) + li), IN THAT ORDER, then a butterfly over
+  // li.  Here lane (col, h) holds 16 channels of the pixels (row, col): the lanes col and col ^ 16 (rows 16 lanes apart in the wave) exchange
+  // half of what they hold -- ONE v_permlane16_swap per packed dword: the lane with col < 16 keeps its channels 0 - 7 and receives its
+  // partner's, the other one keeps 8 - 15 -- and every lane then owns ONE slot (channels n + 8 (col / 16) ...) of the pixels it = 2 row,
+  // 2 row + 1 of column li: exactly the old thread's set, consumed in the old order; the final butterfly runs over the 16 lanes of a row.
+  // Same sums, bit for bit (tests/test_00_kat_gpu.py holds both kernels to one digest).
+  constexpr int E_ST = KIND == 1 ? 34 : 0;                       // 2 swaps + 2 x 16 accumulate micro-ops per tile row
+  constexpr int E_A0 = KIND == 1 ? 6 : 0;                        // tile row 0: the shift (the tile's first pixel) to every lane of the slot
+  constexpr int E_ROW = 14 + E_ST, E_HALF = 2 * E_ROW + E_A0;    // (half B, rows 0 - 1, carries the E_A0 ops; half A's slots for them stay empty)
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
-  u32x4 eo;
+  u32x4 eo, oL, oH;
+  float s1[8], s2[8], a0[8];
   auto pk2 = [](float lo, float hi) __attribute__((always_inline)) { bf16x2 v; v[0] = (bf16_t)lo; v[1] = (bf16_t)hi; return __builtin_bit_cast(unsigned, v); };
-  // (again no dependent pair inside a micro-op)
-  auto epi_micro = [&](const int i, const int u, const TileCo& c) __attribute__((always_inline)) {
-    if (u == 0) { f0 = acc[i][0][0] + bias_r[0]; f1 = acc[i][0][1] + bias_r[1]; }
-    else if (u == 1) { f2 = acc[i][0][2] + bias_r[2]; f3 = acc[i][0][3] + bias_r[3]; }
-    else if (u == 2) { eo[0] = pk2(f0, f1); eo[1] = pk2(f2, f3); }
-    else if (u == 3) { f0 = acc[i][1][0] + bias_r[4]; f1 = acc[i][1][1] + bias_r[5]; }
-    else if (u == 4) { f2 = acc[i][1][2] + bias_r[6]; f3 = acc[i][1][3] + bias_r[7]; }
-    else if (u == 5) { eo[2] = pk2(f0, f1); eo[3] = pk2(f2, f3); }
-    else {
-      char* yb = reinterpret_cast<char*>(p.y) + ((size_t)c.b * HW + (size_t)(c.y0 + (i >> 1)) * W + c.x0 + (i & 1) * 16) * (CIN * 2);
-      *reinterpret_cast<u32x4*>(yb + yoff) = eo;
+  auto lo_f = [](unsigned u) __attribute__((always_inline)) { return __builtin_bit_cast(float, u << 16); };
+  auto hi_f = [](unsigned u) __attribute__((always_inline)) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+  // accumulator register r of a lane = channel n + r (the row -> channel assignment above).  No dependent pair inside a micro-op.
+  auto epi_micro = [&](const int row, const int u, const TileCo& c) __attribute__((always_inline)) {
+    if (u < 14) {
+      const int e8 = u / 7, v = u - 7 * e8, c0 = 8 * e8;          // the 8 channels c0 .. c0 + 7: seven micro-ops
+      if (v == 0) { f0 = acc[row][c0 + 0] + bias_r[c0 + 0]; f1 = acc[row][c0 + 1] + bias_r[c0 + 1]; }
+      else if (v == 1) { f2 = acc[row][c0 + 2] + bias_r[c0 + 2]; f3 = acc[row][c0 + 3] + bias_r[c0 + 3]; }
+      else if (v == 2) { eo[0] = pk2(f0, f1); eo[1] = pk2(f2, f3); }
+      else if (v == 3) { f0 = acc[row][c0 + 4] + bias_r[c0 + 4]; f1 = acc[row][c0 + 5] + bias_r[c0 + 5]; }
+      else if (v == 4) { f2 = acc[row][c0 + 6] + bias_r[c0 + 6]; f3 = acc[row][c0 + 7] + bias_r[c0 + 7]; }
+      else if (v == 5) { eo[2] = pk2(f0, f1); eo[3] = pk2(f2, f3); }
+      else {
+        char* yb = reinterpret_cast<char*>(p.y) + ((size_t)c.b * HW + (size_t)(c.y0 + row) * W + c.x0) * (CIN * 2) + e8 * 16;
+        *reinterpret_cast<u32x4*>(yb + yoff) = eo;
+        if (KIND == 1) { if (e8 == 0) oL = eo; else oH = eo; }
+      }
+      return;
+    }
+    if constexpr (KIND == 1) {
+      const int w = u - 14;
+      if (w < 2) {                       // the exchange: dwords 2 w, 2 w + 1
+#pragma unroll
+        for (int j = 2 * w; j < 2 * w + 2; ++j) {
+          const auto r = __builtin_amdgcn_permlane16_swap(oL[j], oH[j], false, false);
+          oL[j] = r[0]; oH[j] = r[1];
+        }
+        return;
+      }
+      if (w < 2 + E_A0 && row == 0) {    // (tile row 0 only) the shift = the slot's values at the tile's first pixel: from lane li = 0 of this row
+        const int z = w - 2;
+        if (z < 2) { eo[2 * z] = __shfl(oL[2 * z], lane & 48, 64); eo[2 * z + 1] = __shfl(oL[2 * z + 1], lane & 48, 64); }
+        else { const int j = z - 2; a0[2 * j] = lo_f(eo[j]); a0[2 * j + 1] = hi_f(eo[j]); }
+        return;
+      }
+      const int v = w - 2 - (row == 0 ? E_A0 : 0);                 // 0 .. 31: it-step (L', then H') x channel pair x {unpack, - shift, s1, s2}
+      if (v < 0 || v >= 32) return;
+      const int x = v >> 4, j = (v >> 2) & 3, o = v & 3;
+      const unsigned pkd = x ? oH[j] : oL[j];
+      if (o == 0) { f0 = lo_f(pkd); f1 = hi_f(pkd); }
+      else if (o == 1) { f0 = f0 - a0[2 * j]; f1 = f1 - a0[2 * j + 1]; }
+      else if (o == 2) { s1[2 * j] += f0; s1[2 * j + 1] += f1; }
+      else { s2[2 * j] = fmaf(f0, f0, s2[2 * j]); s2[2 * j + 1] = fmaf(f1, f1, s2[2 * j + 1]); }
     }
   };
+  // number of micro-ops of tile row `row` (its E_A0 ops exist on row 0 only)
+  // the statistics of a finished tile: butterfly over the 16 lanes of a row (old order: xor 1, 2, 4, 8), lane li = 0 writes the slab row
+  auto stats_finish = [&](const TileCo& c, const bool write) __attribute__((always_inline)) {
+    if constexpr (KIND == 1) {
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], d, 64); s2[e] += __shfl_xor(s2[e], d, 64); }
+      if (write && (lane & 15) == 0) {       // (not for the garbage the first tile's stand-in "previous half" produced)
+        const int tr = (c.y0 >> 2) * tiles_x + (c.x0 >> 5);
+        const size_t srow = (size_t)c.b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
+        float* out = p.st_partial + (srow * 3) * CIN + n + 8 * ((lane >> 4) & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { out[e] = s1[e]; out[CIN + e] = s2[e]; out[2 * CIN + e] = a0[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    }
+  };
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; a0[e] = 0.f; }
 
   int buf = 0;
   TileCo prev = cur;            // (first tile: the "previous tile's" half epilogue stores garbage where this tile's own epilogue writes later)
@@ -312,45 +375,42 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const char* pb = fbase + buf * PATCH_BYTES;
     char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) { frag_load1(0, ii, pb); frag_load1(1, ii, pb); }
+    for (int g = 0; g < 8; ++g) frag_load1(g, pb);
     stage_norm_load(nxt);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          // a slot: the two MFMAs of pixel block i, the read that refills their fragment two steps ahead, this slot's share of the staging
-          // (wst::slot0 / load_of) and of the other half's epilogue, a full scheduling barrier: the emitted order IS this order
-          const int s = half * ITERS + it, g = s * 4 + ii, i = half * 4 + ii;
-#pragma unroll
-          for (int jb = 0; jb < 2; ++jb) {
-            if (WST_DBG & 8) { asm volatile("" : "+v"(pf[(s & 1) * 4 + ii])); continue; }
-            if (it == 0) acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[it][jb], pf[(s & 1) * 4 + ii], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            else acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[it][jb], pf[(s & 1) * 4 + ii], acc[i][jb], 0, 0, 0);
-          }
-          if (s + 2 < 2 * ITERS && !(WST_DBG & 4)) frag_load1(s + 2, ii, pb);
-          if (load_of(g) >= 0 && !(WST_DBG & 1)) stage_load(load_of(g), q);
-          if (g >= SLOT0 && g < slot0(NITP) && !(WST_DBG & 1)) {
-            const int k = (g - SLOT0) / MICRO, u = (g - SLOT0) - k * MICRO;
-            stage_micro(k, u, q, nb);
-            // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
-            // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
-            if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
-          }
-          {
-            const int gl = it * 4 + ii;
-#pragma unroll
-            for (int eu = gl * E_HALF / (ITERS * 4); eu < (gl + 1) * E_HALF / (ITERS * 4) && !(WST_DBG & 2); ++eu) {
-              epi_micro((half ? 0 : 4) + eu / E_BLOCK, eu % E_BLOCK, half ? cur : prev);
-              asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(eo));
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+      for (int sl = 0; sl < ITERS * 4; ++sl) {
+        // a slot: the MFMA, the read that refills its fragment eight slots ahead, this slot's share of the staging (wst::slot0 / load_of) and
+        // of the other half's epilogue, a full scheduling barrier: the emitted order IS this order
+        const int g = half * ITERS * 4 + sl, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
+        if (WST_DBG & 8) asm volatile("" : "+v"(pf[g & 7]));
+        else if (it == 0 && ss == 0) acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g & 7], f32x16{}, 0, 0, 0);
+        else acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g & 7], acc[row], 0, 0, 0);
+        if (g + 8 < SLOTS && !(WST_DBG & 4)) frag_load1(g + 8, pb);
+        if (load_of(g) >= 0 && !(WST_DBG & 1)) stage_load(load_of(g), q);
+        if (g >= SLOT0 && g < slot0(NITP) && !(WST_DBG & 1)) {
+          const int k = (g - SLOT0) / MICRO, u = (g - SLOT0) - k * MICRO;
+          stage_micro(k, u, q, nb);
+          // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
+          // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
+          if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
         }
+#pragma unroll
+        for (int eu = sl * E_HALF / (ITERS * 4); eu < (sl + 1) * E_HALF / (ITERS * 4) && !(WST_DBG & 2); ++eu) {
+          // (half B finishes tile rows 0 - 1 of this tile -- row 0 carries the E_A0 extra ops --, half A rows 2 - 3 of the previous one)
+          const int r0n = E_ROW + (half ? E_A0 : 0);
+          if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev);
+          else if (eu - r0n < E_ROW) epi_micro(half ? 1 : 3, eu - r0n, half ? cur : prev);
+          asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(eo));
+          if (KIND == 1) asm volatile("" : "+v"(oL), "+v"(oH));
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       stamp(2 + 3 * tile_no + half);
+      if (half == 0) stats_finish(prev, tile_no > 0);            // the previous tile's rows 2 - 3 went in during this half A: its sums are complete
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loops
     stamp(4 + 3 * tile_no); ++tile_no;
@@ -360,7 +420,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   }
   // the last tile's second half
 #pragma unroll
-  for (int eu = 0; eu < E_HALF; ++eu) epi_micro(4 + eu / E_BLOCK, eu % E_BLOCK, prev);
+  for (int eu = 0; eu < 2 * E_ROW; ++eu) epi_micro(2 + eu / E_ROW, eu % E_ROW, prev);
+  stats_finish(prev, true);
   stamp(31);
 }
 
@@ -369,7 +430,7 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
          p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
-         !(p.st_partial && p.nb_partial) && !p.nb_partial && !p.st_partial && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
+         !(p.st_partial && p.nb_partial) && !p.nb_partial && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
 }
 
 template <bool NRM>

@@ -6,6 +6,7 @@ import dbglib  # noqa: F401
 from pixelwiseregression_amd import kernels as K, _lib
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+STATS = len(sys.argv) > 2 and sys.argv[2] == "stats"
 P, F_ = 64, 128
 x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
 w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
@@ -15,10 +16,14 @@ bias = torch.zeros(F_, device=dev)
 nwg = 256
 stamps = torch.zeros(nwg, 32, dtype=torch.int64, device=dev)
 l = _lib.lib()
-for _ in range(3): K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st)
+def conv():
+    if STATS:
+        return K.conv_fwd_stats(x, pack, F_, 3, 1, bias=bias, norm=st)
+    return K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st)
+for _ in range(3): conv()
 torch.cuda.synchronize()
 l.pwr_debug_set_stamps(stamps.data_ptr())
-K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st)
+conv()
 torch.cuda.synchronize()
 l.pwr_debug_set_stamps(None)
 s = stamps.cpu()
@@ -27,6 +32,7 @@ ntile = B * 32 // nwg
 print("workgroups", nwg, "tiles per workgroup", ntile, " kernel span (s_memtime ticks = shader cycles?)", int((s[:, 31] - t0).max()))
 print("  start skew: mean %.0f max %.0f" % ((s[:, 0] - t0).double().mean(), (s[:, 0] - t0).max()))
 print("  prologue (weights + first patch + barrier): mean %.0f min %.0f max %.0f" % tuple(f((s[:, 1] - s[:, 0]).double()) for f in (torch.mean, torch.min, torch.max)))
+print("  prologue parts: start -> patch loads issued %.0f -> weights issued + patch written %.0f -> barrier %.0f -> weights landed %.0f" % tuple(float(v.double().mean()) for v in (s[:, 25] - s[:, 0], s[:, 26] - s[:, 25], s[:, 27] - s[:, 26], s[:, 1] - s[:, 27])))
 prev = s[:, 1]
 for k in range(min(ntile, 9)):
     a, b_, c = s[:, 2 + 3 * k], s[:, 3 + 3 * k], s[:, 4 + 3 * k]
@@ -37,6 +43,6 @@ clk = ((s[:, 31] - s[:, 0]).double() / (s[:, 30] - s[:, 29]).double() * 100.0)
 print("  workgroup life: mean %.0f cycles = %.2f us at the %.0f MHz (min %.0f max %.0f) shader clock it measured" % ((s[:, 31] - s[:, 0]).double().mean(), ((s[:, 30] - s[:, 29]).double().mean() / 100.0), clk.mean(), clk.min(), clk.max()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st)
+for _ in range(20): conv()
 e1.record(); torch.cuda.synchronize()
 print("  us per launch (incl. host allocation):", e0.elapsed_time(e1) / 20 * 1e3)
