@@ -56,7 +56,8 @@ def time_head_conv(dev, B, iters=20, precision="bf16"):
     if precision == "bf16":
         x = x.to(torch.bfloat16)
     w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
-    pack = K.pack_conv(w, 0, K.BF16 if precision == "bf16" else K.F32)
+    # (bf16: the pack in the order the engine hands this layer's weights to the kernel -- csrc/conv_wstat.hip's fragment order)
+    pack = K.pack_conv(w, 0, K.BF16, frag=True) if precision == "bf16" else K.pack_conv(w, 0, K.F32)
     gamma, beta = torch.ones(F_, device=dev), torch.zeros(F_, device=dev)
     st = K.norm_stats(x, gamma, beta, mode=0)
     bias = torch.zeros(F_, device=dev)

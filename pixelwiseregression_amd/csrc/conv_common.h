@@ -33,6 +33,7 @@ struct ConvParams {
   // them: 4 x tiles rows per sample, class c at rows c * tiles ...
   int st_nchunks = 0, st_chunk0 = 0;
   int epi16 = 1;            // (debug build: 0 = the two-pass fp32 epilogue also for the 16x16x32 tile)
+  int w_frag = 0;           // the pack is in conv_wstat.hip's fragment order (PackDesc::order 1; the caller passed the pack address with bit 0 set)
 };
 
 struct WgradParams {
@@ -215,6 +216,7 @@ void set_debug_delay(int d);
 // conv_wstat.hip (round 5): the 128 -> 128 3x3 stride-1 bf16 conv with the weights stationary in registers, persistent workgroups;
 // one job (b == nullptr) or two jobs of one geometry per launch
 bool conv_wstat_applicable(const ConvParams& p, int dtype);
+bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int dtype);   // would a plain conv of this shape run on it?
 bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype);
 int launch_conv_wstat(const ConvParams& a, const ConvParams* b, hipStream_t s);
 

@@ -1004,11 +1004,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(ReduceGroup g) 
 //   kind 0 (forward): rows = cout, k = cin            value = W[row][k][ky][kx]
 //   kind 1 (dgrad of a stride-1 conv): rows = cin, k = cout, taps flipped   value = W[k][row][K-1-ky][K-1-kx]
 //   kind 2 (dgrad of a stride-2 conv, gather form): rows = cin, k = cout    value = W[k][row][ky][kx]
+// order 1 (bf16, 3x3, 128 rows x 128 k only): the same 16-byte units in conv_wstat.hip's FRAGMENT order -- [tap][kch][wave = row / 32][ss][lane]
+//   with lane = r + 32 h holding unit (row = 32 wave + chan(r), k slot 2 ss + h), chan(r) = 16 (r / 4 % 2) + 4 (r / 8) + r % 4: every weight
+//   fragment of that kernel is then ONE contiguous 1-KiB load (from the standard order it is 32 pieces of 32 B per wave instruction, and
+//   the 72 such loads per lane were 13 000 of a workgroup's 63 000 cycles).  Callers pass such a pack with bit 0 of its address set.
 // ---------------------------------------------------------------------------------------------
 struct PackDesc {
   long long src_off;   // floats into the flat parameter buffer
   long long dst_off;   // bytes into the pack buffer
-  int Cout, Cin, ksize, kind, rows_pad, KCH, dtype, pad_;
+  int Cout, Cin, ksize, kind, rows_pad, KCH, dtype, order;
 };
 
 // One thread = 8 consecutive K elements of one pack row: 8 gathered floats (stride = taps for the forward packs, Cin x taps for the
@@ -1049,7 +1053,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-      *reinterpret_cast<bf16x8*>(packs + d.dst_off + i * 2) = o;
+      size_t unit = i8;
+      if (d.order == 1) {        // (rows_pad == 128, KE8 == 4: checked on the host)
+        const int slot = i8 % KE8, wave = row >> 5, c = row & 31;
+        const int r = (c & 3) | (((c >> 4) & 1) << 2) | (((c >> 2) & 3) << 3);       // inverse of chan(r)
+        unit = (size_t)(tap * d.KCH + kch) * 512 + wave * 128 + (slot >> 1) * 64 + r + 32 * (slot & 1);
+      }
+      *reinterpret_cast<bf16x8*>(packs + d.dst_off + unit * 16) = o;
     } else {
       float* dst = reinterpret_cast<float*>(packs + d.dst_off) + i;
       *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -1207,7 +1217,10 @@ static int conv_params_fill(pwr::ConvParams& p, const void* x, const void* wpack
                             int stride, int mode, int dtype) {
   const int EP = dtype == PWR_BF16 ? 8 : 4, KE = dtype == PWR_BF16 ? 32 : 16;
   if (Cin % EP || (y && Cout % EP) || (ksize != 1 && ksize != 3 && ksize != 5 && ksize != 7) || (stride != 1 && stride != 2)) return PWR_EUNSUPPORTED;
-  p.x = x; p.w = wpack; p.bias = bias; p.in_norm = in_norm; p.residual = residual;
+  p.x = x; p.bias = bias; p.in_norm = in_norm; p.residual = residual;
+  p.w_frag = (int)((uintptr_t)wpack & 1);                       // (a fragment-order pack: only the shapes conv_wstat.hip takes may carry one)
+  p.w = reinterpret_cast<const void*>((uintptr_t)wpack & ~(uintptr_t)1);
+  if (p.w_frag && !pwr::conv_wstat_shape(B, H, W, Cin, Cout, ksize, stride, dtype)) return PWR_EINVAL;
   p.y = y; p.y_nchw = y_nchw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.ksize = ksize; p.pad = ksize / 2; p.mode = mode; p.relu_in = relu_in;
   if (mode == 0) {

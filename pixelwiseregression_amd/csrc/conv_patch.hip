@@ -923,6 +923,7 @@ bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dt
 }
 int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s) {
   if (conv_wstat_pair_applicable(a, b, PWR_BF16)) return launch_conv_wstat(a, &b, s);
+  if (a.w_frag || b.w_frag) return PWR_EINVAL;       // a fragment-order pack and a launch that is not conv_wstat.hip's
   ConvPair g{a, b};
   g.a.epi16 = g.b.epi16 = 1;
   g.a.stamps = g.b.stamps = nullptr;
@@ -949,6 +950,7 @@ int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
   }
   if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);
   if (conv_wstat_applicable(p, dtype)) return launch_conv_wstat(p, nullptr, s);
+  if (p.w_frag) return PWR_EINVAL;                   // a fragment-order pack and a launch that is not conv_wstat.hip's
   return dtype == PWR_BF16 ? launch_patch_t<bf16_t>(p, s) : launch_patch_t<float>(p, s);
 }
 

@@ -19,6 +19,8 @@
 //     software pipeline, since a second wave per SIMD does not fit beside 288 weight registers.  One barrier per tile.
 // Work per tile and wave: 576 MFMAs (9216 matrix-pipe cycles), 288 ds_read_b128, 13 global loads + 13 ds_write_b128 + ~550 VALU of staging,
 // ~500 VALU of epilogue: the vector work has to ride in the issue shadow of the MFMAs (sched_group_barrier pipelines below).
+#include <type_traits>
+
 #include "conv_common.h"
 #include "pwr.h"
 
@@ -233,9 +235,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const int row = lane & 31;
     const int ch = 32 * wn + 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3);
     const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
+    // (fragment-order pack, conv_mfma.hip PackDesc::order 1: fragment q of wave wn is the contiguous KiB [q / 2][wn][q % 2][lane]; the standard
+    // pack serves too -- 32 pieces of 32 B per wave instruction, a ~10 000-cycle prologue)
+    const T* __restrict__ wl = p.w_frag ? w + ((size_t)wn * 128 + lane) * 8 : w + (size_t)ch * 32 + hh * 8;
+    const int qs0 = p.w_frag ? 512 * 8 : p.CoutPad * 32, qs1 = p.w_frag ? 64 * 8 : 16;       // element strides of q / 2 and q % 2
 #pragma unroll
-    for (int q = 0; q < 2 * ITERS; ++q)
-      wreg[q] = *reinterpret_cast<const V*>(w + ((size_t)(q >> 1) * p.CoutPad + ch) * 32 + (2 * (q & 1) + hh) * 8);
+    for (int q = 0; q < 2 * ITERS; ++q) wreg[q] = *reinterpret_cast<const V*>(wl + (size_t)(q >> 1) * qs0 + (q & 1) * qs1);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -278,11 +283,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // per row, as micro-ops of two independent vector instructions (E_ROW per tile row).  A store's address is a scalar base (tile, row) plus a
   // per-lane constant offset.
   const int n = 32 * wn + 16 * hh;
-  float bias_r[16];
-  {
+  float bias_r[16];            // (a data gradient has no bias: KIND 2 spends these sixteen registers on the norm state instead)
+  if constexpr (KIND != 2) {
     const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
 #pragma unroll
     for (int e = 0; e < 16; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias_r[e] = 0.f;
   }
   const unsigned yoff = (unsigned)(pc * CIN + n) * 2u;
   // KIND 1 (forward statistics of the norm that follows, conv_common.h EpiStats): per 8-channel slot and pixel column li = col % 16 the old
@@ -292,12 +300,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // partner's, the other one keeps 8 - 15 -- and every lane then owns ONE slot (channels n + 8 (col / 16) ...) of the pixels it = 2 row,
   // 2 row + 1 of column li: exactly the old thread's set, consumed in the old order; the final butterfly runs over the 16 lanes of a row.
   // Same sums, bit for bit (tests/test_00_kat_gpu.py holds both kernels to one digest).
-  constexpr int E_ST = KIND == 1 ? 34 : 0;                       // 2 swaps + 2 x 16 accumulate micro-ops per tile row
+  // KIND 2 (this launch is a data gradient g; sums of the norm backward of the tensor y it belongs to: relu-masked g and g * xhat): the same
+  // exchange and order; the forward activations y of the lane's slot and two pixels come straight from global memory (two 16-byte loads per
+  // tile row, issued with the row's first micro-op), the norm state of the sample sits in 32 registers, re-read at the half boundary.
+  constexpr int E_ST = KIND == 1 ? 34 : (KIND == 2 ? 2 + 72 : 0);    // per tile row: 2 swaps + 2 pixels x 4 channel pairs x (4 | 9) micro-ops
   constexpr int E_A0 = KIND == 1 ? 6 : 0;                        // tile row 0: the shift (the tile's first pixel) to every lane of the slot
-  constexpr int E_ROW = 14 + E_ST, E_HALF = 2 * E_ROW + E_A0;    // (half B, rows 0 - 1, carries the E_A0 ops; half A's slots for them stay empty)
+  constexpr int E_BF = KIND != 0 ? 48 : 0;                       // the butterfly over the 16 lanes of a row: 6 steps x 8 pairs of sums
+  constexpr int E_ROW = 14 + E_ST;
+  constexpr int E_HALF_A = 2 * E_ROW + E_BF, E_HALF_B = 2 * E_ROW + E_A0;     // half A: rows 2 - 3 of the previous tile + its butterfly; half B: rows 0 - 1
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
   u32x4 eo, oL, oH;
   float s1[8], s2[8], a0[8];
+  float a1[8], a2[8], a3[8], g0 = 0.f, g1 = 0.f;                  // (KIND 2: rstd, scale, beta of the slot's channels; the masked gradients of a pair)
+  u32x4 yv0, yv1;                                                 // (KIND 2: y of the slot's channels at the row's two pixels)
+  const bool nb_relu = p.nb_relu != 0;
+  const int slot_ch = n + 8 * ((lane >> 4) & 1);                  // first channel of the statistics slot this lane owns after the exchange
   auto pk2 = [](float lo, float hi) __attribute__((always_inline)) { bf16x2 v; v[0] = (bf16_t)lo; v[1] = (bf16_t)hi; return __builtin_bit_cast(unsigned, v); };
   auto lo_f = [](unsigned u) __attribute__((always_inline)) { return __builtin_bit_cast(float, u << 16); };
   auto hi_f = [](unsigned u) __attribute__((always_inline)) { return __builtin_bit_cast(float, u & 0xffff0000u); };
@@ -314,8 +331,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       else {
         char* yb = reinterpret_cast<char*>(p.y) + ((size_t)c.b * HW + (size_t)(c.y0 + row) * W + c.x0) * (CIN * 2) + e8 * 16;
         *reinterpret_cast<u32x4*>(yb + yoff) = eo;
-        if (KIND == 1) { if (e8 == 0) oL = eo; else oH = eo; }
+        if (KIND != 0) { if (e8 == 0) oL = eo; else oH = eo; }
       }
+      if (KIND == 2 && u == 0) {       // y of (row, li) and (row, 16 + li), the slot's 8 channels: in flight while the row's values are stored
+        const char* yr = reinterpret_cast<const char*>(p.nb_y) + ((size_t)c.b * HW + (size_t)(c.y0 + row) * W + c.x0) * (CIN * 2);
+        const unsigned o16 = (unsigned)((lane & 15) * CIN + slot_ch) * 2u;
+        yv0 = *reinterpret_cast<const u32x4*>(yr + o16);
+        yv1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2);
+      }
+      return;
+    }
+    if constexpr (KIND == 2) {
+      const int w = u - 14;
+      if (w < 2) {
+#pragma unroll
+        for (int j = 2 * w; j < 2 * w + 2; ++j) {
+          const auto r = __builtin_amdgcn_permlane16_swap(oL[j], oH[j], false, false);
+          oL[j] = r[0]; oH[j] = r[1];
+        }
+        return;
+      }
+      const int v = w - 2;                                         // 0 .. 71: pixel (L', then H') x channel pair x 9 micro-ops
+      const int x = v / 36, j = (v / 9) & 3, o = v % 9;
+      const unsigned gp = x ? oH[j] : oL[j], yp = x ? yv1[j] : yv0[j];
+      // EpiStats::add_pre: gg = g unless relu && !(fma(y - mean, scale, beta) > 0); s1 += gg; s2 = fma(gg, (y - mean) * rstd, s2)
+      if (o == 0) { f0 = lo_f(yp); f1 = hi_f(yp); }
+      else if (o == 1) { g0 = lo_f(gp); g1 = hi_f(gp); }
+      else if (o == 2) { f0 = f0 - a0[2 * j]; f1 = f1 - a0[2 * j + 1]; }
+      else if (o == 3) { f2 = fmaf(f0, a2[2 * j], a3[2 * j]); f3 = fmaf(f1, a2[2 * j + 1], a3[2 * j + 1]); }
+      else if (o == 4) { g0 = (!nb_relu || f2 > 0.f) ? g0 : 0.f; }
+      else if (o == 5) { g1 = (!nb_relu || f3 > 0.f) ? g1 : 0.f; }
+      else if (o == 6) { s1[2 * j] += g0; s1[2 * j + 1] += g1; }
+      else if (o == 7) { f0 = f0 * a1[2 * j]; f1 = f1 * a1[2 * j + 1]; }
+      else { s2[2 * j] = fmaf(g0, f0, s2[2 * j]); s2[2 * j + 1] = fmaf(g1, f1, s2[2 * j + 1]); }
       return;
     }
     if constexpr (KIND == 1) {
@@ -344,27 +392,57 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       else { s2[2 * j] = fmaf(f0, f0, s2[2 * j]); s2[2 * j + 1] = fmaf(f1, f1, s2[2 * j + 1]); }
     }
   };
-  // number of micro-ops of tile row `row` (its E_A0 ops exist on row 0 only)
-  // the statistics of a finished tile: butterfly over the 16 lanes of a row (old order: xor 1, 2, 4, 8), lane li = 0 writes the slab row
-  auto stats_finish = [&](const TileCo& c, const bool write) __attribute__((always_inline)) {
-    if constexpr (KIND == 1) {
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += __shfl_xor(s1[e], d, 64); s2[e] += __shfl_xor(s2[e], d, 64); }
+  // The butterfly over the 16 lanes of a row (xor 1, 2, 4, 8 like the old kernel's __shfl_xor loop, which hipcc turns into ds_bpermute_b32:
+  // 64 LDS round trips, each behind a wait that also drains the fragment reads) as DPP moves: xor 1 / 2 = quad_perm, xor 8 = row_ror:8,
+  // xor 4 = row_shl:4 into banks 0 and 2 + row_shr:4 into banks 1 and 3 (two moves and an add).  A micro-op handles one pair of sums
+  // 2 j, 2 j + 1 of (s1[0 .. 7], s2[0 .. 7]).
+  float bt0 = 0.f, bt1 = 0.f;
+  auto dpp = [](float old, float src, auto CTRL, auto BANK) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), decltype(CTRL)::value, 0xF,
+                                                                  decltype(BANK)::value, false));
+  };
+  auto bfly_micro = [&](const int b) __attribute__((always_inline)) {
+    if constexpr (KIND != 0) {
+      // (b = 0 .. 15: xor 1, xor 2 over the eight pairs; 16 .. 39: per pair its three xor-4 ops in a row -- they share the two temporaries --;
+      // 40 .. 47: xor 8)
+      const int step = b < 16 ? (b >> 3) : (b < 40 ? 2 + (b - 16) % 3 : 5), j = b < 16 ? (b & 7) : (b < 40 ? (b - 16) / 3 : b - 40);
+      float& x0 = j < 4 ? s1[2 * j] : s2[2 * (j - 4)];
+      float& x1 = j < 4 ? s1[2 * j + 1] : s2[2 * (j - 4) + 1];
+      typedef std::integral_constant<int, 0xF> ALL;
+      if (step == 0) { x0 += dpp(x0, x0, std::integral_constant<int, 0xB1>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0xB1>{}, ALL{}); }
+      else if (step == 1) { x0 += dpp(x0, x0, std::integral_constant<int, 0x4E>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0x4E>{}, ALL{}); }
+      else if (step == 2) { bt0 = dpp(x0, x0, std::integral_constant<int, 0x104>{}, std::integral_constant<int, 0x5>{}); bt1 = dpp(x1, x1, std::integral_constant<int, 0x104>{}, std::integral_constant<int, 0x5>{}); }
+      else if (step == 3) { bt0 = dpp(bt0, x0, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xA>{}); bt1 = dpp(bt1, x1, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xA>{}); }
+      else if (step == 4) { x0 += bt0; x1 += bt1; }
+      else { x0 += dpp(x0, x0, std::integral_constant<int, 0x128>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0x128>{}, ALL{}); }
+    }
+  };
+  // the finished sums of tile c: lane li = 0 of every row writes its slot's slab entries; then the sums restart
+  auto stats_write = [&](const TileCo& c, const bool write) __attribute__((always_inline)) {
+    if constexpr (KIND != 0) {
       if (write && (lane & 15) == 0) {       // (not for the garbage the first tile's stand-in "previous half" produced)
         const int tr = (c.y0 >> 2) * tiles_x + (c.x0 >> 5);
         const size_t srow = (size_t)c.b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
-        float* out = p.st_partial + (srow * 3) * CIN + n + 8 * ((lane >> 4) & 1);
+        float* out = (KIND == 1 ? p.st_partial + (srow * 3) * CIN : p.nb_partial + (srow * 2) * CIN) + slot_ch;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { out[e] = s1[e]; out[CIN + e] = s2[e]; out[2 * CIN + e] = a0[e]; }
+        for (int e = 0; e < 8; ++e) { out[e] = s1[e]; out[CIN + e] = s2[e]; if (KIND == 1) out[2 * CIN + e] = a0[e]; }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     }
   };
+  // (KIND 2) mean, rstd, scale, beta of sample b for the slot's channels (conv_common.h: nb_state = [4][B][C])
+  auto nb_state_load = [&](const int b) __attribute__((always_inline)) {
+    if constexpr (KIND == 2) {
+      const size_t plane = (size_t)p.B * CIN;
+      const float* st = p.nb_state + (size_t)b * CIN + slot_ch;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0[e] = st[e]; a1[e] = st[plane + e]; a2[e] = st[2 * plane + e]; a3[e] = st[3 * plane + e]; }
+    }
+  };
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; a0[e] = 0.f; }
+  nb_state_load(cur.b);
 
   int buf = 0;
   TileCo prev = cur;            // (first tile: the "previous tile's" half epilogue stores garbage where this tile's own epilogue writes later)
@@ -398,18 +476,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
           if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
         }
 #pragma unroll
-        for (int eu = sl * E_HALF / (ITERS * 4); eu < (sl + 1) * E_HALF / (ITERS * 4) && !(WST_DBG & 2); ++eu) {
-          // (half B finishes tile rows 0 - 1 of this tile -- row 0 carries the E_A0 extra ops --, half A rows 2 - 3 of the previous one)
+        for (int eu = sl * (half ? E_HALF_B : E_HALF_A) / (ITERS * 4); eu < (sl + 1) * (half ? E_HALF_B : E_HALF_A) / (ITERS * 4) && !(WST_DBG & 2); ++eu) {
+          // (half B finishes tile rows 0 - 1 of this tile -- row 0 carries the E_A0 extra ops --, half A rows 2 - 3 of the previous one and
+          // then the butterfly of its sums)
           const int r0n = E_ROW + (half ? E_A0 : 0);
           if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev);
           else if (eu - r0n < E_ROW) epi_micro(half ? 1 : 3, eu - r0n, half ? cur : prev);
+          else bfly_micro(eu - r0n - E_ROW);
           asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(eo));
-          if (KIND == 1) asm volatile("" : "+v"(oL), "+v"(oH));
+          if (KIND != 0) {
+            asm volatile("" : "+v"(oL), "+v"(oH), "+v"(bt0), "+v"(bt1));
+            if (KIND == 2) asm volatile("" : "+v"(g0), "+v"(g1));
+            if (eu - r0n >= E_ROW) {      // (tie the pair of sums this butterfly op touched)
+              const int bb = eu - r0n - E_ROW, j = bb < 16 ? (bb & 7) : (bb < 40 ? (bb - 16) / 3 : bb - 40);
+              if (j < 4) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]));
+              else asm volatile("" : "+v"(s2[2 * (j - 4)]), "+v"(s2[2 * (j - 4) + 1]));
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       stamp(2 + 3 * tile_no + half);
-      if (half == 0) stats_finish(prev, tile_no > 0);            // the previous tile's rows 2 - 3 went in during this half A: its sums are complete
+      if (half == 0) {
+        stats_write(prev, tile_no > 0);                            // the previous tile's rows 2 - 3 and the butterfly went in during this half A
+        if (KIND == 2 && cur.b != prev.b) nb_state_load(cur.b);    // (first needed some twenty slots into half B)
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loops
@@ -421,8 +512,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // the last tile's second half
 #pragma unroll
   for (int eu = 0; eu < 2 * E_ROW; ++eu) epi_micro(2 + eu / E_ROW, eu % E_ROW, prev);
-  stats_finish(prev, true);
+#pragma unroll
+  for (int b = 0; b < E_BF; ++b) bfly_micro(b);
+  stats_write(prev, true);
   stamp(31);
+}
+
+bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int dtype) {
+  ConvParams p;
+  p.x = nullptr; p.w = nullptr; p.bias = nullptr; p.in_norm = nullptr; p.residual = nullptr; p.y = (void*)1; p.y_nchw = nullptr;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CoutPad = Cout; p.Ho = H; p.Wo = W;
+  p.ksize = ksize; p.stride = stride; p.pad = ksize / 2; p.mode = 0; p.relu_in = 1; p.KCH = Cin / 32; p.M = B * H * W;
+  return conv_wstat_applicable(p, dtype);
 }
 
 bool conv_wstat_applicable(const ConvParams& p, int dtype) {
@@ -430,14 +531,14 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
          p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
-         !(p.st_partial && p.nb_partial) && !p.nb_partial && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
+         !(p.st_partial && p.nb_partial) && !(p.nb_partial && (p.in_norm || p.bias)) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
 }
 
 template <bool NRM>
 static void launch_kind(const WstatArgs& a, int kind, dim3 grid, hipStream_t s) {
   if (kind == 0) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 0>), grid, dim3(256), 0, s, a);
   else if (kind == 1) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 1>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 2>), grid, dim3(256), 0, s, a);
+  else if constexpr (!NRM) hipLaunchKernelGGL((conv3x3_wstat_kernel<false, 2>), grid, dim3(256), 0, s, a);
 }
 
 // one job (b == nullptr) or two jobs of one geometry, one norm / statistics form

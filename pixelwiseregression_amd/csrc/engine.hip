@@ -23,6 +23,7 @@
 
 #include "pwr.h"
 #include "pwr_common.h"
+namespace pwr { bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int dtype); }   // conv_wstat.hip
 #ifdef PWR_DEBUG_BUILD
 #include "pwr_debug.h"
 #endif
@@ -272,7 +273,9 @@ struct Engine {
   void want_slab(size_t bytes) { if (bytes > scr_slab_bytes) scr_slab_bytes = bytes; }
 
   // ---------------------------------------------------------------- layer constructors
-  ConvL conv_params(int cin, int cout, int k, int stride, bool mfma, bool need_dgrad) {
+  // map_hw > 0: the layer runs on map_hw x map_hw maps; where conv_wstat.hip takes that shape its packs are written in that kernel's fragment
+  // order and handed over with bit 0 of the address set (conv_mfma.hip PackDesc::order)
+  ConvL conv_params(int cin, int cout, int k, int stride, bool mfma, bool need_dgrad, int map_hw = 0) {
     ConvL c;
     c.Cin = cin; c.Cout = cout; c.k = k; c.stride = stride; c.cin_real = cin;
     c.w = take_param((long long)cout * cin * k * k);
@@ -280,9 +283,11 @@ struct Engine {
     if (mfma) {
       PackDescHost d;
       const int KE = dtype == PWR_BF16 ? 32 : 16;
+      const bool frag = map_hw > 0 && pwr::conv_wstat_shape(B, map_hw, map_hw, cin, cout, k, stride, dtype);
       c.pack_f = alloc_pack(pwr_conv_pack_bytes(cout, cin, k, 0, dtype));
-      d = {c.w, (long long)c.pack_f, cout, cin, k, 0, pwr_conv_out_pad(cout), (cin + KE - 1) / KE, dtype, 0};
+      d = {c.w, (long long)c.pack_f, cout, cin, k, 0, pwr_conv_out_pad(cout), (cin + KE - 1) / KE, dtype, frag ? 1 : 0};
       descs.push_back(d);
+      if (frag) c.pack_f |= 1;
       if (need_dgrad && training) {
         const int kind = stride == 2 ? 2 : 1;
         c.pack_d = alloc_pack(pwr_conv_pack_bytes(cout, cin, k, kind, dtype));
@@ -796,9 +801,9 @@ struct Engine {
     for (int k = 0; k < 2; ++k) {
       Head& h = *hs[k];
       scope = "s" + std::to_string(stage_idx) + (k == 0 ? ".plane" : ".depth");
-      h.c0 = conv_params(F, F, ks, 1, true, true); h.n0 = norm_params(F);
-      h.c1 = conv_params(F, F, ks, 1, true, true); h.n1 = norm_params(F);
-      h.c2 = conv_params(F, F, ks, 1, true, true); h.n2 = norm_params(F);
+      h.c0 = conv_params(F, F, ks, 1, true, true, P); h.n0 = norm_params(F);
+      h.c1 = conv_params(F, F, ks, 1, true, true, P); h.n1 = norm_params(F);
+      h.c2 = conv_params(F, F, ks, 1, true, true, P); h.n2 = norm_params(F);
       h.c3 = conv_params(F, J, ks, 1, true, true);
     }
     scope = "s" + std::to_string(stage_idx) + ".heads";

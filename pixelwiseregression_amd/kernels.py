@@ -37,27 +37,46 @@ def _p(t):
 
 
 def pack_descs(entries, device):
-    """entries: list of (src_off_floats, dst_off_bytes, Cout, Cin, ksize, kind, dtype) -> device tensor."""
+    """entries: list of (src_off_floats, dst_off_bytes, Cout, Cin, ksize, kind, dtype[, order]) -> device tensor."""
     l = _lib.lib()
     buf = bytearray()
-    for (src, dst, cout, cin, k, kind, dtype) in entries:
+    for ent in entries:
+        (src, dst, cout, cin, k, kind, dtype), order = ent[:7], (ent[7] if len(ent) > 7 else 0)
         rows, kdim = (cout, cin) if kind == 0 else (cin, cout)
         ke = 32 if dtype == BF16 else 16
         buf += struct.pack("<qqiiiiiiii", src, dst, cout, cin, k, kind, l.pwr_conv_out_pad(rows), (kdim + ke - 1) // ke,
-                           dtype, 0)
+                           dtype, order)
     return torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
 
 
-def pack_conv(weight, kind, dtype):
-    """weight: OIHW fp32 cuda tensor -> packed uint8 buffer for pwr_conv_fwd."""
+class FragPack:
+    """A weight pack in the fragment order of the weight-stationary 128 -> 128 3x3 conv (csrc/conv_wstat.hip): the C ABI takes its address with
+    bit 0 set, and only for the shapes that kernel takes."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def data_ptr(self):
+        return self.t.data_ptr() | 1
+
+    is_cuda = True
+
+    def is_contiguous(self):
+        return True
+
+
+def pack_conv(weight, kind, dtype, frag=False):
+    """weight: OIHW fp32 cuda tensor -> packed uint8 buffer for pwr_conv_fwd.  frag: the fragment-order pack (bf16 128 x 128 3x3 only)."""
     l = _lib.lib()
     cout, cin, k, _ = weight.shape
+    if frag and not (dtype == BF16 and cout == 128 and cin == 128 and k == 3 and kind in (0, 1)):
+        raise ValueError("fragment-order packs exist for bf16 128 x 128 3x3 stride-1 weights")
     nbytes = l.pwr_conv_pack_bytes(cout, cin, k, kind, dtype)
     packs = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     flat = weight.contiguous().float().view(-1)
-    descs = pack_descs([(0, 0, cout, cin, k, kind, dtype)], weight.device)
+    descs = pack_descs([(0, 0, cout, cin, k, kind, dtype, 1 if frag else 0)], weight.device)
     _lib.check(l.pwr_pack_weights(_p(flat), _p(packs), _p(descs), 1, _s(weight)), "pwr_pack_weights")
-    return packs
+    return FragPack(packs) if frag else packs
 
 
 def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_in=True, residual=None, mode=0,

@@ -124,6 +124,37 @@ def test_conv_forward(case, dtype, prologue):
     assert_close(nchw(y), ref, tol(dtype), "conv fwd %s" % (case,))
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 32, 64), (5, 8, 96), (3, 32, 32)])
+@pytest.mark.parametrize("form", ["plain", "norm", "norm_stats", "dgrad_nbsums"])
+def test_weight_stationary_conv_fragment_order_pack(B, H, W, form):
+    """csrc/conv_wstat.hip (the 128 -> 128 3x3 stride-1 bf16 conv with the weights stationary in registers): the pack in the kernel's own
+    fragment order (PackDesc::order 1, handed over with bit 0 of the address set -- what the engine does for the heads' layers) gives
+    exactly the bytes of the standard pack, outputs and epilogue statistics, for every tile count from 4 up (1 .. several tiles per persistent
+    workgroup, partial last ranges); and a fragment-order pack on a shape the kernel does not take is refused."""
+    from pixelwiseregression_amd import kernels as K, _lib
+    x = nhwc(rnd(B, 128, H, W, seed=41), torch.bfloat16)
+    w = rnd(128, 128, 3, 3, seed=42, scale=(128 * 9) ** -0.5).float().to(DEV)
+    bias = (rnd(128, seed=43) * 3).float().to(DEV)
+    _, st = apply_nr(q(rnd(B, 128, H, W, seed=41), torch.bfloat16), B, 128, torch.bfloat16)
+    outs = []
+    for frag in (False, True):
+        if form == "dgrad_nbsums":
+            pack = K.pack_conv(w, 1, K.BF16, frag=frag)
+            nby = nhwc(rnd(B, 128, H, W, seed=44), torch.bfloat16)
+            y, part, _ = K.conv_fwd_stats(x, pack, 128, 3, 1, nb_y=nby, nb_state=st)
+            outs.append((y, part))
+        elif form == "norm_stats":
+            y, part, _ = K.conv_fwd_stats(x, K.pack_conv(w, 0, K.BF16, frag=frag), 128, 3, 1, bias=bias, norm=st)
+            outs.append((y, part))
+        else:
+            y, _ = K.conv_fwd(x, K.pack_conv(w, 0, K.BF16, frag=frag), 128, 3, 1, bias=bias, norm=st if form == "norm" else None)
+            outs.append((y,))
+    for a, b_ in zip(*outs):
+        assert float(a.float().abs().max()) > 0 and torch.equal(a, b_), float((a.float() - b_.float()).abs().max())
+    with pytest.raises(_lib.PwrError):
+        K.conv_fwd(x, K.pack_conv(w, 0, K.BF16, frag=True), 128, 3, 2, bias=bias)          # stride 2: not that kernel's shape
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("J", [14, 4, 21])
 @pytest.mark.parametrize("H,Cin", [(32, 64), (64, 128), (16, 64)])

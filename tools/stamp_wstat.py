@@ -10,7 +10,7 @@ STATS = len(sys.argv) > 2 and sys.argv[2] == "stats"
 P, F_ = 64, 128
 x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
 w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
-pack = K.pack_conv(w, 0, K.BF16)
+pack = K.pack_conv(w, 0, K.BF16, frag="std" not in sys.argv)
 st = K.norm_stats(x, torch.ones(F_, device=dev), torch.zeros(F_, device=dev), mode=0)
 bias = torch.zeros(F_, device=dev)
 nwg = 256
