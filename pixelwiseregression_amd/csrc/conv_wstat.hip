@@ -1,24 +1,34 @@
-// 3x3 stride-1 convolution 128 -> 128 channels, bf16, WEIGHT-STATIONARY and persistent (round 5): the heads' convs and their data gradients,
-// 72 % of the conv FLOPs of /root/reference/model.py:54-65 / :103-114.
+// 3x3 stride-1 convolution 128 -> 128 channels, bf16, WEIGHT-STATIONARY and persistent (round 5): the heads' convs
+// (/root/reference/model.py:54-65 / :103-114: 72 % of the conv FLOPs of a forward pass), plain, with the norm + ReLU prologue, with the
+// forward-statistics epilogue and with the norm-backward-sums epilogue of their data gradients.
 //
 // Why another form.  conv3x3_patch_kernel (conv_patch.hip) spends 30 % of a workgroup's life staging its input patch, 53 % in the K loop and
 // 17 % in the epilogue, the two workgroups of a CU run in phase, and it streams all 288 KiB of weights through LDS for every 128-pixel tile
 // (a 3-stage LDS-DMA ring with a barrier per 32-channel K step): 0.355 of the bf16 MFMA peak for two rounds.  Here:
-//   * ONE workgroup of 4 waves per CU, ONE wave per SIMD, all 512 registers of the SIMD; the workgroup is PERSISTENT and walks tiles.
+//   * ONE workgroup of 4 waves per CU, ONE wave per SIMD, all 512 registers of the SIMD; the workgroup is PERSISTENT and walks a contiguous
+//     range of 4 x 32-pixel tiles.
 //   * The WEIGHTS live in REGISTERS for the whole launch: wave w owns output channels 32 w ... 32 w + 31 for the whole K extent
-//     (9 taps x 128 input channels = 36 K steps x 2 row blocks x 4 registers = 288 VGPRs), loaded once from L2.  No weight traffic through LDS,
-//     no weight ring, NO barrier inside the K loop.  LDS read traffic per MFMA halves (only the pixel operand is read from LDS).
-//   * MFMA operands are swapped against conv_patch.hip: A = weights (rows = output channels), B = pixels (columns), v_mfma_f32_16x16x32_bf16.
-//     The accumulator of a lane is then 4 consecutive channels of ONE pixel per row block; with the channel <-> MFMA-row assignment
-//     ch = 8 (row / 4) + 4 block + row % 4 a lane holds 8 CONSECUTIVE channels of a pixel: the epilogue is bias + round + ONE 16-byte NHWC store
-//     per pixel block straight from registers (no LDS round trip), and the column statistics fall out in exactly the per-thread order of the
-//     one-pass epilogue of conv_patch.hip (same K-step order, same MFMA shape, same operands => outputs AND statistics bit-identical to it;
-//     tests/test_00_kat_gpu.py holds both kernels to the same digests).
+//     (9 taps x 128 input channels = 72 K steps of 16 channels x 4 registers = 288 registers: 256 AGPRs + 32 VGPRs), loaded once from L2 --
+//     from a pack in the kernel's own fragment order every fragment is one contiguous KiB (conv_mfma.hip PackDesc::order).  No weight
+//     traffic through LDS, no weight ring, NO barrier inside the K loop; LDS read traffic per MFMA halves (only pixels are read from LDS).
+//   * MFMA operands are swapped against conv_patch.hip: A = weights (rows = output channels), B = pixels (columns = one tile row),
+//     v_mfma_f32_32x32x16_bf16, accumulators in VGPRs.  With the channel <-> MFMA-row assignment of the weight load a lane's 16 accumulator
+//     registers of a tile row are 16 CONSECUTIVE channels of one pixel: the epilogue is bias + round + two 16-byte NHWC stores per row
+//     straight from registers (no LDS round trip).  Same K-step order and same operands as the patch kernel's 16x16x32 form => outputs
+//     bit-identical to it; the epilogue statistics keep its summation order through one v_permlane16_swap per packed dword (below):
+//     tests/test_00_kat_gpu.py holds both kernels to the same digests, tools/wstat_check.py compares them directly.
 //   * The input patch (6 x 34 pixels x 128 channels, norm + ReLU applied on the way, pixel pitch padded by 16 B like conv_patch.hip) is DOUBLE
-//     buffered in LDS (2 x 54 KiB): the patch of tile n + 1 is loaded, normalised and written while the MFMAs of tile n issue -- the wave's own
+//     buffered in LDS (2 x 55 KiB): the patch of tile n + 1 is loaded, normalised and written while the MFMAs of tile n issue -- the wave's own
 //     software pipeline, since a second wave per SIMD does not fit beside 288 weight registers.  One barrier per tile.
-// Work per tile and wave: 576 MFMAs (9216 matrix-pipe cycles), 288 ds_read_b128, 13 global loads + 13 ds_write_b128 + ~550 VALU of staging,
-// ~500 VALU of epilogue: the vector work has to ride in the issue shadow of the MFMAs (sched_group_barrier pipelines below).
+//   * A tile runs as two half-tile K loops (tile rows 0 - 1, then 2 - 3); the epilogue of the half finished before rides behind the MFMAs
+//     of the running one.  ALL vector work inside the K loops -- staging and epilogue -- is cut into MICRO-OPS of two independent vector
+//     instructions that are handed out per MFMA slot by compile-time tables; a full scheduling barrier closes every slot and an empty asm
+//     ties each micro-op's temporaries into it (left alone hipcc emits a vector's 45 staging instructions as one lump and the pipe drains).
+// Work per tile and wave: 288 MFMAs (9216 matrix-pipe cycles), 288 ds_read_b128, 13 global loads + 13 ds_write_b128 + ~550 vector instructions
+// of staging (norm form), ~100 (plain) / ~400 (forward statistics) / ~700 (norm-backward sums) of epilogue.  Measured (MI355X, B = 32, 64 x 64,
+// s_memtime stamps): prologue 13 k cycles (340 KiB per CU: cold patch from HBM + the weights from L2), half-tile K loops 5.4 - 6.0 k cycles
+// (MFMA alone: 4.7 k), the norm-backward-sums form 9 - 11 k: with one wave per SIMD the vector work beyond ~5 instructions per MFMA is no
+// longer hidden, so the data gradients stay on conv_patch.hip's pair kernel (two workgroups per CU hide that epilogue better).
 #include <type_traits>
 
 #include "conv_common.h"
@@ -80,7 +90,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // the 16x16x32 build ran its K loops at 1.36x the matrix-pipe time.)  The plain LDS image (pixel pitch 272 B, channel slot c at 16 c)
   // is conflict-free for these reads: the 32 lanes of a half read ONE slot of 32 consecutive pixels.
   const int pc = lane & 31, hh = lane >> 5;
-  auto tau = [](int c) { return c; };
   const int job = blockIdx.x % a.njobs, wgj = blockIdx.x / a.njobs;
   const ConvParams& p = a.job[job];
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   const int H = p.H, W = p.W;
   const int st_pl = tid >> 4, st_slot = tid & 15;
   const int r12 = st_pl >> 1, c12 = 32 + (st_pl & 1);                      // vector 12's patch pixel
-  const int lds_st = (st_pl * PITCH) + tau(st_slot) * 16;                  // + (row * PW + 16 (k % 2)) * PITCH
-  const int lds_st12 = (st_pl < 12 ? (r12 * PW + c12) : (PP + st_pl - 12)) * PITCH + tau(st_slot) * 16;
+  const int lds_st = (st_pl * PITCH) + st_slot * 16;                  // + (row * PW + 16 (k % 2)) * PITCH
+  const int lds_st12 = (st_pl < 12 ? (r12 * PW + c12) : (PP + st_pl - 12)) * PITCH + st_slot * 16;
   V sv[NITP];
   float mu[EP], sc[EP], be[EP];
   struct TileCo { int b, y0, x0; };
@@ -312,14 +321,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   u32x4 eo, oL, oH;
   float s1[8], s2[8], a0[8];
   float a1[8], a2[8], a3[8], g0 = 0.f, g1 = 0.f;                  // (KIND 2: rstd, scale, beta of the slot's channels; the masked gradients of a pair)
-  u32x4 yv0, yv1;                                                 // (KIND 2: y of the slot's channels at the row's two pixels)
+  // (KIND 2: y of the slot's channels at a row's two pixels, two sets: a row's loads are issued with the FIRST micro-op of the row before it --
+  // some 45 slots = 1400 cycles ahead; issued with its own row they arrived ~1000 cycles late, 4 x per tile: the tensor comes from HBM)
+  u32x4 yvA0, yvA1, yvB0, yvB1;
   const bool nb_relu = p.nb_relu != 0;
   const int slot_ch = n + 8 * ((lane >> 4) & 1);                  // first channel of the statistics slot this lane owns after the exchange
   auto pk2 = [](float lo, float hi) __attribute__((always_inline)) { bf16x2 v; v[0] = (bf16_t)lo; v[1] = (bf16_t)hi; return __builtin_bit_cast(unsigned, v); };
   auto lo_f = [](unsigned u) __attribute__((always_inline)) { return __builtin_bit_cast(float, u << 16); };
   auto hi_f = [](unsigned u) __attribute__((always_inline)) { return __builtin_bit_cast(float, u & 0xffff0000u); };
   // accumulator register r of a lane = channel n + r (the row -> channel assignment above).  No dependent pair inside a micro-op.
-  auto epi_micro = [&](const int row, const int u, const TileCo& c) __attribute__((always_inline)) {
+  auto epi_micro = [&](const int row, const int u, const TileCo& c, const TileCo& cn) __attribute__((always_inline)) {
     if (u < 14) {
       const int e8 = u / 7, v = u - 7 * e8, c0 = 8 * e8;          // the 8 channels c0 .. c0 + 7: seven micro-ops
       if (v == 0) { f0 = acc[row][c0 + 0] + bias_r[c0 + 0]; f1 = acc[row][c0 + 1] + bias_r[c0 + 1]; }
@@ -333,11 +344,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         *reinterpret_cast<u32x4*>(yb + yoff) = eo;
         if (KIND != 0) { if (e8 == 0) oL = eo; else oH = eo; }
       }
-      if (KIND == 2 && u == 0) {       // y of (row, li) and (row, 16 + li), the slot's 8 channels: in flight while the row's values are stored
-        const char* yr = reinterpret_cast<const char*>(p.nb_y) + ((size_t)c.b * HW + (size_t)(c.y0 + row) * W + c.x0) * (CIN * 2);
+      if (KIND == 2 && u == 0) {       // y of the NEXT row in processing order (rows 0, 1 of `cn` = the current tile; 2, 3 of the tile c)
+        const int nr = (row + 1) & 3;
+        const TileCo& cc = row == 3 ? cn : c;
+        const char* yr = reinterpret_cast<const char*>(p.nb_y) + ((size_t)cc.b * HW + (size_t)(cc.y0 + nr) * W + cc.x0) * (CIN * 2);
         const unsigned o16 = (unsigned)((lane & 15) * CIN + slot_ch) * 2u;
-        yv0 = *reinterpret_cast<const u32x4*>(yr + o16);
-        yv1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2);
+        if (nr & 1) { yvB0 = *reinterpret_cast<const u32x4*>(yr + o16); yvB1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2); }
+        else { yvA0 = *reinterpret_cast<const u32x4*>(yr + o16); yvA1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2); }
       }
       return;
     }
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       }
       const int v = w - 2;                                         // 0 .. 71: pixel (L', then H') x channel pair x 9 micro-ops
       const int x = v / 36, j = (v / 9) & 3, o = v % 9;
-      const unsigned gp = x ? oH[j] : oL[j], yp = x ? yv1[j] : yv0[j];
+      const unsigned gp = x ? oH[j] : oL[j], yp = (row & 1) ? (x ? yvB1[j] : yvB0[j]) : (x ? yvA1[j] : yvA0[j]);
       // EpiStats::add_pre: gg = g unless relu && !(fma(y - mean, scale, beta) > 0); s1 += gg; s2 = fma(gg, (y - mean) * rstd, s2)
       if (o == 0) { f0 = lo_f(yp); f1 = hi_f(yp); }
       else if (o == 1) { g0 = lo_f(gp); g1 = hi_f(gp); }
@@ -382,21 +395,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         else { const int j = z - 2; a0[2 * j] = lo_f(eo[j]); a0[2 * j + 1] = hi_f(eo[j]); }
         return;
       }
-      const int v = w - 2 - (row == 0 ? E_A0 : 0);                 // 0 .. 31: it-step (L', then H') x channel pair x {unpack, - shift, s1, s2}
+      // 0 .. 31: channel pair j = v / 8; inside it the four micro-ops {unpack, - shift, s1, s2} of the row's two pixels ALTERNATE (x = v % 2),
+      // each with its own temporaries: consecutive micro-ops never depend on each other; per sum the pixel order is kept
+      const int v = w - 2 - (row == 0 ? E_A0 : 0);
       if (v < 0 || v >= 32) return;
-      const int x = v >> 4, j = (v >> 2) & 3, o = v & 3;
+      const int j = v >> 3, o = (v & 7) >> 1, x = v & 1;
       const unsigned pkd = x ? oH[j] : oL[j];
-      if (o == 0) { f0 = lo_f(pkd); f1 = hi_f(pkd); }
-      else if (o == 1) { f0 = f0 - a0[2 * j]; f1 = f1 - a0[2 * j + 1]; }
-      else if (o == 2) { s1[2 * j] += f0; s1[2 * j + 1] += f1; }
-      else { s2[2 * j] = fmaf(f0, f0, s2[2 * j]); s2[2 * j + 1] = fmaf(f1, f1, s2[2 * j + 1]); }
+      float& q0 = x ? f2 : f0; float& q1 = x ? f3 : f1;
+      if (o == 0) { q0 = lo_f(pkd); q1 = hi_f(pkd); }
+      else if (o == 1) { q0 = q0 - a0[2 * j]; q1 = q1 - a0[2 * j + 1]; }
+      else if (o == 2) { s1[2 * j] += q0; s1[2 * j + 1] += q1; }
+      else { s2[2 * j] = fmaf(q0, q0, s2[2 * j]); s2[2 * j + 1] = fmaf(q1, q1, s2[2 * j + 1]); }
     }
   };
   // The butterfly over the 16 lanes of a row (xor 1, 2, 4, 8 like the old kernel's __shfl_xor loop, which hipcc turns into ds_bpermute_b32:
   // 64 LDS round trips, each behind a wait that also drains the fragment reads) as DPP moves: xor 1 / 2 = quad_perm, xor 8 = row_ror:8,
   // xor 4 = row_shl:4 into banks 0 and 2 + row_shr:4 into banks 1 and 3 (two moves and an add).  A micro-op handles one pair of sums
   // 2 j, 2 j + 1 of (s1[0 .. 7], s2[0 .. 7]).
-  float bt0 = 0.f, bt1 = 0.f;
+  float bt0_ = 0.f, bt1_ = 0.f, bt2 = 0.f, bt3 = 0.f;
   auto dpp = [](float old, float src, auto CTRL, auto BANK) __attribute__((always_inline)) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), decltype(CTRL)::value, 0xF,
                                                                   decltype(BANK)::value, false));
@@ -405,9 +421,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     if constexpr (KIND != 0) {
       // (b = 0 .. 15: xor 1, xor 2 over the eight pairs; 16 .. 39: per pair its three xor-4 ops in a row -- they share the two temporaries --;
       // 40 .. 47: xor 8)
-      const int step = b < 16 ? (b >> 3) : (b < 40 ? 2 + (b - 16) % 3 : 5), j = b < 16 ? (b & 7) : (b < 40 ? (b - 16) / 3 : b - 40);
+      // (the xor-4 ops of two pairs alternate, each pair with its own two temporaries: no dependent neighbours)
+      const int step = b < 16 ? (b >> 3) : (b < 40 ? 2 + ((b - 16) % 6) / 2 : 5);
+      const int j = b < 16 ? (b & 7) : (b < 40 ? 2 * ((b - 16) / 6) + ((b - 16) & 1) : b - 40);
       float& x0 = j < 4 ? s1[2 * j] : s2[2 * (j - 4)];
       float& x1 = j < 4 ? s1[2 * j + 1] : s2[2 * (j - 4) + 1];
+      float& bt0 = (j & 1) ? bt2 : bt0_; float& bt1 = (j & 1) ? bt3 : bt1_;
       typedef std::integral_constant<int, 0xF> ALL;
       if (step == 0) { x0 += dpp(x0, x0, std::integral_constant<int, 0xB1>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0xB1>{}, ALL{}); }
       else if (step == 1) { x0 += dpp(x0, x0, std::integral_constant<int, 0x4E>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0x4E>{}, ALL{}); }
@@ -480,15 +499,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
           // (half B finishes tile rows 0 - 1 of this tile -- row 0 carries the E_A0 extra ops --, half A rows 2 - 3 of the previous one and
           // then the butterfly of its sums)
           const int r0n = E_ROW + (half ? E_A0 : 0);
-          if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev);
-          else if (eu - r0n < E_ROW) epi_micro(half ? 1 : 3, eu - r0n, half ? cur : prev);
+          if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev, cur);
+          else if (eu - r0n < E_ROW) epi_micro(half ? 1 : 3, eu - r0n, half ? cur : prev, cur);
           else bfly_micro(eu - r0n - E_ROW);
           asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(eo));
           if (KIND != 0) {
-            asm volatile("" : "+v"(oL), "+v"(oH), "+v"(bt0), "+v"(bt1));
+            asm volatile("" : "+v"(oL), "+v"(oH), "+v"(bt0_), "+v"(bt1_), "+v"(bt2), "+v"(bt3));
             if (KIND == 2) asm volatile("" : "+v"(g0), "+v"(g1));
             if (eu - r0n >= E_ROW) {      // (tie the pair of sums this butterfly op touched)
-              const int bb = eu - r0n - E_ROW, j = bb < 16 ? (bb & 7) : (bb < 40 ? (bb - 16) / 3 : bb - 40);
+              const int bb = eu - r0n - E_ROW, j = bb < 16 ? (bb & 7) : (bb < 40 ? 2 * ((bb - 16) / 6) + ((bb - 16) & 1) : bb - 40);
               if (j < 4) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]));
               else asm volatile("" : "+v"(s2[2 * (j - 4)]), "+v"(s2[2 * (j - 4) + 1]));
             }
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   }
   // the last tile's second half
 #pragma unroll
-  for (int eu = 0; eu < 2 * E_ROW; ++eu) epi_micro(2 + eu / E_ROW, eu % E_ROW, prev);
+  for (int eu = 0; eu < 2 * E_ROW; ++eu) epi_micro(2 + eu / E_ROW, eu % E_ROW, prev, prev);
 #pragma unroll
   for (int b = 0; b < E_BF; ++b) bfly_micro(b);
   stats_write(prev, true);
@@ -531,7 +550,7 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
          p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
-         !(p.st_partial && p.nb_partial) && !(p.nb_partial && (p.in_norm || p.bias)) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
+         !(p.st_partial && p.nb_partial) && !(p.nb_partial && (p.in_norm || p.bias || !PWR_DBG_ENV("PWR_WSTAT_NB", 0))) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
 }
 
 template <bool NRM>

@@ -229,6 +229,31 @@ def test_no_cross_half_packed_f32_in_shipped_code_objects():
     assert r["async_lds_hazards"] == 0, r["async_lds_examples"]         # no use of an inline-asm LDS read before its wait (conv_wgrad_dma / _ws)
 
 
+def test_weight_stationary_conv_keeps_everything_in_registers():
+    """csrc/conv_wstat.hip holds 288 weight registers, 64 accumulators and its staging / epilogue state in the 512 registers of a wave, with
+    every register index a compile-time constant of its fully unrolled K loops.  If an edit (or a toolchain) breaks that -- the K loop no
+    longer unrolls, the allocator spills -- the kernel still computes the right thing, slowly, through scratch memory: refuse such a build."""
+    import re
+    import subprocess
+    import tempfile
+    import pytest
+    from pixelwiseregression_amd import _lib, codeobj_scan as cs
+    if not cs.available() or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs the LLVM tools of the ROCm toolchain and a built libpwr_hip.so")
+    seen = 0
+    for triple, blob in cs.code_objects(_lib.LIB_PATH):
+        if "gfx950" not in triple:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob); f.flush()
+            txt = subprocess.run([os.path.join(cs.LLVM, "llvm-readelf"), "--notes", f.name], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S*conv3x3_wstat\S*).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", txt, re.S):
+            name, scratch, vgpr, spill = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+            seen += 1
+            assert scratch == 0 and spill == 0 and vgpr <= 512, (name, scratch, vgpr, spill)
+    assert seen >= 5, seen
+
+
 def test_shipped_library_carries_a_clean_scan_record():
     """build.build() writes <lib>.scan.json after every link: the sha256 of the library it scanned and the (clean) result.  A product
     library without a matching record -- linked by hand, or built with PWR_ALLOW_UNSCANNED=1 on a toolchain without llvm-objdump -- is
