@@ -18,6 +18,11 @@ size_t pwr_engine_layout(void* engine, char* buf, size_t cap);
 /* 0 (the product's mode since round 4): the caller's stream waits for the side streams after the last segment only; 1: after every
  * segment (rounds 2 - 3) */
 void pwr_engine_set_join(void* engine, int each_segment);
+/* per-scope time of the chain (the caller's stream): set_timing(1) puts an event at every change of network part ("stem", "s0.hg3",
+ * "s1.heads", ...) in the launch lists of the following forward / backward calls; timing_report synchronises, writes lines
+ * "phase<TAB>scope<TAB>total ms<TAB>intervals", clears the collection and returns the size needed (tools/step_breakdown.py) */
+void pwr_engine_set_timing(void* engine, int on);
+size_t pwr_engine_timing_report(void* engine, char* buf, size_t cap);
 #ifdef __cplusplus
 }
 #endif

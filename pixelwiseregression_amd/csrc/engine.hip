@@ -166,7 +166,28 @@ static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
   return rc;
 }
 
-typedef std::function<int(Ctx&)> Op;
+// A launch op, tagged with the scope (network part: "stem", "s0.hg3", "s1.heads", "s1.plane.bwd" ...) that was current when it was built --
+// the backward lists are built in reverse and spliced, so the tag travels with the op.  Used by the debug build's per-scope timing
+// (pwr_engine_set_timing / pwr_engine_timing_report, include/pwr_debug.h); free otherwise.
+static std::vector<std::string*> g_scope_names;
+static const char* g_scope_tag = "";
+struct ScopeName {
+  std::string s;
+  ScopeName& operator=(const std::string& v) {
+    s = v;
+    g_scope_names.push_back(new std::string(v));          // (a handful per plan; they live as long as the library)
+    g_scope_tag = g_scope_names.back()->c_str();
+    return *this;
+  }
+};
+struct Op {
+  std::function<int(Ctx&)> f;
+  const char* tag;
+  Op() : tag("") {}
+  template <class F, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, Op>::value>::type>
+  Op(F&& fn) : f(std::forward<F>(fn)), tag(g_scope_tag) {}
+  int operator()(Ctx& c) const { return f(c); }
+};
 
 struct Tn {  // NHWC activation in the arena
   size_t off = 0, goff = 0;
@@ -234,12 +255,25 @@ struct Engine {
   // arena layout record (debugging aid: pwr_engine_layout)
   struct AllocRec { size_t off, bytes; std::string tag; };
   std::vector<AllocRec> layout;
-  std::string scope = "";
+  ScopeName scope;
   int cur_stage = -1;
+#ifdef PWR_DEBUG_BUILD
+  // per-scope timing of the CHAIN (the caller's stream): an event at every change of scope tag in the op sequence of a forward / a backward
+  // segment; pwr_engine_timing_report synchronises and adds up.  (The side streams' weight-gradient kernels are not in these numbers.)
+  bool timing = false;
+  struct TimedEv { std::string phase; const char* tag; hipEvent_t ev; };
+  std::vector<TimedEv> timed;
+  void mark(const std::string& phase, const char* tag, void* st) {
+    hipEvent_t ev;
+    hipEventCreate(&ev);
+    hipEventRecord(ev, (hipStream_t)st);
+    timed.push_back({phase, tag, ev});
+  }
+#endif
   size_t alloc(size_t bytes, const char* tag = "") {
     size_t o = arena_bytes;
     arena_bytes += (bytes + 255) / 256 * 256;
-    layout.push_back({o, bytes, scope + ":" + tag + "#" + std::to_string(layout.size())});
+    layout.push_back({o, bytes, scope.s + ":" + tag + "#" + std::to_string(layout.size())});
     return o;
   }
   size_t alloc_pack(size_t bytes) {
@@ -1221,6 +1255,33 @@ extern "C" size_t pwr_engine_layout(void* h, char* buf, size_t cap) {
 }
 extern "C" void pwr_engine_set_join(void* h, int each_segment) { ((Engine*)h)->join_each_segment = each_segment != 0; }
 #endif   // PWR_DEBUG_BUILD
+#ifdef PWR_DEBUG_BUILD
+// Debugging aid: per-scope chain time.  set_timing(1) starts collecting (events on the caller's stream at every change of scope in the op
+// lists); timing_report synchronises the device, writes lines "phase<TAB>scope<TAB>total ms<TAB>intervals" and clears the collection.
+extern "C" void pwr_engine_set_timing(void* h, int on) { ((Engine*)h)->timing = on != 0; }
+extern "C" size_t pwr_engine_timing_report(void* h, char* buf, size_t cap) {
+  Engine* e = (Engine*)h;
+  hipDeviceSynchronize();
+  std::vector<std::pair<std::string, std::pair<double, int>>> acc;
+  for (size_t i = 0; i + 1 < e->timed.size(); ++i) {
+    if (!e->timed[i].tag || e->timed[i].phase != e->timed[i + 1].phase) continue;       // (a closing mark, or the next call's first mark)
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e->timed[i].ev, e->timed[i + 1].ev);
+    const std::string key = e->timed[i].phase + "\t" + e->timed[i].tag;
+    size_t k = 0;
+    while (k < acc.size() && acc[k].first != key) ++k;
+    if (k == acc.size()) acc.push_back({key, {0.0, 0}});
+    acc[k].second.first += ms; acc[k].second.second += 1;
+  }
+  for (auto& t : e->timed) hipEventDestroy(t.ev);
+  e->timed.clear();
+  std::string s;
+  for (auto& a : acc) s += a.first + "\t" + std::to_string(a.second.first) + "\t" + std::to_string(a.second.second) + "\n";
+  if (buf && cap) { const size_t n = s.size() + 1 < cap ? s.size() + 1 : cap; memcpy(buf, s.c_str(), n); buf[n - 1] = 0; }
+  return s.size() + 1;
+}
+#endif
+
 extern "C" size_t pwr_engine_arena_bytes(void* h) { return ((Engine*)h)->arena_bytes; }
 extern "C" size_t pwr_engine_pack_bytes(void* h) { return ((Engine*)h)->pack_bytes; }
 extern "C" int pwr_engine_num_segments(void* h) { return (int)((Engine*)h)->bwd.size(); }
@@ -1267,9 +1328,15 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
     // hand-off counters of the fused norm kernels live at the head of the partial scratch: zero once per call
     if (e->need_partial) hipMemsetAsync(c.arena + e->scr_partial, 0, 8192 < e->need_partial ? 8192 : e->need_partial, (hipStream_t)st);
     for (size_t i = 0; i < e->fwd.size(); ++i) {
+#ifdef PWR_DEBUG_BUILD
+      if (e->timing && (i == 0 || e->fwd[i].tag != e->fwd[i - 1].tag)) e->mark("forward", e->fwd[i].tag, st);
+#endif
       int rc = e->fwd[i](c);
       if (rc) { char b[96]; snprintf(b, sizeof b, "forward op %zu failed with %d", i, rc); g_last_error = b; return rc; }
     }
+#ifdef PWR_DEBUG_BUILD
+    if (e->timing) e->mark("forward", nullptr, st);
+#endif
     return 0;
   };
   // (hipGraph capture + replay of this launch list was measured in round 1: 8.5 vs 7.7 ms per step on ROCm 7.2 -- the host issues
@@ -1327,6 +1394,9 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
     auto& ops = e->bwd[seg];
     int rc = 0;
     for (size_t i = 0; i < ops.size() && !rc; ++i) {
+#ifdef PWR_DEBUG_BUILD
+      if (e->timing && (i == 0 || ops[i].tag != ops[i - 1].tag)) e->mark("backward segment " + std::to_string(seg), ops[i].tag, st);
+#endif
       rc = ops[i](c);
       if (rc) { char b[96]; snprintf(b, sizeof b, "backward seg %d op %zu failed with %d", seg, i, rc); g_last_error = b; }
     }
@@ -1335,6 +1405,9 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
     // slice -- makes ITS stream wait with pwr_engine_wait_segment(); the chain does not stop for it (round 4: a join per segment cost
     // 0.06 - 0.14 ms of a 5.8 ms step; it was kept in rounds 2 - 3 beside the fix of round 1's non-reproducible step -- the packed-f32
     // form, DESIGN.md section 2 -- and measured then at 1 %).
+#ifdef PWR_DEBUG_BUILD
+    if (e->timing) e->mark("backward segment " + std::to_string(seg), nullptr, st);
+#endif
     const bool join_now = e->join_each_segment || seg + 1 == (int)e->bwd.size();
     for (int k = 0; join_now && c.use_side && k < c.n_side; ++k) {
       hipEventRecord(c.ev_join[k], c.side[k]);

@@ -2,8 +2,14 @@
 same op evaluated with plain torch ops in float64 on the CPU -- the per-op restatement of what
 /root/reference/model.py composes (Conv2d, InstanceNorm2d/BatchNorm2d+ReLU, MaxPool2d, nearest interpolate).
 
-Tolerances (relative to max|ref|): fp32 path 2e-5 (exact-fp32 MFMA, different summation order);
-bf16 path 1.5e-2 with the reference fed the same bf16-rounded operands (accumulation is fp32).
+Tolerances.  fp32 path: 2e-5 of max|ref| (exact-fp32 MFMA, different summation order).  bf16 path, the reference fed the SAME
+bf16-rounded operands (products of bf16 operands are exact in fp32; only the fp32 summation order and the output rounding differ):
+  * kernels that write fp32 (weight gradients, the heads' NCHW maps, statistics): 1e-4 of max|ref|; 2e-3 when the kernel applies a norm + ReLU
+    to its operand on the way (its fp32 fma result is rounded to bf16 where the float64 reference's is: an operand can land one bf16 ulp
+    away, rarely) -- `fp32_out_tol`;
+  * kernels that write bf16: per ELEMENT half a bf16 ulp of the reference value (2^-8 |ref|: the one rounding of the output) plus the same
+    1e-4 / 2e-3 of max|ref| for the summation order / the operand roundings -- `assert_close_bf16_out`.
+(Rounds 1 - 4 held every bf16 kernel to 1.5e-2 of max|ref|, which a dropped K step out of 80 or a missing halo column would have passed.)
 """
 import numpy as np
 import pytest
@@ -18,6 +24,24 @@ DTYPES = [torch.float32, torch.bfloat16]
 
 def tol(dtype):
     return 2e-5 if dtype == torch.float32 else 1.5e-2
+
+
+def fp32_out_tol(dtype, prologue=False):
+    """bound (relative to max|ref|) for a kernel whose OUTPUT is fp32"""
+    if dtype == torch.float32:
+        return 2e-5
+    return 2e-3 if prologue else 1e-4
+
+
+def assert_close_out(got, ref, dtype, prologue=False, what=""):
+    """a kernel whose output has the activation dtype: fp32 -> 2e-5 of max|ref|; bf16 -> per element 2^-8 |ref| + (1e-4 | 2e-3) max|ref|"""
+    if dtype == torch.float32:
+        return assert_close(got, ref, 2e-5, what)
+    den = max(ref.abs().max().item(), 1e-6)
+    bound = ref.abs() * 2.0 ** -8 + (2e-3 if prologue else 1e-4) * den
+    err = (got - ref).abs()
+    worst = (err - bound).max().item()
+    assert worst <= 0, "%s: an element is %.3e over its bound (max err %.3e, max|ref| %.3e)" % (what, worst, err.max().item(), den)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -121,7 +145,7 @@ def test_conv_forward(case, dtype, prologue):
     pack = K.pack_conv(w.float().to(DEV), 0, K.BF16 if dtype == torch.bfloat16 else K.F32)
     y, _ = K.conv_fwd(nhwc(x, dtype), pack, Cout, k, stride, bias=bias.float().to(DEV), norm=st, relu_in=True,
                       residual=nhwc(res, dtype))
-    assert_close(nchw(y), ref, tol(dtype), "conv fwd %s" % (case,))
+    assert_close_out(nchw(y), ref, dtype, prologue, "conv fwd %s" % (case,))
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 32, 64), (5, 8, 96), (3, 32, 32)])
@@ -137,12 +161,18 @@ def test_weight_stationary_conv_fragment_order_pack(B, H, W, form):
     bias = (rnd(128, seed=43) * 3).float().to(DEV)
     _, st = apply_nr(q(rnd(B, 128, H, W, seed=41), torch.bfloat16), B, 128, torch.bfloat16)
     outs = []
+    if form == "dgrad_nbsums":
+        # the data gradients with norm-backward sums stay on the patch kernel (their epilogue does not hide behind one wave per SIMD's
+        # MFMAs: DESIGN.md section 4): a fragment-order pack is refused there too, loudly
+        nby = nhwc(rnd(B, 128, H, W, seed=44), torch.bfloat16)
+        with pytest.raises(_lib.PwrError):
+            K.conv_fwd_stats(x, K.pack_conv(w, 1, K.BF16, frag=True), 128, 3, 1, nb_y=nby, nb_state=st)
+        y, part, _ = K.conv_fwd_stats(x, K.pack_conv(w, 1, K.BF16), 128, 3, 1, nb_y=nby, nb_state=st)
+        assert float(y.float().abs().max()) > 0 and not torch.isnan(part).any()
+        return
     for frag in (False, True):
-        if form == "dgrad_nbsums":
-            pack = K.pack_conv(w, 1, K.BF16, frag=frag)
-            nby = nhwc(rnd(B, 128, H, W, seed=44), torch.bfloat16)
-            y, part, _ = K.conv_fwd_stats(x, pack, 128, 3, 1, nb_y=nby, nb_state=st)
-            outs.append((y, part))
+        if False:
+            pass
         elif form == "norm_stats":
             y, part, _ = K.conv_fwd_stats(x, K.pack_conv(w, 0, K.BF16, frag=frag), 128, 3, 1, bias=bias, norm=st)
             outs.append((y, part))
@@ -165,7 +195,7 @@ def test_conv_forward_nchw_out(dtype, J, H, Cin):
     ref = F.conv2d(q(x, dtype), q(w, dtype), bias.float().double(), padding=1)
     pack = K.pack_conv(w.float().to(DEV), 0, K.BF16 if dtype == torch.bfloat16 else K.F32)
     _, yn = K.conv_fwd(nhwc(x, dtype), pack, J, 3, 1, bias=bias.float().to(DEV), nhwc_out=False, nchw_out=True)
-    assert_close(yn.double().cpu(), ref, tol(dtype) if dtype == torch.float32 else 5e-3, "conv nchw out")
+    assert_close(yn.double().cpu(), ref, fp32_out_tol(dtype), "conv nchw out")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -184,7 +214,7 @@ def test_conv_dgrad_stride1(case, dtype):
     F.conv2d(x, q(w, dtype), None, padding=k // 2).backward(q(dy, dtype))
     pack = K.pack_conv(w.float().to(DEV), 1, K.BF16 if dtype == torch.bfloat16 else K.F32)
     dx, _ = K.conv_fwd(nhwc(dy, dtype), pack, Cin, k, 1)
-    assert_close(nchw(dx), x.grad, tol(dtype), "dgrad %s" % (case,))
+    assert_close_out(nchw(dx), x.grad, dtype, False, "dgrad %s" % (case,))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -200,7 +230,7 @@ def test_conv_dgrad_stride2(dtype, B, H, Cin, Cout, k):
     F.conv2d(x, q(w, dtype), None, stride=2, padding=k // 2).backward(q(dy, dtype))
     pack = K.pack_conv(w.float().to(DEV), 2, K.BF16 if dtype == torch.bfloat16 else K.F32)
     dx, _ = K.conv_fwd(nhwc(dy, dtype), pack, Cin, k, 1, mode=1)
-    assert_close(nchw(dx), x.grad, tol(dtype), "dgrad stride 2")
+    assert_close_out(nchw(dx), x.grad, dtype, False, "dgrad stride 2")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -222,7 +252,7 @@ def test_conv_wgrad(case, dtype, prologue):
     w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin, w, None, stride=stride, padding=k // 2).backward(q(dy, dtype))
     dw = K.conv_wgrad(nhwc(x, dtype), nhwc(dy, dtype), Cout, k, stride, norm=st, relu_in=True, splits=splits)
-    assert_close(dw.double().cpu(), w.grad, tol(dtype), "wgrad %s" % (case,))
+    assert_close(dw.double().cpu(), w.grad, fp32_out_tol(dtype, prologue), "wgrad %s" % (case,))
 
 
 @pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 3, 80), (2, 64, 64, 128, 128, 3, 100), (4, 32, 32, 64, 64, 3, 40),
@@ -256,7 +286,7 @@ def test_wgrad3_lds_dma_path(case):
     assert float(new.abs().max()) > 0 and torch.equal(old, new), float((old - new).abs().max())
     w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(q(x, torch.bfloat16), w, None, padding=1).backward(q(dy, torch.bfloat16))
-    assert_close(new.double().cpu(), w.grad, 1.5e-2, "LDS-DMA wgrad %s" % (case,))
+    assert_close(new.double().cpu(), w.grad, 1e-4, "LDS-DMA wgrad %s" % (case,))
 
 
 @pytest.mark.parametrize("case", [(6, 64, 64, 64, 64, 37), (3, 20, 96, 64, 64, 24), (2, 32, 32, 128, 64, 8), (9, 32, 32, 64, 64, 5), (4, 128, 128, 64, 64, 40)])
@@ -280,7 +310,7 @@ def test_wgrad3_lds_dma_norm_in_lds(case):
     xin = q(torch.relu((xq - mean) * scale + shift), torch.bfloat16)
     w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin, w, None, padding=1).backward(q(dy, torch.bfloat16))
-    assert_close(outs[0].double().cpu(), w.grad, 1.5e-2, "LDS-DMA wgrad with the norm in LDS %s" % (case,))
+    assert_close(outs[0].double().cpu(), w.grad, 2e-3, "LDS-DMA wgrad with the norm in LDS %s" % (case,))
 
 
 @pytest.mark.parametrize("case", [(2, 128, 128, 128, 128, 16), (3, 64, 64, 64, 128, 7), (2, 24, 64, 128, 128, 5), (5, 64, 128, 128, 128, 37)])
@@ -302,7 +332,7 @@ def test_wgrad3_stride2(case, prologue):
     F.conv2d(xin, w, None, stride=2, padding=1).backward(q(dy, torch.bfloat16))
     xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
     dw = K.conv_wgrad(xd, dyd, Cout, 3, 2, norm=st, relu_in=True, splits=splits).clone()
-    assert_close(dw.double().cpu(), w.grad, 1.5e-2, "stride-2 three-tap wgrad %s" % (case,))
+    assert_close(dw.double().cpu(), w.grad, 2e-3 if prologue else 1e-4, "stride-2 three-tap wgrad %s" % (case,))
     for _ in range(3):
         assert torch.equal(dw, K.conv_wgrad(xd, dyd, Cout, 3, 2, norm=st, relu_in=True, splits=splits))
 
@@ -329,7 +359,7 @@ def test_wgrad3_64_pixel_steps(case, prologue):
     F.conv2d(xin, w, None, padding=1).backward(q(dy, torch.bfloat16))
     xd, dyd = nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16)
     dw = K.conv_wgrad(xd, dyd, cr, 3, 1, norm=st, relu_in=True, splits=splits).clone()
-    assert_close(dw.double().cpu(), w.grad[:cr], 1.5e-2, "three-tap wgrad, 64-pixel steps %s" % (case,))
+    assert_close(dw.double().cpu(), w.grad[:cr], 2e-3 if prologue else 1e-4, "three-tap wgrad, 64-pixel steps %s" % (case,))
     for _ in range(3):
         assert torch.equal(dw, K.conv_wgrad(xd, dyd, cr, 3, 1, norm=st, relu_in=True, splits=splits))
 
@@ -357,7 +387,7 @@ def test_grouped_weight_gradients_match_float64():
             refs.append(w.grad)
     dws = K.conv_wgrad_group(jobs)
     for i, (dw, ref) in enumerate(zip(dws, refs)):
-        assert_close(dw.double().cpu(), ref, 1.5e-2, "grouped wgrad job %d %s" % (i, tuple(ref.shape)))
+        assert_close(dw.double().cpu(), ref, 2e-3, "grouped wgrad job %d %s" % (i, tuple(ref.shape)))
     again = K.conv_wgrad_group(jobs)
     assert all(torch.equal(a, b_) for a, b_ in zip(dws, again))
 
@@ -374,14 +404,14 @@ def test_conv_wgrad_padded_dy(dtype):
     assert dyp.shape == (B, P, P, Jp) and float(dyp[..., J:].abs().max()) == 0.0
     assert_close(dyp[..., :J].double().cpu().permute(0, 3, 1, 2), q(g.float().double(), dtype), 1e-7, "transpose")
     dw = K.conv_wgrad(nhwc(x, dtype), dyp, J, 3, 1, splits=4)
-    assert_close(dw.double().cpu(), w.grad, tol(dtype), "wgrad padded")
+    assert_close(dw.double().cpu(), w.grad, fp32_out_tol(dtype), "wgrad padded")
     # and the matching data gradient: K dimension = Jp with a pack built from the J real channels
     wt = rnd(J, Cin, 3, 3, seed=9, scale=0.05)
     xg = torch.zeros(B, Cin, P, P, dtype=torch.float64, requires_grad=True)
     F.conv2d(xg, q(wt, dtype), None, padding=1).backward(q(g, dtype))
     pack = K.pack_conv(wt.float().to(DEV), 1, K.BF16 if dtype == torch.bfloat16 else K.F32)
     dx, _ = K.conv_fwd(dyp, pack, Cin, 3, 1)
-    assert_close(nchw(dx), xg.grad, tol(dtype), "dgrad padded")
+    assert_close_out(nchw(dx), xg.grad, dtype, False, "dgrad padded")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -534,12 +564,12 @@ def test_concat_nhwc_roundtrip_and_stage_input_conv(dtype, J, P):
     ref = F.conv2d(catq, wd, None)
     dt = K.BF16 if dtype == torch.bfloat16 else K.F32
     y, _ = K.conv_fwd(xc, K.pack_conv(w.float().to(DEV), 0, dt), Fo, 1, 1)
-    assert_close(nchw(y), ref.detach(), tol(dtype), "stage-in fwd")
+    assert_close_out(nchw(y), ref.detach(), dtype, False, "stage-in fwd")
     dy = rnd(B, Fo, P, P, seed=6)
     ref.backward(q(dy, dtype))
     dw = K.conv_wgrad(xc, nhwc(dy, dtype), Fo, 1, 1, splits=4, cin_real=2 * J + 1)
     assert dw.shape == (Fo, 2 * J + 1, 1, 1)
-    assert_close(dw.double().cpu(), wd.grad, tol(dtype), "stage-in wgrad")
+    assert_close(dw.double().cpu(), wd.grad, fp32_out_tol(dtype), "stage-in wgrad")
     dx, _ = K.conv_fwd(nhwc(dy, dtype), K.pack_conv(w.float().to(DEV), 1, dt), Cp, 1, 1)
     gp, gd = K.nhwc_to_cat_grad(dx, J)
     assert_close(gp.double().cpu(), catq.grad[:, :J], tol(dtype), "stage-in dgrad p")
@@ -903,7 +933,7 @@ def test_wgrad3_wave_specialised(case, prologue):
     if B <= 8:
         w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
         F.conv2d(xin, w, None, padding=1).backward(q(dy, torch.bfloat16))
-        assert_close(outs[0].double().cpu(), w.grad, 1.5e-2, "wave-specialised wgrad %s" % (case,))
+        assert_close(outs[0].double().cpu(), w.grad, 2e-3 if prologue else 1e-4, "wave-specialised wgrad %s" % (case,))
     if not prologue:
         ident = torch.zeros(4, B, Cin, device=DEV)
         ident[1:3] = 1.0                                    # [mean, rstd, scale, beta] = [0, 1, 1, 0]

@@ -179,3 +179,72 @@ def test_bf16_engine_gradient_against_the_reference_in_float64(golden_dir):
             "stages.1.conv": 0.74, "stages.1.hourglass": 0.66, "stages.1.plane_regression": 0.12, "stages.1.depth_regression": 0.05}
     for k in grp:
         assert grp[k] <= max(ceil.get(k, 0.0), 1.15 * grp_a[k] + 0.01), (k, grp[k], grp_a[k], ceil.get(k))
+
+
+def _oracle_bf16_storage(g, b, dtype):
+    """outputs and flat gradient of the fixture's functional from oracle/model_ref.py with storage="bf16", all other arithmetic in `dtype`"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import model_ref
+    cfg = model_ref.RefConfig(14, 2, 64, 128, 4, 3, "instance", "softmax")
+    keys = [str(k) for k in g["grad_keys"]]
+    sd = {k[3:]: (torch.from_numpy(g[k]).to(dtype) if g[k].dtype.kind == "f" else torch.from_numpy(g[k])) for k in g.files if k.startswith("sd_")}
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    cpu = {k: v.cpu().to(dtype) for k, v in b.items()}
+    res = model_ref.forward(sd, cfg, cpu["img"], cpu["label_img"], cpu["mask"], training=True, storage="bf16")
+    up = lambda a: torch.from_numpy(np.kron(a, np.ones((8, 8), dtype=np.float32))).to(dtype)
+    sum((u_ * torch.from_numpy(g["GU%d" % s_]).to(dtype)).sum() + (p_ * up(g["GH%d" % s_])).sum() + (D_ * up(g["GD%d" % s_])).sum()
+        for s_, (p_, D_, u_) in enumerate(res)).backward()
+    return res, torch.cat([sd[k].grad.flatten() for k in keys]).double()
+
+
+def _group_cos(a, b_, g):
+    out, o = {}, 0
+    acc = {}
+    for k, n in zip(g["grad_keys"], g["grad_numel"]):
+        k, n = str(k), int(n)
+        grp = "stem" if k.startswith("conv.") else ".".join(k.split(".")[:3])
+        d = acc.setdefault(grp, [0.0, 0.0, 0.0])
+        d[0] += float(torch.dot(a[o:o + n], b_[o:o + n])); d[1] += float(a[o:o + n].pow(2).sum()); d[2] += float(b_[o:o + n].pow(2).sum())
+        o += n
+    return {k: v[0] / max((v[1] * v[2]) ** 0.5, 1e-300) for k, v in acc.items()}, {k: (v[1] / max(v[2], 1e-300)) ** 0.5 for k, v in acc.items()}
+
+
+def test_bf16_engine_against_the_oracle_that_rounds_where_it_rounds(golden_dir):
+    """Every parameter group of the bf16 engine's gradient -- stem and hourglasses included -- against oracle/model_ref.py evaluated with
+    storage="bf16": the same op sequence on the CPU, rounded to bfloat16 at exactly the tensors (and gradient tensors) the engine stores in
+    bfloat16, pinned to the reference's float64 outputs by tests/test_oracle_golden.py.  Against float64 a bf16 implementation is 60 - 100 %
+    off below the last heads on this network (the test above), so float64 cannot tell a wrong hourglass / stem gradient kernel from a
+    right one.
+    What the round-4 review asked for -- the engine within 5 % of such an oracle in EVERY group -- turns out not to exist: the oracle
+    disagrees with ITSELF by ~50 % in those groups when nothing changes but the precision of its sums (fp32 against float64 accumulation,
+    same rounding points: measured here, every run).  A sum that lands on the other side of ONE bf16 rounding boundary is a whole-ulp
+    perturbation of a stored activation, and the InstanceNorm backwards amplify those like any other bf16 noise: two faithful bf16
+    implementations are two SAMPLES of that noise.  So the test is relative to that measured self-distance: per group the engine is no
+    further from the oracle than 1.25 x the oracle's two arithmetics are from each other (+ 0.02), its cosine to the oracle no more than
+    0.06 below theirs, its norm within 25 % -- where the noise is small that is tight (last stage's heads: 1.5 - 5 %), and everywhere a
+    gradient kernel that writes zeros (cosine 0), drops a ReLU mask or a residual path, or scales wrongly fails by a wide margin; and the
+    forward outputs agree to 4e-3 in uvd and 6e-4 in the heat maps.  (What pins the bf16 backward bit for bit is the known-answer digest of
+    220 train steps, tests/test_00_kat_gpu.py.)"""
+    g, m, b = _load(golden_dir)
+    m.set_precision("bf16").train()
+    res = m(b["img"], b["label_img"], b["mask"])
+    _functional(res, g).backward()
+    got = _flat_grad(m)
+    ref_res, ref = _oracle_bf16_storage(g, b, torch.float32)
+    _, ref64 = _oracle_bf16_storage(g, b, torch.float64)
+    for s_, ((p, D, uvd), (rp, rD, ruvd)) in enumerate(zip(res, ref_res)):
+        du = float((uvd.detach().cpu() - ruvd.detach()).abs().max())
+        dp = float((p.detach().cpu() - rp.detach()).abs().max())
+        print("stage %d, bf16 engine vs bf16-storage oracle: uvd %.2e, max |dp| %.2e" % (s_, du, dp))
+        assert du <= 4e-3 and dp <= 6e-4, (s_, du, dp)
+    self_err, eng_err = _group_errors(ref, ref64, g), _group_errors(got, ref64, g)
+    eng_err32 = _group_errors(got, ref, g)
+    (self_cos, _), (eng_cos, eng_ratio) = _group_cos(ref, ref64, g), _group_cos(got, ref64, g)
+    for k in self_err:
+        print("%-28s oracle fp32-sums vs float64-sums: rel L2 %.3f cos %.3f | engine vs oracle: rel L2 %.3f (%.3f vs the fp32-sums one) cos %.3f norm ratio %.3f"
+              % (k, self_err[k], self_cos[k], eng_err[k], eng_err32[k], eng_cos[k], eng_ratio[k]))
+    for k in self_err:
+        assert min(eng_err[k], eng_err32[k]) <= 1.25 * self_err[k] + 0.02, (k, eng_err[k], eng_err32[k], self_err[k])
+        assert eng_cos[k] >= self_cos[k] - 0.06 and 0.75 <= eng_ratio[k] <= 1.25, (k, eng_cos[k], self_cos[k], eng_ratio[k])
