@@ -11,7 +11,8 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
 dy = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
 w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
-pack = K.pack_conv(w, 0, K.BF16)
+pack = K.pack_conv(w, 0, K.BF16, frag=True)      # (the order the engine hands the heads' weights over in: csrc/conv_wstat.hip)
+pack_d = K.pack_conv(w, 1, K.BF16)                # (data gradients: the patch kernel, standard order)
 st = K.norm_stats(x, torch.ones(F_, device=dev), torch.zeros(F_, device=dev), mode=0)
 bias = torch.zeros(F_, device=dev)
 flops = 2.0 * B * P * P * F_ * F_ * 9
@@ -27,9 +28,12 @@ def timeit(fn):
 
 if which in ("all", "fwd"):
     t = timeit(lambda: K.conv_fwd(x, pack, F_, 3, 1, bias=bias, norm=st))
-    print(json.dumps({"kernel": "conv3x3_patch fwd (+NR prologue)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+    print(json.dumps({"kernel": "conv3x3_wstat fwd (+NR prologue)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
     t = timeit(lambda: K.conv_fwd(x, pack, F_, 3, 1))
-    print(json.dumps({"kernel": "conv3x3_patch (no prologue: dgrad form)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+    print(json.dumps({"kernel": "conv3x3_wstat (no prologue)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+    ys = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
+    t = timeit(lambda: K.conv_fwd_stats(x, pack_d, F_, 3, 1, nb_y=ys, nb_state=st))
+    print(json.dumps({"kernel": "conv3x3_patch data gradient + norm-backward sums (incl. the NaN fill of the test wrapper)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
 if which in ("all", "wgrad"):
     # the engine's split count for this layer (80) only, so that the rocprofv3 average of these launches is the number quoted in
     # DESIGN.md; `sweep` as third argument walks the split counts (round 2's 81 us "average" was over such a sweep)

@@ -1,4 +1,4 @@
-"""Summaries of tools/profile_r4.sh's (rounds 2, 3: profile_r2.sh, profile_r3.sh) rocprofv3 output -> small csv / json files for profiles/ (run on the GPU
+"""Summaries of tools/profile_r5.sh's (earlier rounds: profile_r2.sh ... profile_r4.sh) rocprofv3 output -> small csv / json files for profiles/ (run on the GPU
 box, right after).   python tools/profile_summary.py <raw dir> <out dir> [prefix = r3]"""
 import collections, csv, glob, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
@@ -16,7 +16,7 @@ def short(n):
 
 
 # 1. kernel statistics (step, isolated kernels, decoder, dist)
-for d in ("step", "roof", "iso", "iso24", "dec", "dist", "serial"):
+for d in ("step", "roof", "iso", "iso24", "dec", "dist", "serial", "trainsteps"):
     f = find(d, "kernel_stats.csv")
     if f:
         rows = list(csv.DictReader(open(f)))
@@ -60,6 +60,8 @@ def entry(table_f, table_w, match, grid, alg, label):
 
 
 entry(fe, wr, "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128")
+entry(fe, wr, "conv3x3_wstat_kernel<true, 0>", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_wstat_kernel<norm prologue, no statistics> B=32 64x64 128->128")
+entry(fe, wr, "conv3x3_wstat_kernel<false, 0>", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_wstat_kernel<plain> B=32 64x64 128->128")
 entry(fe, wr, "conv_wgrad3d_kernel<64, 128>", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3d_kernel<64,128> same shape")
 entry(fe, wr, "conv_wgrad3_kernel<2, 2, 1, 2", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3_kernel<2,2,1,2> same shape")
 entry(fe, wr, "wgrad_reduce_fast_kernel<9", None, None, "wgrad_reduce_fast_kernel<9,3> same shape (80 slabs)")
@@ -87,7 +89,7 @@ if f:
         dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     mm = {}
     for k, c in acc.items():
-        if "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1" in k or "conv_wgrad3_kernel<2, 2, 1, 2" in k or "conv_wgrad3d_kernel<64, 128>" in k or "conv_wgrad3w_kernel" in k:
+        if "conv3x3_wstat_kernel" in k or "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1" in k or "conv_wgrad3_kernel<2, 2, 1, 2" in k or "conv_wgrad3d_kernel<64, 128>" in k or "conv_wgrad3w_kernel" in k:
             m = {n: sum(v) / len(v) for n, v in c.items()}
             e = {"mean_ns_under_pmc": sum(dur[k]) / len(dur[k]), **m}
             if m.get("GRBM_GUI_ACTIVE", 0) > 0:
@@ -121,7 +123,7 @@ if f:
         lines.append("of the last %d RCCL kernels, %d overlap engine kernels of other queues" % (len(rc[-9:]), ov))
     open(os.path.join(dst, PRE + "_dist_overlap.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
-for nm in ("step_bench.json", "iso_bench.jsonl", "iso24_bench.jsonl", "dec_bench.jsonl", "dist_bench.json", "roofline_only.json", "serial_bench.json"):
+for nm in ("step_bench.json", "trainsteps.json", "iso_bench.jsonl", "iso24_bench.jsonl", "dec_bench.jsonl", "dist_bench.json", "roofline_only.json", "serial_bench.json"):
     p = os.path.join(src, nm)
     if os.path.exists(p):
         open(os.path.join(dst, PRE + "_" + nm), "w").write(open(p).read())
