@@ -39,6 +39,7 @@ namespace pwr {
 struct WstatArgs {
   ConvParams job[2];
   int njobs, wgs_per_job;
+  int tiles_q, tiles_r;      // tiles / wgs_per_job and the remainder: workgroup c of a job takes tiles [c q + min(c, r), ... + q + (c < r))
 };
 
 #ifdef PWR_DEBUG_BUILD
@@ -59,18 +60,23 @@ constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN 
 constexpr int NITP = 13;                 // staging vectors per thread: 204 pixels x 16 slots / 256 threads ...
 constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 208 pixels: the last round's 4 surplus pixels are written (never read), no branch
 // Staging schedule inside the K loops.  A SLOT is one v_mfma_f32_32x32x16_bf16 (288 per tile, 32 matrix-pipe cycles each, 24 of them open to
-// the vector ALU); a slot carries ONE micro-op (two independent vector instructions) of the next patch's staging: vector k's 21 micro-ops run
-// in slots S0(k) ... S0(k) + 20, its global load is issued LEAD slots earlier.
-constexpr int SLOTS = ITERS * 8, MICRO = 21, SLOT0 = 12, LEAD = 40;      // (slots are counted over both half-tile K loops: 2 x 36 x 4 MFMAs)
-__host__ __device__ constexpr int slot0(int k) { return SLOT0 + MICRO * k; }
-__host__ __device__ constexpr int load_slot(int k) { return slot0(k) - LEAD > k ? slot0(k) - LEAD : k; }
-// the vector whose load is issued in slot g, or -1 (closed form: a search loop here keeps the K loop from unrolling)
+// the vector ALU).  The next patch's staging is 13 vectors x 21 micro-ops (two independent vector instructions each) = 273 micro-ops; they
+// are spread evenly over the slots S_START ... 287 (one per slot, two in every tenth), a vector's global load goes out LEAD slots before its
+// first micro-op: the first 40 slots of a tile carry no staging arithmetic, so that even the first vector's load (issued in slot 0, from
+// L2 / the Infinity Cache) has ~1300 cycles to land (with the micro-ops starting in slot 12 every tile's first K loop stalled ~500 cycles).
+constexpr int SLOTS = ITERS * 8, MICRO = 21, NMICRO = NITP * MICRO, S_START = 40, S_LEN = SLOTS - S_START, LEAD = 40;
+// micro-ops [stage_lo(g), stage_lo(g + 1)) run in slot g
+__host__ __device__ constexpr int stage_lo(int g) { return g <= S_START ? 0 : ((g - S_START) * NMICRO + S_LEN - 1) / S_LEN; }
+__host__ __device__ constexpr int slot_of_micro(int m) { return S_START + m * S_LEN / NMICRO; }
+__host__ __device__ constexpr int load_slot(int k) { return slot_of_micro(MICRO * k) - LEAD; }
+// the vector whose load is issued in slot g, or -1
 __host__ __device__ constexpr int load_of(int g) {
-  const int kk = (g + LEAD - SLOT0) / MICRO;
-  return (g + LEAD - SLOT0 >= 0 && (g + LEAD - SLOT0) % MICRO == 0 && kk < NITP && load_slot(kk) == g) ? kk : ((g < NITP && load_slot(g) == g) ? g : -1);
+  for (int k = 0; k < NITP; ++k)
+    if (load_slot(k) == g) return k;
+  return -1;
 }
-static_assert(slot0(NITP) <= SLOTS, "staging schedule");
-static_assert(load_of(0) == 0 && load_of(1) == 1 && load_of(load_slot(2)) == 2 && load_of(load_slot(12)) == 12 && load_of(load_slot(5) + 1) == -1, "staging schedule");
+static_assert(stage_lo(SLOTS) == NMICRO && stage_lo(S_START + 1) >= 1 && stage_lo(S_START + 1) <= 2 && slot_of_micro(NMICRO - 1) == SLOTS - 1, "staging schedule");
+static_assert(load_slot(0) == 0 && load_of(0) == 0 && load_of(load_slot(12)) == 12 && load_of(1) == -1, "staging schedule");
 }  // namespace wst
 
 // NRM: the input carries a pending norm + ReLU (forward); KIND: 0 no statistics, 1 forward statistics, 2 norm-backward sums (data gradient)
@@ -101,8 +107,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const int NW = a.wgs_per_job, nx = 8 / a.njobs;              // workgroups of one job sit on `nx` XCD labels (blockIdx % 8: speed only)
     const int q = NW / nx, r = NW % nx, xl = wgj % nx;
     const int c = (xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q) + wgj / nx;
-    t = (int)((long long)c * ntiles / NW);
-    t_end = (int)((long long)(c + 1) * ntiles / NW);
+    t = c * a.tiles_q + (c < a.tiles_r ? c : a.tiles_r);          // (no 64-bit division in the prologue)
+    t_end = t + a.tiles_q + (c < a.tiles_r ? 1 : 0);
   }
   if (t >= t_end) return;
   // (debug build: s_memtime stamps of thread 0, 32 x int64 per workgroup: 0 start, 1 first patch staged, then per tile: half A done, half B
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
       for (int sl = 0; sl < ITERS * 4; ++sl) {
-        // a slot: the MFMA, the read that refills its fragment eight slots ahead, this slot's share of the staging (wst::slot0 / load_of) and
+        // a slot: the MFMA, the read that refills its fragment eight slots ahead, this slot's share of the staging (wst::stage_lo / load_of) and
         // of the other half's epilogue, a full scheduling barrier: the emitted order IS this order
         const int g = half * ITERS * 4 + sl, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
         if (WST_DBG & 8) asm volatile("" : "+v"(pf[g & 7]));
@@ -487,8 +493,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         else acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g & 7], acc[row], 0, 0, 0);
         if (g + 8 < SLOTS && !(WST_DBG & 4)) frag_load1(g + 8, pb);
         if (load_of(g) >= 0 && !(WST_DBG & 1)) stage_load(load_of(g), q);
-        if (g >= SLOT0 && g < slot0(NITP) && !(WST_DBG & 1)) {
-          const int k = (g - SLOT0) / MICRO, u = (g - SLOT0) - k * MICRO;
+#pragma unroll
+        for (int mi = stage_lo(g); mi < stage_lo(g + 1) && !(WST_DBG & 1); ++mi) {
+          const int k = mi / MICRO, u = mi - k * MICRO;
           stage_micro(k, u, q, nb);
           // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
           // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
@@ -574,6 +581,7 @@ int launch_conv_wstat(const ConvParams& pa, const ConvParams* pb, hipStream_t s)
   int per = ncu / a.njobs;
   if (per > tiles) per = tiles;
   a.wgs_per_job = per;
+  a.tiles_q = tiles / per; a.tiles_r = tiles % per;
   const int kind = pa.st_partial ? 1 : (pa.nb_partial ? 2 : 0);
   dim3 grid(per * a.njobs);
   if (pa.in_norm) launch_kind<true>(a, kind, grid, s);
