@@ -480,17 +480,19 @@ def main():
         out["step_mfma_frac"] = step_flops / (dt / args.steps) / (peak * 1e12)
         if True:   # (kept as a block: the roofline probes run on every rank-0 report)
             t, flops = time_head_conv(dev, B_PER_GPU, precision=args.precision)
-            # HBM bytes per launch are NOT measured in this run (PMC collection needs rocprofv3 passes of its own: tools/profile_r4.sh), so
+            # HBM bytes per launch are NOT measured in this run (PMC collection needs rocprofv3 passes of its own: tools/profile_r5.sh), so
             # `traffic` is null here; the counter result of the committed profile of the same kernel and shape is quoted beside it
             traffic_profile = None
-            for tj in ("r4_traffic.json", "r3_traffic.json"):
-                fp = os.path.join(ROOT, "profiles", tj)
-                if os.path.exists(fp) and args.precision == "bf16":
-                    v = json.load(open(fp)).get("conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128", {}).get("hbm_bytes_corrected")
-                    if v is not None:
-                        traffic_profile = {"hbm_bytes_per_launch": v, "source": "profiles/" + tj, "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another lease"}
-                        break
-            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3 128->128 @64x64, B=%d (+fused norm/ReLU), %s operands" % (B_PER_GPU, args.precision),
+            tkey = "conv3x3_wstat_kernel<norm prologue, no statistics> B=32 64x64 128->128"
+            fp = os.path.join(ROOT, "profiles", "r5_traffic.json")
+            if os.path.exists(fp) and args.precision == "bf16":
+                v = json.load(open(fp)).get(tkey, {})
+                if v.get("hbm_bytes_corrected") is not None:
+                    traffic_profile = {"hbm_bytes_per_launch": v["hbm_bytes_corrected"], "algorithmic_bytes": v.get("algorithmic_bytes"),
+                                       "source": "profiles/r5_traffic.json", "kernel": tkey,
+                                       "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on another lease"}
+            out["roofline"] = {"bound": "mfma", "kernel": "%s: conv3x3 128->128 @64x64, B=%d (+fused norm/ReLU), %s operands"
+                                                          % ("conv3x3_wstat_kernel<true,0>" if args.precision == "bf16" else "conv_fwd_kernel<float>", B_PER_GPU, args.precision),
                                "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                                "frac": flops / t / 1e12 / peak, "traffic": None, "traffic_profile": traffic_profile, "us_per_launch": t * 1e6,
                                "flop_per_launch": flops}
@@ -498,7 +500,7 @@ def main():
                 out["roofline"]["vendor_gemm_same_shape"] = vendor_gemm_yardstick(dev, B_PER_GPU)
             td, nb = time_decoder(dev, B_PER_GPU)
             dprofile = None
-            for tj in ("r4_traffic.json", "r3_traffic.json"):
+            for tj in ("r5_traffic.json", "r4_traffic.json"):
                 fp = os.path.join(ROOT, "profiles", tj)
                 if os.path.exists(fp) and dprofile is None:
                     v = json.load(open(fp)).get("decode_fwd B=%d J=%d P=%d" % (B_PER_GPU, J, P), {}).get("hbm_bytes_corrected")
@@ -508,7 +510,7 @@ def main():
                                        "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "traffic_profile": dprofile,
                                        "us_per_launch": td * 1e6,
                                        "note": "23 MB per launch: launch / latency bound at this shape (the rocprofv3 average of the same probe is ~1 us longer than this "
-                                               "HIP-event figure: profiles/r4_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r4_dec_bench.jsonl)"}
+                                               "HIP-event figure: profiles/r5_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r5_dec_bench.jsonl)"}
         if world == 1 and args.with_pipeline and native:
             model.train()
             out["pipeline"] = pipeline_block(model, trainer, dev, max(10, min(args.steps, 100)))

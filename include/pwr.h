@@ -77,7 +77,13 @@ size_t pwr_conv_pack_bytes(int cout, int cin, int ksize, int kind, int dtype);
 
 /* descs_dev: device array of n_desc records {int64 src_off (floats into flat_params), int64 dst_off (bytes
  * into packs), int32 Cout, Cin, ksize, kind, rows_pad, KCH, dtype, pad}.  rows_pad = pwr_conv_out_pad(rows),
- * KCH = ceil(kdim / (dtype==PWR_BF16 ? 32 : 16)) with rows/kdim = (Cout,Cin) for kind 0, (Cin,Cout) else. */
+ * KCH = ceil(kdim / (dtype==PWR_BF16 ? 32 : 16)) with rows/kdim = (Cout,Cin) for kind 0, (Cin,Cout) else.
+ * The last int32 of a record (`pad` until round 5) is the pack's ORDER: 0 = the standard [tap][kch][row][32 bf16] image every conv
+ * kernel reads; 1 = the fragment order of the weight-stationary 128 -> 128 3x3 bf16 conv ([tap][kch][32-row group][k half][lane][8 bf16],
+ * kind 0, bf16, Cout = Cin = 128, ksize 3 only -- same bytes, another permutation).  A fragment-order pack is handed to pwr_conv_fwd /
+ * pwr_conv_fwd_stats / pwr_conv_fwd_pair with BIT 0 OF ITS ADDRESS SET (packs are 256-byte aligned, the bit is free): the launch
+ * strips it, takes the weight-stationary kernel and returns PWR_EINVAL if the shape is not one that kernel takes (H % 4, W % 32,
+ * stride 1, NHWC output, no residual, >= 16 tiles) -- it never reads a pack in the wrong order. */
 int pwr_pack_weights(const float* flat_params, void* packs, const void* descs_dev, int n_desc, void* stream);
 
 /* y = conv(NR(x)) + bias (+ residual).  NR(x) = (x - mean[b,c]) * scale[b,c] + beta[b,c], then ReLU if relu_in;
