@@ -216,6 +216,7 @@ void set_debug_delay(int d);
 // conv_wstat.hip (round 5): the 128 -> 128 3x3 stride-1 bf16 conv with the weights stationary in registers, persistent workgroups;
 // one job (b == nullptr) or two jobs of one geometry per launch
 bool conv_wstat_applicable(const ConvParams& p, int dtype);
+bool conv_wstat_narrow_applicable(const ConvParams& p, int dtype);   // 128 -> Cout <= 32, fp32 NCHW output (the heads' last conv)
 bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int dtype);   // would a plain conv of this shape run on it?
 bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype);
 int launch_conv_wstat(const ConvParams& a, const ConvParams* b, hipStream_t s);

@@ -949,7 +949,7 @@ int launch_conv_patch(const ConvParams& p, int dtype, hipStream_t s) {
     return launch_patch_1x1<32>(p, s);
   }
   if (small_map(p, dtype)) return dtype == PWR_BF16 ? launch_patch_small<bf16_t>(p, s) : launch_patch_small<float>(p, s);
-  if (conv_wstat_applicable(p, dtype)) return launch_conv_wstat(p, nullptr, s);
+  if (conv_wstat_applicable(p, dtype) || conv_wstat_narrow_applicable(p, dtype)) return launch_conv_wstat(p, nullptr, s);
   if (p.w_frag) return PWR_EINVAL;                   // a fragment-order pack and a launch that is not conv_wstat.hip's
   return dtype == PWR_BF16 ? launch_patch_t<bf16_t>(p, s) : launch_patch_t<float>(p, s);
 }

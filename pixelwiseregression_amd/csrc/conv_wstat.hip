@@ -77,16 +77,23 @@ __host__ __device__ constexpr int load_of(int g) {
 }
 static_assert(stage_lo(SLOTS) == NMICRO && stage_lo(S_START + 1) >= 1 && stage_lo(S_START + 1) <= 2 && slot_of_micro(NMICRO - 1) == SLOTS - 1, "staging schedule");
 static_assert(load_slot(0) == 0 && load_of(0) == 0 && load_of(load_slot(12)) == 12 && load_of(1) == -1, "staging schedule");
+// the narrow form (KIND 3): 72 slots per tile, the same 273 micro-ops spread evenly over all of them
+constexpr int NSLOTS = ITERS * 2;
+__host__ __device__ constexpr int nar_lo(int g) { return g * NMICRO / NSLOTS; }
+static_assert(nar_lo(0) == 0 && nar_lo(NSLOTS) == NMICRO, "staging schedule of the narrow form");
 }  // namespace wst
 
-// NRM: the input carries a pending norm + ReLU (forward); KIND: 0 no statistics, 1 forward statistics, 2 norm-backward sums (data gradient)
+// NRM: the input carries a pending norm + ReLU (forward); KIND: 0 no statistics, 1 forward statistics, 2 norm-backward sums (data gradient),
+// 3 the NARROW form: Cout <= 32 (the heads' last conv, 128 -> J, model.py:64 / :113), fp32 NCHW output -- see the block behind the prologue
 template <bool NRM, int KIND>
 __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a) {
   using namespace wst;
   typedef bf16_t T;
   typedef bf16x8 V;
   constexpr int EP = 8;
+  constexpr bool NAR = KIND == 3;
   __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
+  __shared__ float sbias[NAR ? 32 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = 32-channel group
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   V wreg[2 * ITERS];
   {
     const int row = lane & 31;
-    const int ch = 32 * wn + 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3);
+    const int ch = NAR ? row : 32 * wn + 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3);    // (narrow: every wave holds the same 32 rows)
     const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
     // (fragment-order pack, conv_mfma.hip PackDesc::order 1: fragment q of wave wn is the contiguous KiB [q / 2][wn][q % 2][lane]; the standard
     // pack serves too -- 32 pieces of 32 B per wave instruction, a ~10 000-cycle prologue)
@@ -262,6 +269,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   for (int k = 0; k < NITP; ++k)
 #pragma unroll
     for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q0, smem);
+  if constexpr (NAR) {
+    if (tid < 32) sbias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+  }
   stamp(26);
   __syncthreads();
   stamp(27);
@@ -276,6 +286,74 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   }
   stamp(1);
   int tile_no = 0;
+  V pf[8];                                                       // B fragments: a ring of eight
+
+  if constexpr (NAR) {
+    // ---- the NARROW form: all four waves hold the SAME 32 output channels (Cout <= 32, pack padded to 32 rows; MFMA row = channel) and
+    // split the tile's four rows: wave w accumulates tile row w, 72 slots per tile, one accumulator block.  conv_patch.hip ran this shape
+    // (the heads' 128 -> J conv) with a barrier per 32-channel K step around TWO MFMAs per wave: 29.6 us for a quarter of the dominant
+    // conv's FLOPs.  Here the K loop has no barrier and the staging of the next patch is what bounds it (3.8 micro-ops per MFMA), so the
+    // staging pipeline is TWO tiles deep: the global load of vector k of tile n + 2 is issued into the registers of vector k of tile n + 1
+    // the moment that vector's last micro-op has written it to LDS -- a whole tile (~2.5 k cycles) ahead of its use, no second register set.
+    // Same K order and operands as conv_patch.hip's <4, 1, 1, 1> form (tap-major, two 16-channel halves per K step) => bit-identical output.
+    const char* fb = smem + pc * PITCH + hh * 16 + wn * (PW * PITCH);
+    auto frag_load_n = [&](const int g, const char* base) __attribute__((always_inline)) {
+      const int it = g >> 1, ss = g & 1, tap = it / KCH, kch = it - tap * KCH, ky = tap / 3, kx = tap - ky * 3;
+      pf[g & 7] = *reinterpret_cast<const V*>(base + (ky * PW + kx) * PITCH + (4 * kch + 2 * ss) * 16);
+    };
+    // accumulator register r of lane (col, h) = channel (r % 4) + 8 (r / 4) + 4 h of pixel (row wn, col); the bias waits in LDS (sixteen
+    // vector registers for it were sixteen too many in the prologue, beside 288 weights and 13 vectors in flight)
+    TileCo nx1 = (t + 1 < t_end) ? tile_next(cur) : cur;
+    StageCo q1 = stage_co(nx1);
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) stage_load(k, q1);              // tile 1's vectors (tile 0's have been written to LDS above)
+    f32x16 accn;
+    int buf = 0;
+    for (; t < t_end; ++t) {
+      const TileCo nx2 = (t + 2 < t_end) ? tile_next(nx1) : nx1;   // (the last tiles re-stage themselves: branch-free K loop)
+      const StageCo q2 = stage_co(nx2);
+      const char* pb = fb + buf * PATCH_BYTES;
+      char* nb = smem + (buf ^ 1) * PATCH_BYTES;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) frag_load_n(g, pb);
+      stage_norm_load(nx1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sl = 0; sl < NSLOTS; ++sl) {
+        if (WST_DBG & 8) asm volatile("" : "+v"(pf[sl & 7]));
+        else if (sl == 0) accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl & 7], f32x16{}, 0, 0, 0);
+        else accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl & 7], accn, 0, 0, 0);
+        if (sl + 8 < NSLOTS && !(WST_DBG & 4)) frag_load_n(sl + 8, pb);
+#pragma unroll
+        for (int mi = nar_lo(sl); mi < nar_lo(sl + 1) && !(WST_DBG & 1); ++mi) {
+          const int k = mi / MICRO, u = mi - k * MICRO;
+          stage_micro(k, u, q1, nb);
+          if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
+          if (u == MICRO - 1) stage_load(k, q2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stamp(2 + 3 * tile_no);
+      {
+        float* yo = p.y_nchw + ((size_t)cur.b * p.Cout * H + (size_t)(cur.y0 + wn)) * W + cur.x0 + pc;
+        float ov[16];             // (all sixteen bias reads in flight at once; read inside the predicated stores they were sixteen LDS round trips)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = accn[r] + sbias[(r & 3) + 8 * (r >> 2) + 4 * hh];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int chn = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (chn < p.Cout) yo[(size_t)chn * HW] = ov[r];
+        }
+      }
+      stamp(3 + 3 * tile_no);
+      __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loop
+      stamp(4 + 3 * tile_no); ++tile_no;
+      cur = nx1; nx1 = nx2; q1 = q2;
+      buf ^= 1;
+    }
+    stamp(31);
+    return;
+  }
 
   f32x16 acc[4];                                                 // one per tile row (32 pixels x this wave's 32 channels)
   const char* fbase = smem + pc * PITCH + hh * 16;               // per-lane part of every B-fragment address (+ buffer, tap, K step: constants)
@@ -286,7 +364,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // A SLOT is one MFMA (32 matrix-pipe cycles): slot sl = 4 * step + 2 * ss + blk of a half multiplies the 16-channel half ss of K step `step`
   // into tile row 2 * half + blk.  Fragments: a ring of eight; the fragment of slot g + 8 is read into the registers of slot g's right
   // behind the MFMA that consumed them (256 matrix-pipe cycles ahead of its own use).
-  V pf[8];
   auto frag_load1 = [&](const int g, const char* base) __attribute__((always_inline)) {      // g = 144 * half + slot
     const int half = g / (ITERS * 4), sl = g - half * ITERS * 4, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
     const int tap = it / KCH, kch = it - tap * KCH;
@@ -560,10 +637,19 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
          !(p.st_partial && p.nb_partial) && !(p.nb_partial && (p.in_norm || p.bias || !PWR_DBG_ENV("PWR_WSTAT_NB", 0))) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
 }
 
+// the narrow form (KIND 3): 128 -> Cout <= 32 channels, fp32 NCHW output only (the heads' last conv)
+bool conv_wstat_narrow_applicable(const ConvParams& p, int dtype) {
+  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) && (PWR_DBG_ENV("PWR_WSTAT_NARROW", 1) != 0);
+  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout <= 32 &&
+         p.CoutPad == 32 && p.W % 32 == 0 && p.H % 4 == 0 && p.y == nullptr && p.y_nchw != nullptr && !p.residual && !p.w_frag &&
+         (!p.in_norm || p.relu_in) && !p.st_partial && !p.nb_partial && p.B * (p.H / 4) * (p.W / 32) >= PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
+}
+
 template <bool NRM>
 static void launch_kind(const WstatArgs& a, int kind, dim3 grid, hipStream_t s) {
   if (kind == 0) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 0>), grid, dim3(256), 0, s, a);
   else if (kind == 1) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 1>), grid, dim3(256), 0, s, a);
+  else if (kind == 3) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 3>), grid, dim3(256), 0, s, a);
   else if constexpr (!NRM) hipLaunchKernelGGL((conv3x3_wstat_kernel<false, 2>), grid, dim3(256), 0, s, a);
 }
 
@@ -582,7 +668,7 @@ int launch_conv_wstat(const ConvParams& pa, const ConvParams* pb, hipStream_t s)
   if (per > tiles) per = tiles;
   a.wgs_per_job = per;
   a.tiles_q = tiles / per; a.tiles_r = tiles % per;
-  const int kind = pa.st_partial ? 1 : (pa.nb_partial ? 2 : 0);
+  const int kind = pa.y_nchw ? 3 : (pa.st_partial ? 1 : (pa.nb_partial ? 2 : 0));
   dim3 grid(per * a.njobs);
   if (pa.in_norm) launch_kind<true>(a, kind, grid, s);
   else launch_kind<false>(a, kind, grid, s);

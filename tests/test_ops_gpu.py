@@ -198,6 +198,33 @@ def test_conv_forward_nchw_out(dtype, J, H, Cin):
     assert_close(yn.double().cpu(), ref, fp32_out_tol(dtype), "conv nchw out")
 
 
+@pytest.mark.parametrize("J", [14, 21, 1, 32])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (5, 36, 96), (1, 64, 32), (9, 8, 32)])
+@pytest.mark.parametrize("form", ["plain", "norm"])
+def test_narrow_weight_stationary_conv(J, B, H, W, form):
+    """conv_wstat.hip KIND 3: the heads' last conv (128 -> J <= 32, fp32 NCHW out, model.py:64 / :113) as a persistent weight-stationary
+    kernel whose four waves split the tile's rows.  Ragged tile counts per workgroup (B * H / 4 * W / 32 = 32 ... 135 tiles, not a
+    multiple of the workgroup count; 18 tiles: one tile per workgroup), J odd / 1 / the full 32, with and without the norm + ReLU prologue
+    and the bias, against float64."""
+    from pixelwiseregression_amd import kernels as K
+    x, w, bias = rnd(B, 128, H, W, seed=1), rnd(J, 128, 3, 3, seed=2, scale=0.05), rnd(J, seed=3)
+    xq = q(x, torch.bfloat16)
+    st = None
+    if form == "norm":
+        g = torch.Generator().manual_seed(7)
+        mean, rstd = torch.randn(B, 128, generator=g) * 0.2, torch.rand(B, 128, generator=g) + 0.5
+        gam, bet = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.2
+        st = torch.stack([mean, rstd, rstd * gam[None], bet[None].expand(B, 128)]).float().contiguous().to(DEV)
+        # the engine's operand: fmaf(x - mean, rstd * gamma, beta), ReLU, ONE rounding to bf16 (conv_wstat.hip stage_micro)
+        xn = torch.relu((xq - mean.double()[:, :, None, None]) * (rstd * gam[None]).float().double()[:, :, None, None] + bet.double()[None, :, None, None])
+        xq = q(xn.float(), torch.bfloat16)
+    ref = F.conv2d(xq, q(w, torch.bfloat16), bias.float().double(), padding=1)
+    pack = K.pack_conv(w.float().to(DEV), 0, K.BF16)
+    _, yn = K.conv_fwd(nhwc(x, torch.bfloat16), pack, J, 3, 1, bias=bias.float().to(DEV), norm=st, nhwc_out=False, nchw_out=True)
+    # (norm form: the fp32 fma rounds once where float64 does not, so a few operands land on the neighbouring bf16: 2^-9 of an operand)
+    assert_close(yn.double().cpu(), ref, fp32_out_tol(torch.bfloat16, form == "norm"), "narrow conv %s" % form)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 3), (2, 64, 64, 128, 128, 3), (3, 5, 7, 64, 128, 3),
                                   (2, 16, 16, 128, 64, 1), (1, 4, 4, 16, 16, 3), (2, 32, 32, 128, 16, 3),

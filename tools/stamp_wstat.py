@@ -8,10 +8,11 @@ dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 STATS = len(sys.argv) > 2 and sys.argv[2] == "stats"
 NB = len(sys.argv) > 2 and sys.argv[2] == "nb"
+NAR = len(sys.argv) > 2 and sys.argv[2] == "nar"     # the narrow form (128 -> 14, fp32 NCHW): "half A" = the tile's K loop, "half B" = its stores
 P, F_ = 64, 128
 x = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
-w = torch.randn(F_, F_, 3, 3, device=dev) * 0.03
-pack = K.pack_conv(w, 1 if NB else 0, K.BF16, frag="std" not in sys.argv)
+w = torch.randn(14 if NAR else F_, F_, 3, 3, device=dev) * 0.03
+pack = K.pack_conv(w, 1 if NB else 0, K.BF16, frag="std" not in sys.argv and not NAR)
 nby = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
 st = K.norm_stats(x, torch.ones(F_, device=dev), torch.zeros(F_, device=dev), mode=0)
 bias = torch.zeros(F_, device=dev)
@@ -19,6 +20,8 @@ nwg = 256
 stamps = torch.zeros(nwg, 32, dtype=torch.int64, device=dev)
 l = _lib.lib()
 def conv():
+    if NAR:
+        return K.conv_fwd(x, pack, 14, 3, 1, bias=bias[:14].contiguous(), norm=st, nhwc_out=False, nchw_out=True)
     if NB:
         return K.conv_fwd_stats(x, pack, F_, 3, 1, nb_y=nby, nb_state=st)
     if STATS:
