@@ -54,6 +54,12 @@ long long* wstat_stamps();        // conv_patch.hip: the buffer of pwr_debug_set
 #ifndef WST_AGPR_STEPS
 #define WST_AGPR_STEPS 32
 #endif
+#ifndef WST_RING
+#define WST_RING 6
+#endif
+#ifndef WST_TAPS_AHEAD
+#define WST_TAPS_AHEAD(NRM, KIND) (((KIND) == 2 || ((KIND) == 1 && (NRM))) ? 9 : 3)
+#endif
 
 namespace wst {
 constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN * 2 + 16;
@@ -248,22 +254,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   for (int k = 0; k < NITP; ++k) stage_load(k, q0);
   __builtin_amdgcn_sched_barrier(0);
   stamp(25);
+  // (the bias goes out BEFORE the weights: vmcnt counts in order, a wait for anything issued behind the weights is a wait for all of them)
+  const int n = 32 * wn + 16 * hh;
+  float bias_r[16];            // (a data gradient has no bias: KIND 2 spends these sixteen registers on the norm state instead)
+  if constexpr (KIND != 2) {
+    const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias_r[e] = bp[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias_r[e] = 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
   // ---- the weights of this wave: A fragments of all 72 K steps of 16 channels (lane = row + 32 h: weight row `row`, channels 8 h .. 8 h + 7
   // of the step).  MFMA row -> output channel: the accumulator of lane (col, h) holds rows (r % 4) + 8 (r / 4) + 4 h, r = 0 .. 15; with
   // channel = 16 (row / 4 % 2) + 4 (row / 8) + row % 4 those are the 16 CONSECUTIVE channels 16 h .. 16 h + 15 of the wave's 32: two
   // 16-byte NHWC stores per pixel straight from registers.
+  // Only taps 0 .. 2 are requested here.  vmcnt counts in order, so the first wait for anything issued behind the weights is a wait for ALL
+  // weights requested so far: with all 288 KiB per CU requested up front, a workgroup sat ~5 k cycles between its first patch and its first
+  // MFMA while they streamed in from L2.  Taps 3 .. 8 are requested from inside the first tile's first K loop, three taps (48 MFMA slots)
+  // ahead of their use (load_tap below): the first tile computes while its weights arrive.
   V wreg[2 * ITERS];
+  unsigned wvoff;                                                // per-lane byte offset of the lane's 16 bytes inside a fragment
+  int qs0, qs1;                                                  // byte strides of q / 2 and q % 2
   {
     const int row = lane & 31;
     const int ch = NAR ? row : 32 * wn + 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3);    // (narrow: every wave holds the same 32 rows)
-    const T* __restrict__ w = reinterpret_cast<const T*>(p.w);
     // (fragment-order pack, conv_mfma.hip PackDesc::order 1: fragment q of wave wn is the contiguous KiB [q / 2][wn][q % 2][lane]; the standard
     // pack serves too -- 32 pieces of 32 B per wave instruction, a ~10 000-cycle prologue)
-    const T* __restrict__ wl = p.w_frag ? w + ((size_t)wn * 128 + lane) * 8 : w + (size_t)ch * 32 + hh * 8;
-    const int qs0 = p.w_frag ? 512 * 8 : p.CoutPad * 32, qs1 = p.w_frag ? 64 * 8 : 16;       // element strides of q / 2 and q % 2
-#pragma unroll
-    for (int q = 0; q < 2 * ITERS; ++q) wreg[q] = *reinterpret_cast<const V*>(wl + (size_t)(q >> 1) * qs0 + (q & 1) * qs1);
+    wvoff = p.w_frag ? (unsigned)(wn * 128 + lane) * 16u : (unsigned)(ch * 32 + hh * 8) * 2u;
+    qs0 = p.w_frag ? 512 * 16 : p.CoutPad * 64; qs1 = p.w_frag ? 64 * 16 : 32;
   }
+  constexpr int TAPS_AHEAD = WST_TAPS_AHEAD(NRM, KIND);
+  // (`z`: an opaque zero.  With addresses the compiler can prove loop-invariant it computes all 48 in front of the tile loop and keeps them
+  // in 96 registers that do not exist)
+  auto load_tap = [&](const int tap, const int z) __attribute__((always_inline)) {
+    const char* wb = reinterpret_cast<const char*>(p.w) + z;
+#pragma unroll
+    for (int q = 8 * tap; q < 8 * tap + 8; ++q) wreg[q] = *reinterpret_cast<const V*>(wb + ((q >> 1) * qs0 + (q & 1) * qs1) + wvoff);
+  };
+#pragma unroll
+  for (int tap = 0; tap < TAPS_AHEAD; ++tap) load_tap(tap, 0);
+  if (TAPS_AHEAD < 9) load_tap(8, 0);      // (tap 8 lives in VGPRs; requested from inside the loop it cost the statistics form 27 spilled registers)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < NITP; ++k)
@@ -272,21 +304,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   if constexpr (NAR) {
     if (tid < 32) sbias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
   }
+  if constexpr (KIND != 2) {      // (no bias: zeros.  Here, behind the staging arithmetic, so that the wait for the loaded values stands here too)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { asm volatile("" : "+v"(bias_r[e])); bias_r[e] = p.bias ? bias_r[e] : 0.f; }
+  }
   stamp(26);
   __syncthreads();
   stamp(27);
-  {
-    // Register files: the vector ALU only reaches the 256 architectural VGPRs, the MFMA reads its operands from either file.  Left alone the
-    // allocator puts most weights into VGPRs, runs out of them where the staging arithmetic lives and shuffles weights through AGPR spill
-    // slots (4 v_accvgpr_mov per MFMA operand, in the middle of the K loop).  So: the weights of taps 0 .. 7 are DEFINED in AGPRs (all 256
-    // of them) and stay there; tap 8, the ACCUMULATORS (the file is built with -amdgpu-mfma-vgpr-form: the epilogue's vector instructions
-    // read them directly, no v_accvgpr_read per value) and everything else the vector ALU touches share the VGPRs.
+  // Register files: the vector ALU only reaches the 256 architectural VGPRs, the MFMA reads its operands from either file.  Left alone the
+  // allocator puts most weights into VGPRs, runs out of them where the staging arithmetic lives and shuffles weights through AGPR spill
+  // slots (4 v_accvgpr_mov per MFMA operand, in the middle of the K loop).  So: the weights of taps 0 .. 7 are DEFINED in AGPRs (all 256
+  // of them: an empty asm with a "+a" operand) and stay there; tap 8, the ACCUMULATORS (the file is built with -amdgpu-mfma-vgpr-form: the
+  // epilogue's vector instructions read them directly, no v_accvgpr_read per value) and everything else the vector ALU touches share the VGPRs.
+  // WHERE those empty asms stand is where a wave first waits for the weights: in front of each tap's first MFMA of a tile's first K loop,
+  // not in front of the loop -- the first tile starts on tap 0 while taps 1 .. 8 are still streaming in from L2 (288 KiB per CU; waiting
+  // for all of it before the first MFMA was ~5 k of a workgroup's ~60 k cycles).  In later tiles the waits they imply are already satisfied.
+  auto pin_tap = [&](const int tap) __attribute__((always_inline)) {
+    if (tap < WST_AGPR_STEPS / 4) {
 #pragma unroll
-    for (int q = 0; q < 2 * WST_AGPR_STEPS; ++q) asm volatile("" : "+a"(wreg[q]));
-  }
+      for (int q = 8 * tap; q < 8 * tap + 8; ++q) asm volatile("" : "+a"(wreg[q]));
+    }
+  };
   stamp(1);
   int tile_no = 0;
-  V pf[8];                                                       // B fragments: a ring of eight
+  constexpr int RING = WST_RING;                                 // B fragments: a ring of RING (read RING slots = 32 RING matrix-pipe cycles ahead of their use)
+  V pf[RING];
 
   if constexpr (NAR) {
     // ---- the NARROW form: all four waves hold the SAME 32 output channels (Cout <= 32, pack padded to 32 rows; MFMA row = channel) and
@@ -299,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const char* fb = smem + pc * PITCH + hh * 16 + wn * (PW * PITCH);
     auto frag_load_n = [&](const int g, const char* base) __attribute__((always_inline)) {
       const int it = g >> 1, ss = g & 1, tap = it / KCH, kch = it - tap * KCH, ky = tap / 3, kx = tap - ky * 3;
-      pf[g & 7] = *reinterpret_cast<const V*>(base + (ky * PW + kx) * PITCH + (4 * kch + 2 * ss) * 16);
+      pf[g % RING] = *reinterpret_cast<const V*>(base + (ky * PW + kx) * PITCH + (4 * kch + 2 * ss) * 16);
     };
     // accumulator register r of lane (col, h) = channel (r % 4) + 8 (r / 4) + 4 h of pixel (row wn, col); the bias waits in LDS (sixteen
     // vector registers for it were sixteen too many in the prologue, beside 288 weights and 13 vectors in flight)
@@ -315,15 +357,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       const char* pb = fb + buf * PATCH_BYTES;
       char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) frag_load_n(g, pb);
+      for (int g = 0; g < RING; ++g) frag_load_n(g, pb);
       stage_norm_load(nx1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int sl = 0; sl < NSLOTS; ++sl) {
-        if (WST_DBG & 8) asm volatile("" : "+v"(pf[sl & 7]));
-        else if (sl == 0) accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl & 7], f32x16{}, 0, 0, 0);
-        else accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl & 7], accn, 0, 0, 0);
-        if (sl + 8 < NSLOTS && !(WST_DBG & 4)) frag_load_n(sl + 8, pb);
+        if ((sl & 7) == 0) {
+          if ((sl >> 3) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap((sl >> 3) + TAPS_AHEAD, z); }
+          pin_tap(sl >> 3);
+        }
+        if (WST_DBG & 8) asm volatile("" : "+v"(pf[sl % RING]));
+        else if (sl == 0) accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl % RING], f32x16{}, 0, 0, 0);
+        else accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl % RING], accn, 0, 0, 0);
+        if (sl + RING < NSLOTS && !(WST_DBG & 4)) frag_load_n(sl + RING, pb);
 #pragma unroll
         for (int mi = nar_lo(sl); mi < nar_lo(sl + 1) && !(WST_DBG & 1); ++mi) {
           const int k = mi / MICRO, u = mi - k * MICRO;
@@ -368,22 +414,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const int half = g / (ITERS * 4), sl = g - half * ITERS * 4, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
     const int tap = it / KCH, kch = it - tap * KCH;
     const int ky = tap / 3, kx = tap - ky * 3;
-    pf[g & 7] = *reinterpret_cast<const V*>(base + ((row + ky) * PW + kx) * PITCH + (4 * kch + 2 * ss) * 16);
+    pf[g % RING] = *reinterpret_cast<const V*>(base + ((row + ky) * PW + kx) * PITCH + (4 * kch + 2 * ss) * 16);
   };
 
   // ---- epilogue: lane (col, h) holds channels n .. n + 15 of the pixels (row, col) of the tile: bias, one rounding, two 16-byte NHWC stores
   // per row, as micro-ops of two independent vector instructions (E_ROW per tile row).  A store's address is a scalar base (tile, row) plus a
   // per-lane constant offset.
-  const int n = 32 * wn + 16 * hh;
-  float bias_r[16];            // (a data gradient has no bias: KIND 2 spends these sixteen registers on the norm state instead)
-  if constexpr (KIND != 2) {
-    const float* bp = p.bias ? p.bias + n : reinterpret_cast<const float*>(p.w);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { const float bv = bp[e]; bias_r[e] = p.bias ? bv : 0.f; }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) bias_r[e] = 0.f;
-  }
   const unsigned yoff = (unsigned)(pc * CIN + n) * 2u;
   // KIND 1 (forward statistics of the norm that follows, conv_common.h EpiStats): per 8-channel slot and pixel column li = col % 16 the old
   // kernel's thread adds the pixels (it, li), it = 0 .. 7 (= tile row it / 2, column 16 (it % 2) + li), IN THAT ORDER, then a butterfly over
@@ -555,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const char* pb = fbase + buf * PATCH_BYTES;
     char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) frag_load1(g, pb);
+    for (int g = 0; g < RING; ++g) frag_load1(g, pb);
     stage_norm_load(nxt);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -565,10 +601,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         // a slot: the MFMA, the read that refills its fragment eight slots ahead, this slot's share of the staging (wst::stage_lo / load_of) and
         // of the other half's epilogue, a full scheduling barrier: the emitted order IS this order
         const int g = half * ITERS * 4 + sl, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
-        if (WST_DBG & 8) asm volatile("" : "+v"(pf[g & 7]));
-        else if (it == 0 && ss == 0) acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g & 7], f32x16{}, 0, 0, 0);
-        else acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g & 7], acc[row], 0, 0, 0);
-        if (g + 8 < SLOTS && !(WST_DBG & 4)) frag_load1(g + 8, pb);
+        if (half == 0 && (sl & 15) == 0) {
+          if ((sl >> 4) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap((sl >> 4) + TAPS_AHEAD, z); }     // (first tile only: a uniform branch)
+          pin_tap(sl >> 4);
+        }
+        if (WST_DBG & 8) asm volatile("" : "+v"(pf[g % RING]));
+        else if (it == 0 && ss == 0) acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g % RING], f32x16{}, 0, 0, 0);
+        else acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g % RING], acc[row], 0, 0, 0);
+        if (g + RING < SLOTS && !(WST_DBG & 4)) frag_load1(g + RING, pb);
         if (load_of(g) >= 0 && !(WST_DBG & 1)) stage_load(load_of(g), q);
 #pragma unroll
         for (int mi = stage_lo(g); mi < stage_lo(g + 1) && !(WST_DBG & 1); ++mi) {

@@ -10,7 +10,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // MODE bits: 1 ds_read_b128 per slot (ring of 8, consumed by the MFMA 8 slots later), 2 accumulators in AGPRs, 4 s_waitcnt lgkmcnt(7) per slot,
 // 8 the extra instructions are SALU (s_add_u32), 16 they are s_nop 0, 32 they form ONE dependent chain (else round-robin over 8 registers),
-// 64 they are v_cvt_pk_bf16_f32, 128 a single accumulator chain (every MFMA depends on the one before)
+// 64 they are v_cvt_pk_bf16_f32, 128 a single accumulator chain (every MFMA depends on the one before), 256 v_pk_add_f32, 512 v_med3_f32
 template <int NV, int MODE>
 __global__ __launch_bounds__(256, 1) void probe(long long* out, float* sink, int iters) {
   __shared__ __attribute__((aligned(16))) char smem[120 * 1024];      // one workgroup per CU
@@ -24,6 +24,9 @@ __global__ __launch_bounds__(256, 1) void probe(long long* out, float* sink, int
   float x[8];
   for (int i = 0; i < 8; ++i) x[i] = 1.0f + i + lane;
   const float c1 = 0.999f, c2 = 0.001f;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 xp[4], cp = {0.5f, 0.25f};
+  for (int i = 0; i < 4; ++i) xp[i] = f32x2{1.0f + lane, 2.0f + i};
   unsigned addr = (unsigned)(size_t)(smem) + lane * 272;
   unsigned s0 = 1;
   const long long t0 = __builtin_amdgcn_s_memtime();
@@ -41,7 +44,9 @@ __global__ __launch_bounds__(256, 1) void probe(long long* out, float* sink, int
       if (MODE & 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pf[s]) : "v"(addr), "n"(s * 64));
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        if (MODE & 8) asm volatile("s_add_u32 %0, %0, 3" : "+s"(s0));
+        if (MODE & 8) asm volatile("s_add_u32 %0, %0, 3" : "+s"(s0) : : "scc");
+        else if (MODE & 256) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(xp[v & 3]) : "v"(cp));
+        else if (MODE & 512) asm volatile("v_med3_f32 %0, %0, 0, %1" : "+v"(x[(MODE & 32) ? 0 : v & 7]) : "v"(c1));
         else if (MODE & 16) asm volatile("s_nop 0");
         else if (MODE & 64) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[(MODE & 32) ? 0 : v & 7]) : "v"(c1));
         else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[(MODE & 32) ? 0 : v & 7]) : "v"(c1), "v"(c2));
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(256, 1) void probe(long long* out, float* sink, int
   float r = 0.f;
   for (int i = 0; i < 16; ++i) r += acc0[i] + acc1[i];
   for (int i = 0; i < 8; ++i) r += x[i] + __builtin_bit_cast(float, pf[i][0]);
+  for (int i = 0; i < 4; ++i) r += xp[i][0] + xp[i][1];
   sink[blockIdx.x * 256 + threadIdx.x] = r + (float)s0;
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
@@ -90,6 +96,8 @@ int main(int argc, char** argv) {
   SWEEP(1 | 4 | 8, "mfma (VGPR acc) + ds_read_b128 + s_waitcnt + n x s_add_u32")
   SWEEP(1 | 4 | 16, "mfma (VGPR acc) + ds_read_b128 + s_waitcnt + n x s_nop")
   SWEEP(1 | 4 | 64, "mfma (VGPR acc) + ds_read_b128 + s_waitcnt + n x v_cvt_pk_bf16_f32")
+  SWEEP(1 | 4 | 256, "mfma (VGPR acc) + ds_read_b128 + s_waitcnt + n x v_pk_add_f32")
+  SWEEP(1 | 4 | 512, "mfma (VGPR acc) + ds_read_b128 + s_waitcnt + n x v_med3_f32")
   SWEEP(128, "mfma, ONE accumulator chain (VGPR) + n x v_fma_f32")
   SWEEP(128 | 2, "mfma, ONE accumulator chain (AGPR) + n x v_fma_f32")
   return 0;
