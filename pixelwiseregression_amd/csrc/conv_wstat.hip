@@ -30,6 +30,7 @@
 // (MFMA alone: 4.7 k), the norm-backward-sums form 9 - 11 k: with one wave per SIMD the vector work beyond ~5 instructions per MFMA is no
 // longer hidden, so the data gradients stay on conv_patch.hip's pair kernel (two workgroups per CU hide that epilogue better).
 #include <type_traits>
+#include <utility>
 
 #include "conv_common.h"
 #include "pwr.h"
@@ -65,28 +66,113 @@ namespace wst {
 constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN * 2 + 16;
 constexpr int NITP = 13;                 // staging vectors per thread: 204 pixels x 16 slots / 256 threads ...
 constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 208 pixels: the last round's 4 surplus pixels are written (never read), no branch
-// Staging schedule inside the K loops.  A SLOT is one v_mfma_f32_32x32x16_bf16 (288 per tile, 32 matrix-pipe cycles each, 24 of them open to
-// the vector ALU).  The next patch's staging is 13 vectors x 21 micro-ops (two independent vector instructions each) = 273 micro-ops; they
-// are spread evenly over the slots S_START ... 287 (one per slot, two in every tenth), a vector's global load goes out LEAD slots before its
-// first micro-op: the first 40 slots of a tile carry no staging arithmetic, so that even the first vector's load (issued in slot 0, from
-// L2 / the Infinity Cache) has ~1300 cycles to land (with the micro-ops starting in slot 12 every tile's first K loop stalled ~500 cycles).
-constexpr int SLOTS = ITERS * 8, MICRO = 21, NMICRO = NITP * MICRO, S_START = 40, S_LEN = SLOTS - S_START, LEAD = 40;
-// micro-ops [stage_lo(g), stage_lo(g + 1)) run in slot g
-__host__ __device__ constexpr int stage_lo(int g) { return g <= S_START ? 0 : ((g - S_START) * NMICRO + S_LEN - 1) / S_LEN; }
-__host__ __device__ constexpr int slot_of_micro(int m) { return S_START + m * S_LEN / NMICRO; }
-__host__ __device__ constexpr int load_slot(int k) { return slot_of_micro(MICRO * k) - LEAD; }
-// the vector whose load is issued in slot g, or -1
-__host__ __device__ constexpr int load_of(int g) {
-  for (int k = 0; k < NITP; ++k)
-    if (load_slot(k) == g) return k;
-  return -1;
+// Schedule inside the K loops.  A SLOT is one v_mfma_f32_32x32x16_bf16 (288 per tile, 72 in the narrow form; 32 matrix-pipe cycles).  With ONE
+// wave per SIMD the wave that issues the MFMAs issues everything else too, one instruction per four cycles, and the MFMA itself occupies
+// the issue port for a while: measured (tools/csrc_debug/issue_probe.cpp, profiles/r5_issue_probe.jsonl) a slot of MFMA + fragment read +
+// its wait runs in 32.5 cycles, with 1 / 2 / 3 more instructions of ANY kind (vector, s_nop) in 33.5 / 34 / 35, and every further one
+// costs 4 - 5 (39, 44, 49); a scalar instruction beyond two costs 8, a v_pk_add_f32 22.  So what matters is that NO slot carries more
+// than three extra instructions: the staging of the next patch (13 vectors x SV items) and the epilogue of the finished half tile are
+// ITEMS with an instruction cost, dealt out to the slots by the compile-time table below -- the epilogue proportionally over its half, the
+// staging in order over what the epilogue leaves of three instructions per slot -- instead of by item count.
+constexpr int SLOTS = ITERS * 8, HSLOTS = ITERS * 4, NSLOTS = ITERS * 2, S_START = 40, LEAD = 40;
+// staging items of a vector.  Norm form, per channel pair j (i = 5 j + o): {unpack lo, unpack hi (+ the vector's keep value, i = 0)}
+// {- mean x 2} {fma x 2} {ReLU-and-mask x 2: v_med3_f32(x, 0, keep), keep = +inf or 0} {round + pack}; i = 20: the 16-byte LDS store.
+// Plain form: i = 0 .. 3 the mask of one dword, i = 4 the store.
+__host__ __device__ constexpr int sv_items(bool nrm) { return nrm ? 21 : 5; }
+__host__ __device__ constexpr int s_cost(bool nrm, bool nar, int i) {
+  if (i == sv_items(nrm) - 1) return nar ? 2 : 1;     // (narrow form: the LDS store and the global load of the vector's next-but-one tile)
+  if (!nrm) return i == 0 ? 2 : 1;
+  return i == 0 ? 3 : (i % 5 == 4 ? 1 : 2);
 }
-static_assert(stage_lo(SLOTS) == NMICRO && stage_lo(S_START + 1) >= 1 && stage_lo(S_START + 1) <= 2 && slot_of_micro(NMICRO - 1) == SLOTS - 1, "staging schedule");
-static_assert(load_slot(0) == 0 && load_of(0) == 0 && load_of(load_slot(12)) == 12 && load_of(1) == -1, "staging schedule");
-// the narrow form (KIND 3): 72 slots per tile, the same 273 micro-ops spread evenly over all of them
-constexpr int NSLOTS = ITERS * 2;
-__host__ __device__ constexpr int nar_lo(int g) { return g * NMICRO / NSLOTS; }
-static_assert(nar_lo(0) == 0 && nar_lo(NSLOTS) == NMICRO, "staging schedule of the narrow form");
+// epilogue items per tile row (see epi_micro): 14 base items (6 x two vector instructions, a store) per 16 channels, then the statistics
+__host__ __device__ constexpr int e_st(int kind) { return kind == 1 ? 34 : (kind == 2 ? 2 + 72 : 0); }
+__host__ __device__ constexpr int e_a0(int kind) { return kind == 1 ? 6 : 0; }
+__host__ __device__ constexpr int e_bf(int kind) { return (kind == 1 || kind == 2) ? 48 : 0; }
+__host__ __device__ constexpr int e_row(int kind) { return 14 + e_st(kind); }
+__host__ __device__ constexpr int e_half(int kind, int half) { return kind == 3 ? 0 : 2 * e_row(kind) + (half ? e_a0(kind) : e_bf(kind)); }
+__host__ __device__ constexpr int e_cost(int kind, int half, int eu) {
+  const int r0n = e_row(kind) + (half ? e_a0(kind) : 0);
+  const int u = eu < r0n ? eu : (eu - r0n < e_row(kind) ? eu - r0n : 99);
+  return (u < 14 && u % 7 == 6) ? 3 : 2;             // (a store: its scalar address arithmetic rides with it)
+}
+struct Deal {
+  short s_lo[SLOTS + 1];        // staging items [s_lo[g], s_lo[g + 1]) run in slot g (item m = vector m / SV, step m % SV)
+  short e_lo[SLOTS + 1];        // epilogue items likewise; items >= e_half(kind, 0) belong to the second half (index - e_half(kind, 0))
+  signed char ld[SLOTS];        // the vector whose global load is issued in slot g, or -1
+  short max_s, max_e, max_cost; // (for the static_asserts and the fixed-trip loops of the kernel)
+};
+__host__ __device__ constexpr Deal make_deal(bool nrm, int kind) {
+  Deal d{};
+  const bool nar = kind == 3;
+  const int nslots = nar ? NSLOTS : SLOTS;
+  const int sv = sv_items(nrm), ns = NITP * sv;
+  int ecost[SLOTS] = {};
+  const int eha = e_half(kind, 0);
+  for (int half = 0; half < 2 && !nar; ++half) {
+    const int eh = e_half(kind, half);
+    int ce = 0;
+    for (int i = 0; i < eh; ++i) ce += e_cost(kind, half, i);
+    int idx = 0, cum = 0;
+    for (int sl = 0; sl < HSLOTS; ++sl) {
+      const int g = half * HSLOTS + sl;
+      d.e_lo[g] = (short)((half ? eha : 0) + idx);
+      while (idx < eh && (2 * cum + e_cost(kind, half, idx)) * HSLOTS < 2 * ce * (sl + 1)) {     // the item's midpoint falls into this slot
+        ecost[g] += e_cost(kind, half, idx); cum += e_cost(kind, half, idx); ++idx;
+      }
+    }
+  }
+  for (int g = nar ? 0 : SLOTS; g <= SLOTS; ++g) d.e_lo[g] = (short)(nar ? 0 : eha + e_half(kind, 1));
+  // staging: in order, proportionally over the slots from s_start on, never lifting a slot above `cap` instructions; cap = the smallest that
+  // fits.  (Wide forms: a vector's global load goes out LEAD slots before its first item and the first S_START slots of a tile carry no
+  // staging, so that even the first vector's load -- issued in slot 0, from L2 / the Infinity Cache -- has ~1300 cycles to land.  The
+  // narrow form has the registers for a pipeline TWO tiles deep: a vector's load for the tile after next rides with its store item.)
+  const int s_start = nar ? 0 : S_START, margin = nar ? 2 : 8;      // (aim `margin` slots short of the end: a slot that is full makes an item wait)
+  int cs = 0;
+  for (int m = 0; m < ns; ++m) cs += s_cost(nrm, nar, m % sv);
+  for (int cap = 3; cap <= 12; ++cap) {
+    int idx = 0, cum = 0;
+    for (int g = 0; g < nslots; ++g) {
+      d.s_lo[g] = (short)idx;
+      // (where the staging has fallen six instructions behind its proportional share -- slots the epilogue filled -- one more is allowed)
+      const long long due = g < s_start ? 0 : (long long)cs * (g + 1 - s_start) / (nslots - s_start - margin);
+      int room = g < s_start ? 0 : cap + (due - cum >= 6 ? 1 : 0) - ecost[g];
+      while (idx < ns && s_cost(nrm, nar, idx % sv) <= room &&
+             (long long)(2 * cum + s_cost(nrm, nar, idx % sv)) * (nslots - s_start - margin) < (long long)2 * cs * (g + 1 - s_start)) {
+        room -= s_cost(nrm, nar, idx % sv); cum += s_cost(nrm, nar, idx % sv); ++idx;
+      }
+    }
+    if (idx == ns) break;
+  }
+  for (int g = nslots; g <= SLOTS; ++g) d.s_lo[g] = (short)ns;
+  for (int g = 0; g < SLOTS; ++g) d.ld[g] = -1;
+  if (!nar) {
+    int g = 0;
+    for (int k = 0; k < NITP; ++k) {
+      while (d.s_lo[g + 1] <= k * sv) ++g;             // the slot of the vector's first item
+      int l = g - LEAD < 0 ? 0 : g - LEAD;
+      while (d.ld[l] >= 0) ++l;
+      d.ld[l] = (signed char)k;
+    }
+  }
+  for (int g = 0; g < nslots; ++g) {
+    int c = ecost[g];
+    for (int m = d.s_lo[g]; m < d.s_lo[g + 1]; ++m) c += s_cost(nrm, nar, m % sv);
+    if (d.s_lo[g + 1] - d.s_lo[g] > d.max_s) d.max_s = (short)(d.s_lo[g + 1] - d.s_lo[g]);
+    if (d.e_lo[g + 1] - d.e_lo[g] > d.max_e) d.max_e = (short)(d.e_lo[g + 1] - d.e_lo[g]);
+    if (c > d.max_cost) d.max_cost = (short)c;
+  }
+  return d;
+}
+template <bool NRM, int KIND> struct DealOf { static constexpr Deal v = make_deal(NRM, KIND); };
+constexpr int MAXS = 8, MAXE = 4;
+// the K loops are written as compile-time loops: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), every slot number a
+// constant expression that indexes the deal table (as `#pragma unroll` loops over table look-ups the file took 20+ minutes to compile)
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+static_assert(make_deal(true, 0).s_lo[SLOTS] == NITP * 21 && make_deal(false, 1).s_lo[SLOTS] == NITP * 5 && make_deal(true, 3).s_lo[NSLOTS] == NITP * 21, "deal");
+static_assert(make_deal(true, 0).max_s <= MAXS && make_deal(true, 1).max_s <= MAXS && make_deal(false, 0).max_s <= MAXS && make_deal(true, 3).max_s <= MAXS, "deal");
+static_assert(make_deal(true, 0).max_e <= MAXE && make_deal(true, 1).max_e <= MAXE && make_deal(false, 2).max_e <= MAXE, "deal");
+static_assert(make_deal(true, 0).max_cost <= 4 && make_deal(false, 0).max_cost <= 3 && make_deal(true, 1).max_cost <= 6, "deal: no slot above four (statistics form: six) extra instructions");
 }  // namespace wst
 
 // NRM: the input carries a pending norm + ReLU (forward); KIND: 0 no statistics, 1 forward statistics, 2 norm-backward sums (data gradient),
@@ -150,37 +236,49 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   V sv[NITP];
   float mu[EP], sc[EP], be[EP];
   struct TileCo { int b, y0, x0; };
-  struct StageCo {                 // per tile: scalar row bases (bytes from x), per-thread column byte offsets and validity masks
-    long long rowbase[6];          // clamped row (y0 + r - 1) of sample b
-    unsigned rowok;                // bit r: row y0 + r - 1 is inside the image
-    unsigned voff0, voff1, voff12; // byte offset of this thread's vector inside a row, for even k / odd k / k = 12 (clamped into the row)
-    long long rowbase12;           // (per thread) row base of vector 12
-    unsigned keep0, keep12;        // all-ones or zero: even k (odd k: always inside), k = 12
+  // per tile, two records: where its vectors come from (LoadCo: scalar row pointers, per-thread column byte offsets) and which of them lie
+  // outside the image (MaskCo).  A keep value is all-ones or zero -- in the norm form +inf or zero, as v_med3_f32(x, 0, keep) is then the
+  // ReLU and the zero padding in ONE instruction (x < 0 -> 0, NaN -> 0 like v_max_f32, keep = 0 -> 0).
+  constexpr unsigned KEEP = NRM ? 0x7f800000u : ~0u;
+  // (addresses: raw buffer loads / stores -- a scalar 32-bit row offset in the instruction's soffset, a per-thread 32-bit byte offset, the
+  // tensor's base in a resource descriptor.  As 64-bit pointers the six row bases of a tile cost ~50 scalar instructions -- 8 issue
+  // cycles each with one wave per SIMD -- between the barrier and the tile's first MFMA, and every epilogue store six more.  The tensors of
+  // this kernel are below 4 GiB: conv_wstat_applicable.)
+  struct LoadCo {
+    unsigned row[6];               // (scalar) byte offset of the clamped row y0 + r - 1 of sample b
+    unsigned voff0, voff1, voff12; // byte offset of this thread's vector inside a row, for even k / odd k; k = 12: its full offset (clamped)
   };
-  auto stage_co = [&](const TileCo& c) __attribute__((always_inline)) {
-    StageCo q;
-    q.rowok = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int iy = c.y0 + r - 1;
-      const bool ok = iy >= 0 && iy < H;
-      q.rowok |= (ok ? 1u : 0u) << r;
-      q.rowbase[r] = ((long long)c.b * HW + (long long)min(max(iy, 0), H - 1) * W) * (CIN * 2);
-    }
-    const int ix0 = c.x0 + st_pl - 1;                                      // even k: columns x0 - 1 ... x0 + 14
-    q.voff0 = (unsigned)(max(ix0, 0) * (CIN * 2) + st_slot * 16);
-    q.keep0 = ix0 >= 0 ? ~0u : 0u;
-    q.voff1 = (unsigned)((c.x0 + 15 + st_pl) * (CIN * 2) + st_slot * 16);  // odd k: columns x0 + 15 ... x0 + 30, always inside
+  struct MaskCo {
+    unsigned rowm[6];              // (scalar) KEEP if row y0 + r - 1 is inside the image
+    unsigned keep0, keep12;        // even k: all-ones or zero by column (odd k: always inside); k = 12: KEEP or zero
+  };
+  const unsigned RS = (unsigned)W * (CIN * 2);                    // bytes of an image row
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, -1, 0x00020000);
+  auto load_co = [&](const TileCo& c) __attribute__((always_inline)) {
+    LoadCo q;
+    // rows y0 .. y0 + 3 are inside the image; only the halo rows r = 0 and r = 5 clamp
+    q.row[1] = (unsigned)(c.b * H + c.y0) * RS;
+    q.row[2] = q.row[1] + RS; q.row[3] = q.row[2] + RS; q.row[4] = q.row[3] + RS;
+    q.row[0] = q.row[1] - (c.y0 > 0 ? RS : 0u);
+    q.row[5] = q.row[4] + (c.y0 + 4 < H ? RS : 0u);
+    q.voff0 = (unsigned)(max(c.x0 + st_pl - 1, 0) * (CIN * 2) + st_slot * 16);          // even k: columns x0 - 1 ... x0 + 14
+    q.voff1 = (unsigned)((c.x0 + 15 + st_pl) * (CIN * 2) + st_slot * 16);               // odd k: columns x0 + 15 ... x0 + 30, always inside
     const int ix12 = c.x0 + c12 - 1, iy12 = c.y0 + r12 - 1;
-    q.voff12 = (unsigned)(min(ix12, W - 1) * (CIN * 2) + st_slot * 16);
-    q.rowbase12 = ((long long)c.b * HW + (long long)min(max(iy12, 0), H - 1) * W) * (CIN * 2);
-    q.keep12 = (st_pl < 12 && ix12 < W && iy12 >= 0 && iy12 < H) ? ~0u : 0u;
+    q.voff12 = (unsigned)(c.b * H + min(max(iy12, 0), H - 1)) * RS + (unsigned)(min(ix12, W - 1) * (CIN * 2) + st_slot * 16);
     return q;
   };
-  auto stage_load = [&](const int k, const StageCo& q) __attribute__((always_inline)) {
-    const char* xb = reinterpret_cast<const char*>(x);
-    if (k < 12) sv[k] = *reinterpret_cast<const V*>(xb + q.rowbase[k >> 1] + ((k & 1) ? q.voff1 : q.voff0));
-    else sv[k] = *reinterpret_cast<const V*>(xb + q.rowbase12 + q.voff12);
+  auto mask_co = [&](const TileCo& c) __attribute__((always_inline)) {
+    MaskCo q;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { const int iy = c.y0 + r - 1; q.rowm[r] = (iy >= 0 && iy < H) ? KEEP : 0u; }
+    q.keep0 = c.x0 + st_pl - 1 >= 0 ? ~0u : 0u;
+    const int ix12 = c.x0 + c12 - 1, iy12 = c.y0 + r12 - 1;
+    q.keep12 = (st_pl < 12 && ix12 < W && iy12 >= 0 && iy12 < H) ? KEEP : 0u;
+    return q;
+  };
+  auto stage_load = [&](const int k, const LoadCo& q) __attribute__((always_inline)) {
+    if (k < 12) sv[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((k & 1) ? q.voff1 : q.voff0), (int)q.row[k >> 1], 0));
+    else sv[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)q.voff12, 0, 0));
   };
   auto stage_norm_load = [&](const TileCo& c) __attribute__((always_inline)) {
     if constexpr (NRM) {
@@ -190,49 +288,49 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       for (int e = 0; e < EP; ++e) { mu[e] = st[e]; sc[e] = st[2 * plane + e]; be[e] = st[3 * plane + e]; }
     }
   };
-  // A vector's way into LDS as a sequence of MICRO-OPS (compile-time index `op`), so that the K loop can hand them out two or three at a
-  // time behind each MFMA: with one wave per SIMD the vector work only costs nothing while it rides in the issue shadow of the matrix
-  // pipe, and left to itself the scheduler emits a vector's ~45 instructions as one lump (the pipe drains for ~200 cycles, 13 x per tile).
-  // Per channel pair j (10 ops): unpack lo / hi, - mean x 2, fma x 2, ReLU x 2, round + pack, mask; then op NOPS - 1: the 16-byte LDS store.
-  // Same arithmetic and rounding as conv_patch.hip's stage_patch (fmaf(x - mu, sc, be), max 0, one rounding to bf16).
+  // A vector's way into LDS as a sequence of ITEMS (wst::s_cost), handed out behind the MFMAs by the deal table: with one wave per SIMD the
+  // vector work only costs nothing while it fits into the issue slots the matrix pipe leaves, and left to itself the scheduler emits a
+  // vector's ~40 staging instructions as one lump (the pipe drains for ~200 cycles, 13 x per tile).  Same arithmetic and rounding as
+  // conv_patch.hip's stage_patch: fmaf(x - mu, sc, be), max 0, one rounding to bf16 (the masked lanes: zero either way).
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  constexpr int SV = sv_items(NRM);
   u32x4 so;
   float t0 = 0.f, t1 = 0.f;
-  auto keep_of = [&](const int k, const StageCo& q) __attribute__((always_inline)) {
+  unsigned km = 0;               // the keep value of the vector in flight
+  auto keep_of = [&](const int k, const MaskCo& q) __attribute__((always_inline)) {
     // (an arithmetic mask, not a select that hipcc turns into an exec-masked branch -- that would cut the K loop's scheduling region in
     // two; row validity is a scalar)
-    if (k < 12) return (((k & 1) ? ~0u : q.keep0)) & (0u - ((q.rowok >> (k >> 1)) & 1u));
+    if (k < 12) return (k & 1) ? q.rowm[k >> 1] : (q.keep0 & q.rowm[k >> 1]);
     return q.keep12;
   };
-  // micro-op u = 0 .. 20 of vector k.  The two vector instructions of a micro-op never depend on each other (a dependent pair waits out the
-  // first one's latency in the slot it was supposed to hide in): per channel pair j = u / 5: {unpack lo, unpack hi} {- mean, - mean} {fma, fma}
-  // {ReLU, ReLU} {round + pack of pair j, mask of pair j - 1}; u = 20: mask of pair 3, then the 16-byte LDS store.  (No norm: the mask ops only.)
-  auto stage_micro = [&](const int k, const int u, const StageCo& q, char* patch) __attribute__((always_inline)) {
-    if (u == MICRO - 1) {
-      so[3] = so[3] & keep_of(k, q);
+  // item i of vector k.  The two vector instructions of an item never depend on each other (a dependent instruction issued right behind
+  // its producer waits four more cycles in the slot it was supposed to hide in).
+  auto stage_item = [&](const int k, const int i, const MaskCo& q, char* patch) __attribute__((always_inline)) {
+    if (i == SV - 1) {
       const int off = k < 12 ? lds_st + ((k >> 1) * PW + 16 * (k & 1)) * PITCH : lds_st12;
       *reinterpret_cast<u32x4*>(patch + off) = so;
       return;
     }
-    const int j = u / 5, o = u - 5 * j;
     if constexpr (!NRM) {
-      if (o == 4) { so[j] = __builtin_bit_cast(u32x4, sv[k])[j]; if (j > 0) so[j - 1] = so[j - 1] & keep_of(k, q); }
+      if (i == 0) km = keep_of(k, q);
+      so[i] = __builtin_bit_cast(u32x4, sv[k])[i] & km;
     } else {
-      if (o == 0) { t0 = (float)sv[k][2 * j]; t1 = (float)sv[k][2 * j + 1]; }
+      const int j = i / 5, o = i - 5 * j;
+      if (o == 0) { t0 = (float)sv[k][2 * j]; t1 = (float)sv[k][2 * j + 1]; if (j == 0) km = keep_of(k, q); }
       else if (o == 1) { t0 = t0 - mu[2 * j]; t1 = t1 - mu[2 * j + 1]; }
       else if (o == 2) { t0 = fmaf(t0, sc[2 * j], be[2 * j]); t1 = fmaf(t1, sc[2 * j + 1], be[2 * j + 1]); }
-      else if (o == 3) {      // (as asm: behind the pin of the previous micro-op hipcc no longer knows the fma result is canonical and would put a
-        // canonicalising v_max_f32 x, x, x in front of each fmaxf; v_max_f32 quiets a signalling NaN by itself)
-        asm("v_max_f32 %0, 0, %0" : "+v"(t0));
-        asm("v_max_f32 %0, 0, %0" : "+v"(t1));
+      else if (o == 3) {      // (as asm: behind the pin of the previous item hipcc no longer knows the fma result is canonical and would put a
+        // canonicalising v_max_f32 x, x, x in front of it)
+        asm("v_med3_f32 %0, %0, 0, %1" : "+v"(t0) : "v"(km));
+        asm("v_med3_f32 %0, %0, 0, %1" : "+v"(t1) : "v"(km));
       }
-      else {
-        bf16x2 pk; pk[0] = (bf16_t)t0; pk[1] = (bf16_t)t1;
-        so[j] = __builtin_bit_cast(unsigned, pk);
-        if (j > 0) so[j - 1] = so[j - 1] & keep_of(k, q);
-      }
+      else { bf16x2 pk; pk[0] = (bf16_t)t0; pk[1] = (bf16_t)t1; so[j] = __builtin_bit_cast(unsigned, pk); }
     }
   };
+  // (an empty asm that "modifies" the staging temporaries: instruction selection orders side-effect-free arithmetic freely inside a block,
+  // whatever the scheduling barriers say; this ties a slot's items between the barriers around it.  ONE per slot, behind its last item --
+  // hipcc puts a wait state between such an asm and a vector instruction that reads what it "wrote")
+  auto stage_pin = [&]() __attribute__((always_inline)) { asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so), "+v"(km)); };
   // tile coordinates walk incrementally (no division in the loop)
   auto tile_next = [&](TileCo c) {
     c.x0 += 32;
@@ -248,10 +346,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     const int tr = t - cur.b * tiles_img, tyi = tr / tiles_x;
     cur.y0 = tyi * 4; cur.x0 = (tr - tyi * tiles_x) * 32;
   }
-  const StageCo q0 = stage_co(cur);
-  stage_norm_load(cur);
+  TileCo nx1 = (t + 1 < t_end) ? tile_next(cur) : cur;            // (the last tiles re-stage themselves: branch-free K loops)
+  {
+    const LoadCo l0 = load_co(cur);
+    stage_norm_load(cur);
 #pragma unroll
-  for (int k = 0; k < NITP; ++k) stage_load(k, q0);
+    for (int k = 0; k < NITP; ++k) stage_load(k, l0);
+  }
   __builtin_amdgcn_sched_barrier(0);
   stamp(25);
   // (the bias goes out BEFORE the weights: vmcnt counts in order, a wait for anything issued behind the weights is a wait for all of them)
@@ -297,10 +398,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   for (int tap = 0; tap < TAPS_AHEAD; ++tap) load_tap(tap, 0);
   if (TAPS_AHEAD < 9) load_tap(8, 0);      // (tap 8 lives in VGPRs; requested from inside the loop it cost the statistics form 27 spilled registers)
   __builtin_amdgcn_sched_barrier(0);
+  {
+    // the first patch into buffer 0; narrow form: each vector's registers take the SECOND tile's vector the moment they are free (its first
+    // use is in slot 0 of the first K loop: the vectors requested first get the rest of this block, ~2 000 cycles, to arrive)
+    const MaskCo m0 = mask_co(cur);
+    const LoadCo l1 = load_co(nx1);
 #pragma unroll
-  for (int k = 0; k < NITP; ++k)
+    for (int k = 0; k < NITP; ++k) {
 #pragma unroll
-    for (int u = 0; u < MICRO; ++u) stage_micro(k, u, q0, smem);
+      for (int i = 0; i < SV; ++i) stage_item(k, i, m0, smem);
+      stage_pin();
+      if (NAR) stage_load(k, l1);
+    }
+  }
   if constexpr (NAR) {
     if (tid < 32) sbias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
   }
@@ -327,6 +437,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   };
   stamp(1);
   int tile_no = 0;
+
   constexpr int RING = WST_RING;                                 // B fragments: a ring of RING (read RING slots = 32 RING matrix-pipe cycles ahead of their use)
   V pf[RING];
 
@@ -345,24 +456,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     };
     // accumulator register r of lane (col, h) = channel (r % 4) + 8 (r / 4) + 4 h of pixel (row wn, col); the bias waits in LDS (sixteen
     // vector registers for it were sixteen too many in the prologue, beside 288 weights and 13 vectors in flight)
-    TileCo nx1 = (t + 1 < t_end) ? tile_next(cur) : cur;
-    StageCo q1 = stage_co(nx1);
-#pragma unroll
-    for (int k = 0; k < NITP; ++k) stage_load(k, q1);              // tile 1's vectors (tile 0's have been written to LDS above)
     f32x16 accn;
     int buf = 0;
     for (; t < t_end; ++t) {
-      const TileCo nx2 = (t + 2 < t_end) ? tile_next(nx1) : nx1;   // (the last tiles re-stage themselves: branch-free K loop)
-      const StageCo q2 = stage_co(nx2);
+      const TileCo nx2 = (t + 2 < t_end) ? tile_next(nx1) : nx1;
+      const LoadCo l2 = load_co(nx2);
+      const MaskCo m1_ = mask_co(nx1);
       const char* pb = fb + buf * PATCH_BYTES;
       char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
       for (int g = 0; g < RING; ++g) frag_load_n(g, pb);
-      stage_norm_load(nx1);
+      if (nx1.b != cur.b) stage_norm_load(nx1);                    // (its first use is in slot 0: only when the sample changes)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int sl = 0; sl < NSLOTS; ++sl) {
-        if ((sl & 7) == 0) {
+      static_for<NSLOTS>([&](auto SL) __attribute__((always_inline)) {
+        constexpr int sl = decltype(SL)::value;
+        constexpr int m0 = DealOf<NRM, KIND>::v.s_lo[sl], m1 = DealOf<NRM, KIND>::v.s_lo[sl + 1];
+        if constexpr ((sl & 7) == 0) {
           if ((sl >> 3) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap((sl >> 3) + TAPS_AHEAD, z); }
           pin_tap(sl >> 3);
         }
@@ -370,15 +479,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         else if (sl == 0) accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl % RING], f32x16{}, 0, 0, 0);
         else accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl % RING], accn, 0, 0, 0);
         if (sl + RING < NSLOTS && !(WST_DBG & 4)) frag_load_n(sl + RING, pb);
-#pragma unroll
-        for (int mi = nar_lo(sl); mi < nar_lo(sl + 1) && !(WST_DBG & 1); ++mi) {
-          const int k = mi / MICRO, u = mi - k * MICRO;
-          stage_micro(k, u, q1, nb);
-          if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
-          if (u == MICRO - 1) stage_load(k, q2);
+        if constexpr (m1 > m0 && !(WST_DBG & 1)) {
+          static_for<m1 - m0>([&](auto J) __attribute__((always_inline)) {
+            constexpr int m = m0 + decltype(J)::value, k = m / SV, i = m - k * SV;
+            stage_item(k, i, m1_, nb);
+            if (i == SV - 1) stage_load(k, l2);
+          });
+          stage_pin();
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       stamp(2 + 3 * tile_no);
       {
         float* yo = p.y_nchw + ((size_t)cur.b * p.Cout * H + (size_t)(cur.y0 + wn)) * W + cur.x0 + pc;
@@ -394,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       stamp(3 + 3 * tile_no);
       __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loop
       stamp(4 + 3 * tile_no); ++tile_no;
-      cur = nx1; nx1 = nx2; q1 = q2;
+      cur = nx1; nx1 = nx2;
       buf ^= 1;
     }
     stamp(31);
@@ -421,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // per row, as micro-ops of two independent vector instructions (E_ROW per tile row).  A store's address is a scalar base (tile, row) plus a
   // per-lane constant offset.
   const unsigned yoff = (unsigned)(pc * CIN + n) * 2u;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, -1, 0x00020000);
   // KIND 1 (forward statistics of the norm that follows, conv_common.h EpiStats): per 8-channel slot and pixel column li = col % 16 the old
   // kernel's thread adds the pixels (it, li), it = 0 .. 7 (= tile row it / 2, column 16 (it % 2) + li), IN THAT ORDER, then a butterfly over
   // li.  Here lane (col, h) holds 16 channels of the pixels (row, col): the lanes col and col ^ 16 (rows 16 lanes apart in the wave) exchange
@@ -431,11 +542,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // KIND 2 (this launch is a data gradient g; sums of the norm backward of the tensor y it belongs to: relu-masked g and g * xhat): the same
   // exchange and order; the forward activations y of the lane's slot and two pixels come straight from global memory (two 16-byte loads per
   // tile row, issued with the row's first micro-op), the norm state of the sample sits in 32 registers, re-read at the half boundary.
-  constexpr int E_ST = KIND == 1 ? 34 : (KIND == 2 ? 2 + 72 : 0);    // per tile row: 2 swaps + 2 pixels x 4 channel pairs x (4 | 9) micro-ops
-  constexpr int E_A0 = KIND == 1 ? 6 : 0;                        // tile row 0: the shift (the tile's first pixel) to every lane of the slot
-  constexpr int E_BF = KIND != 0 ? 48 : 0;                       // the butterfly over the 16 lanes of a row: 6 steps x 8 pairs of sums
-  constexpr int E_ROW = 14 + E_ST;
-  constexpr int E_HALF_A = 2 * E_ROW + E_BF, E_HALF_B = 2 * E_ROW + E_A0;     // half A: rows 2 - 3 of the previous tile + its butterfly; half B: rows 0 - 1
+  // (wst::e_st: per tile row 2 swaps + 2 pixels x 4 channel pairs x (4 | 9) items; e_a0: tile row 0, the shift (the tile's first pixel) to every
+  // lane of the slot; e_bf: the butterfly over the 16 lanes of a row, 6 steps x 8 pairs of sums; half A = rows 2 - 3 of the previous tile + its
+  // butterfly, half B = rows 0 - 1)
+  constexpr int E_A0 = e_a0(KIND), E_BF = e_bf(KIND), E_ROW = e_row(KIND);
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
   u32x4 eo, oL, oH;
   float s1[8], s2[8], a0[8];
@@ -459,8 +569,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       else if (v == 4) { f2 = acc[row][c0 + 6] + bias_r[c0 + 6]; f3 = acc[row][c0 + 7] + bias_r[c0 + 7]; }
       else if (v == 5) { eo[2] = pk2(f0, f1); eo[3] = pk2(f2, f3); }
       else {
-        char* yb = reinterpret_cast<char*>(p.y) + ((size_t)c.b * HW + (size_t)(c.y0 + row) * W + c.x0) * (CIN * 2) + e8 * 16;
-        *reinterpret_cast<u32x4*>(yb + yoff) = eo;
+        __builtin_amdgcn_raw_buffer_store_b128(eo, ry, (int)(yoff + e8 * 16), (int)((unsigned)((c.b * H + c.y0 + row) * W + c.x0) * (CIN * 2)), 0);
         if (KIND != 0) { if (e8 == 0) oL = eo; else oH = eo; }
       }
       if (KIND == 2 && u == 0) {       // y of the NEXT row in processing order (rows 0, 1 of `cn` = the current tile; 2, 3 of the tile c)
@@ -584,24 +693,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
 
   int buf = 0;
   TileCo prev = cur;            // (first tile: the "previous tile's" half epilogue stores garbage where this tile's own epilogue writes later)
+  constexpr int EHA = e_half(KIND, 0);
   for (; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    const TileCo nxt = more ? tile_next(cur) : cur;              // (the last tile re-stages itself into the other buffer: branch-free K loop)
-    const StageCo q = stage_co(nxt);
+    const LoadCo l1 = load_co(nx1);
+    const MaskCo m1_ = mask_co(nx1);
     const char* pb = fbase + buf * PATCH_BYTES;
     char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
     for (int g = 0; g < RING; ++g) frag_load1(g, pb);
-    stage_norm_load(nxt);
+    if (nx1.b != cur.b) stage_norm_load(nx1);                      // (its first use is in slot 0: only when the sample changes)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int sl = 0; sl < ITERS * 4; ++sl) {
-        // a slot: the MFMA, the read that refills its fragment eight slots ahead, this slot's share of the staging (wst::stage_lo / load_of) and
-        // of the other half's epilogue, a full scheduling barrier: the emitted order IS this order
-        const int g = half * ITERS * 4 + sl, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
-        if (half == 0 && (sl & 15) == 0) {
+    static_for<2>([&](auto HALF) __attribute__((always_inline)) {
+      constexpr int half = decltype(HALF)::value;
+      static_for<HSLOTS>([&](auto SL) __attribute__((always_inline)) {
+        // a slot: the MFMA, the read that refills its fragment RING slots ahead, this slot's items of the staging and of the other half's
+        // epilogue (the deal table), a full scheduling barrier: the emitted order IS this order
+        constexpr int sl = decltype(SL)::value;
+        constexpr int g = half * HSLOTS + sl, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
+        constexpr int m0 = DealOf<NRM, KIND>::v.s_lo[g], m1 = DealOf<NRM, KIND>::v.s_lo[g + 1];
+        constexpr int e0 = DealOf<NRM, KIND>::v.e_lo[g], e1 = DealOf<NRM, KIND>::v.e_lo[g + 1];
+        if constexpr (half == 0 && (sl & 15) == 0) {
           if ((sl >> 4) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap((sl >> 4) + TAPS_AHEAD, z); }     // (first tile only: a uniform branch)
           pin_tap(sl >> 4);
         }
@@ -609,47 +720,49 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         else if (it == 0 && ss == 0) acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g % RING], f32x16{}, 0, 0, 0);
         else acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g % RING], acc[row], 0, 0, 0);
         if (g + RING < SLOTS && !(WST_DBG & 4)) frag_load1(g + RING, pb);
-        if (load_of(g) >= 0 && !(WST_DBG & 1)) stage_load(load_of(g), q);
-#pragma unroll
-        for (int mi = stage_lo(g); mi < stage_lo(g + 1) && !(WST_DBG & 1); ++mi) {
-          const int k = mi / MICRO, u = mi - k * MICRO;
-          stage_micro(k, u, q, nb);
-          // (instruction selection orders side-effect-free arithmetic freely inside the block, whatever the barriers say: an empty asm
-          // that "modifies" the temporaries ties each slot's arithmetic between the barriers around it)
-          if (NRM || u % 5 == 4) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(so));
+        if constexpr (DealOf<NRM, KIND>::v.ld[g] >= 0 && !(WST_DBG & 1)) stage_load(DealOf<NRM, KIND>::v.ld[g], l1);
+        if constexpr (m1 > m0 && !(WST_DBG & 1)) {
+          static_for<m1 - m0>([&](auto J) __attribute__((always_inline)) {
+            constexpr int m = m0 + decltype(J)::value, k = m / SV, i = m - k * SV;
+            stage_item(k, i, m1_, nb);
+          });
+          stage_pin();
         }
-#pragma unroll
-        for (int eu = sl * (half ? E_HALF_B : E_HALF_A) / (ITERS * 4); eu < (sl + 1) * (half ? E_HALF_B : E_HALF_A) / (ITERS * 4) && !(WST_DBG & 2); ++eu) {
+        if constexpr (e1 > e0 && !(WST_DBG & 2)) {
           // (half B finishes tile rows 0 - 1 of this tile -- row 0 carries the E_A0 extra ops --, half A rows 2 - 3 of the previous one and
           // then the butterfly of its sums)
-          const int r0n = E_ROW + (half ? E_A0 : 0);
-          if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev, cur);
-          else if (eu - r0n < E_ROW) epi_micro(half ? 1 : 3, eu - r0n, half ? cur : prev, cur);
-          else bfly_micro(eu - r0n - E_ROW);
+          constexpr int r0n = E_ROW + (half ? E_A0 : 0);
+          constexpr bool bf_any = (half ? e1 - 1 - EHA : e1 - 1) - r0n >= E_ROW;
+          static_for<e1 - e0>([&](auto J) __attribute__((always_inline)) {
+            constexpr int ea = e0 + decltype(J)::value, eu = half ? ea - EHA : ea;
+            if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev, cur);
+            else if (eu - r0n < E_ROW) epi_micro(half ? 1 : 3, eu - r0n, half ? cur : prev, cur);
+            else bfly_micro(eu - r0n - E_ROW);
+          });
+          // (one tie per slot, behind its last item)
           asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(eo));
           if (KIND != 0) {
             asm volatile("" : "+v"(oL), "+v"(oH), "+v"(bt0_), "+v"(bt1_), "+v"(bt2), "+v"(bt3));
             if (KIND == 2) asm volatile("" : "+v"(g0), "+v"(g1));
-            if (eu - r0n >= E_ROW) {      // (tie the pair of sums this butterfly op touched)
-              const int bb = eu - r0n - E_ROW, j = bb < 16 ? (bb & 7) : (bb < 40 ? 2 * ((bb - 16) / 6) + ((bb - 16) & 1) : bb - 40);
-              if (j < 4) asm volatile("" : "+v"(s1[2 * j]), "+v"(s1[2 * j + 1]));
-              else asm volatile("" : "+v"(s2[2 * (j - 4)]), "+v"(s2[2 * (j - 4) + 1]));
+            if (bf_any) {
+              asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
+              asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
             }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       stamp(2 + 3 * tile_no + half);
       if (half == 0) {
         stats_write(prev, tile_no > 0);                            // the previous tile's rows 2 - 3 and the butterfly went in during this half A
         if (KIND == 2 && cur.b != prev.b) nb_state_load(cur.b);    // (first needed some twenty slots into half B)
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loops
     stamp(4 + 3 * tile_no); ++tile_no;
     prev = cur;
-    cur = nxt;
+    cur = nx1; nx1 = (t + 2 < t_end) ? tile_next(nx1) : nx1;
     buf ^= 1;
   }
   // the last tile's second half
@@ -670,7 +783,8 @@ bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int str
 }
 
 bool conv_wstat_applicable(const ConvParams& p, int dtype) {
-  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0);            // (debug build: read on every call, so one process can A/B the two kernels)
+  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) &&          // (debug build: read on every call, so one process can A/B the two kernels)
+                  (long long)p.B * p.H * p.W * 256 < (1ll << 32);            // (32-bit byte offsets into x and y)
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
          p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
@@ -679,7 +793,7 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
 
 // the narrow form (KIND 3): 128 -> Cout <= 32 channels, fp32 NCHW output only (the heads' last conv)
 bool conv_wstat_narrow_applicable(const ConvParams& p, int dtype) {
-  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) && (PWR_DBG_ENV("PWR_WSTAT_NARROW", 1) != 0);
+  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) && (PWR_DBG_ENV("PWR_WSTAT_NARROW", 1) != 0) && (long long)p.B * p.H * p.W * 256 < (1ll << 32);
   return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout <= 32 &&
          p.CoutPad == 32 && p.W % 32 == 0 && p.H % 4 == 0 && p.y == nullptr && p.y_nchw != nullptr && !p.residual && !p.w_frag &&
          (!p.in_norm || p.relu_in) && !p.st_partial && !p.nb_partial && p.B * (p.H / 4) * (p.W / 32) >= PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
@@ -690,7 +804,9 @@ static void launch_kind(const WstatArgs& a, int kind, dim3 grid, hipStream_t s) 
   if (kind == 0) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 0>), grid, dim3(256), 0, s, a);
   else if (kind == 1) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 1>), grid, dim3(256), 0, s, a);
   else if (kind == 3) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 3>), grid, dim3(256), 0, s, a);
+#ifdef PWR_DEBUG_BUILD      // (the norm-backward-sums form: measured and not shipped -- see the header; the product library does not carry it)
   else if constexpr (!NRM) hipLaunchKernelGGL((conv3x3_wstat_kernel<false, 2>), grid, dim3(256), 0, s, a);
+#endif
 }
 
 // one job (b == nullptr) or two jobs of one geometry, one norm / statistics form
