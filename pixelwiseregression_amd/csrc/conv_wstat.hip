@@ -21,14 +21,28 @@
 //     buffered in LDS (2 x 55 KiB): the patch of tile n + 1 is loaded, normalised and written while the MFMAs of tile n issue -- the wave's own
 //     software pipeline, since a second wave per SIMD does not fit beside 288 weight registers.  One barrier per tile.
 //   * A tile runs as two half-tile K loops (tile rows 0 - 1, then 2 - 3); the epilogue of the half finished before rides behind the MFMAs
-//     of the running one.  ALL vector work inside the K loops -- staging and epilogue -- is cut into MICRO-OPS of two independent vector
-//     instructions that are handed out per MFMA slot by compile-time tables; a full scheduling barrier closes every slot and an empty asm
-//     ties each micro-op's temporaries into it (left alone hipcc emits a vector's 45 staging instructions as one lump and the pipe drains).
-// Work per tile and wave: 288 MFMAs (9216 matrix-pipe cycles), 288 ds_read_b128, 13 global loads + 13 ds_write_b128 + ~550 vector instructions
-// of staging (norm form), ~100 (plain) / ~400 (forward statistics) / ~700 (norm-backward sums) of epilogue.  Measured (MI355X, B = 32, 64 x 64,
-// s_memtime stamps): prologue 13 k cycles (340 KiB per CU: cold patch from HBM + the weights from L2), half-tile K loops 5.4 - 6.0 k cycles
-// (MFMA alone: 4.7 k), the norm-backward-sums form 9 - 11 k: with one wave per SIMD the vector work beyond ~5 instructions per MFMA is no
-// longer hidden, so the data gradients stay on conv_patch.hip's pair kernel (two workgroups per CU hide that epilogue better).
+//     of the running one.  ALL vector work inside the K loops -- staging and epilogue -- is cut into ITEMS of one or two independent vector
+//     instructions that are handed out per MFMA slot by a compile-time table (wst::make_deal) under a budget of three extra instructions
+//     per slot; a full scheduling barrier closes every slot and an empty asm ties each slot's temporaries into it (left alone hipcc emits a
+//     vector's 40 staging instructions as one lump and the pipe drains).  Why three: with ONE wave per SIMD everything issues from the wave
+//     that issues the MFMAs, one instruction per four cycles; tools/csrc_debug/issue_probe.cpp measured a slot of MFMA + fragment read + wait
+//     at 32.5 cycles, 33.5 / 34 / 35 with one / two / three more instructions, +4 ... 5 for each one beyond, 8 for a scalar instruction
+//     beyond two, 22 for a v_pk_add_f32 (profiles/r5_issue_probe.jsonl).
+//   * Addresses are raw buffer loads / stores: a scalar 32-bit row offset in soffset, a per-thread 32-bit offset, the tensor base in a
+//     resource descriptor -- as 64-bit pointers the row bases of a tile were ~50 scalar instructions between the barrier and the tile's
+//     first MFMA.  The zero padding is folded into the ReLU: v_med3_f32(x, 0, keep), keep = +inf or 0.
+//   * The weights of taps 3 .. 7 are requested from INSIDE the first tile's first K loop, three taps ahead of their use (vmcnt counts in
+//     order: requested up front, the first wait for anything behind them is a wait for all 288 KiB).  They still bound the first tile:
+//     a CU gets ~26 B / clock out of its XCD's L2 while all 32 CUs of the XCD fetch the same 288 KiB (~11 k cycles however arranged).
+//   * KIND 3, the NARROW form (the heads' last conv, 128 -> J <= 32, fp32 NCHW out): the four waves hold the same 32 channels and split the
+//     tile's rows; the staging pipeline is two tiles deep there (the registers exist).  Staging-bound: 13 x 38 vector instructions per tile
+//     beside 72 MFMAs.
+// Work per tile and wave: 288 MFMAs (9216 matrix-pipe cycles), 288 ds_read_b128, 13 loads + 13 ds_write_b128 + ~490 vector instructions of
+// staging (norm form), ~100 (plain) / ~400 (forward statistics) of epilogue.  Measured (MI355X, B = 32, 64 x 64, s_memtime stamps):
+// prologue 10 k cycles, the first tile's first K loop 7.9 k (waiting for weights), the others 5.2 - 5.7 k (MFMA alone: 4.7 k; by
+// elimination the staging costs ~0.45 k per half, the epilogue ~0.15 k).  The norm-backward-sums form (KIND 2, debug build only) runs
+// 9 - 11 k: its 9 vector instructions per element do not fit beside one wave's MFMAs, so the data gradients stay on conv_patch.hip's pair
+// kernel (two workgroups per CU hide that epilogue better).
 #include <type_traits>
 #include <utility>
 

@@ -34,6 +34,10 @@ if which in ("all", "fwd"):
     ys = torch.randn(B, P, P, F_, device=dev).to(torch.bfloat16)
     t = timeit(lambda: K.conv_fwd_stats(x, pack_d, F_, 3, 1, nb_y=ys, nb_state=st))
     print(json.dumps({"kernel": "conv3x3_patch data gradient + norm-backward sums (incl. the NaN fill of the test wrapper)", "us": t * 1e6, "TFLOPs": flops / t / 1e12}))
+    wj = torch.randn(14, F_, 3, 3, device=dev) * 0.03
+    pack_j = K.pack_conv(wj, 0, K.BF16)
+    t = timeit(lambda: K.conv_fwd(x, pack_j, 14, 3, 1, bias=bias[:14].contiguous(), norm=st, nhwc_out=False, nchw_out=True))
+    print(json.dumps({"kernel": "conv3x3_wstat narrow form: 128 -> 14, fp32 NCHW out (+NR prologue)", "us": t * 1e6, "TFLOPs": flops * 14 / 128 / t / 1e12}))
 if which in ("all", "wgrad"):
     # the engine's split count for this layer (80) only, so that the rocprofv3 average of these launches is the number quoted in
     # DESIGN.md; `sweep` as third argument walks the split counts (round 2's 81 us "average" was over such a sweep)
