@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 4   /* 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 5   /* 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -119,6 +119,13 @@ int pwr_conv_fwd_stats_pair(const void* xa, const void* wa, const float* bias_a,
 /* Two data gradients of stride-1 3x3 convs of ONE shape in ONE launch -- pwr_conv_fwd_stats in its norm-backward form (x = dy, kind-1 pack,
  * no bias, no prologue, nb_partial) for both regression heads of a stage, which walk their convs backwards in lock-step
  * (autograd of model.py:54-65 / :103-114).  PWR_EUNSUPPORTED: no pair kernel for the shape.  Results are those of the two single launches, bit for bit. */
+/* Two pwr_conv_fwd launches that write fp32 NCHW maps only (y == NULL), of ONE shape, as one launch: the two regression heads' last convs
+ * (model.py:64 and :113, 128 -> J).  PWR_EUNSUPPORTED when the shape has no such launch (bf16, 3x3, stride 1, Cin = 128, Cout <= 32,
+ * H % 4 == 0, W % 32 == 0): call pwr_conv_fwd twice.  Results are those of the two single launches, bit for bit. */
+int pwr_conv_fwd_nchw_pair(const void* xa, const void* wa, const float* bias_a, const float* in_norm_a, float* ya_nchw,
+                           const void* xb, const void* wb, const float* bias_b, const float* in_norm_b, float* yb_nchw,
+                           int relu_in, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream);
+
 int pwr_conv_dgrad_stats_pair(const void* dya, const void* wa, void* dxa, const void* nb_y_a, const float* nb_state_a, float* nb_partial_a,
                               const void* dyb, const void* wb, void* dxb, const void* nb_y_b, const float* nb_state_b, float* nb_partial_b,
                               int nb_relu, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream);

@@ -219,6 +219,7 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype);
 bool conv_wstat_narrow_applicable(const ConvParams& p, int dtype);   // 128 -> Cout <= 32, fp32 NCHW output (the heads' last conv)
 bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int dtype);   // would a plain conv of this shape run on it?
 bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype);
+bool conv_wstat_narrow_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype);
 int launch_conv_wstat(const ConvParams& a, const ConvParams* b, hipStream_t s);
 
 // conv_wgrad_dma.hip: 3x3 weight gradient with both operands staged by LDS-DMA (operand already normalised: in_norm == null)

@@ -1304,6 +1304,21 @@ extern "C" int pwr_conv_fwd_stats_pair(const void* xa, const void* wa, const flo
   return pwr::launch_conv_patch_pair(a, b, (hipStream_t)stream);
 }
 
+// Two pwr_conv_fwd launches with fp32 NCHW outputs only (the two heads' last convs, model.py:64 / :113) of ONE shape as one launch of
+// the narrow weight-stationary kernel; PWR_EUNSUPPORTED when the shape has no such launch (the caller then launches them one after the other)
+extern "C" int pwr_conv_fwd_nchw_pair(const void* xa, const void* wa, const float* bias_a, const float* in_norm_a, float* ya_nchw,
+                                      const void* xb, const void* wb, const float* bias_b, const float* in_norm_b, float* yb_nchw,
+                                      int relu_in, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream) {
+  pwr::ConvParams a, b;
+  if (!ya_nchw || !yb_nchw) return PWR_EINVAL;
+  int rc = conv_params_fill(a, xa, wa, bias_a, in_norm_a, relu_in, nullptr, nullptr, ya_nchw, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  rc = conv_params_fill(b, xb, wb, bias_b, in_norm_b, relu_in, nullptr, nullptr, yb_nchw, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  if (dtype != PWR_BF16 || !pwr::conv_wstat_narrow_pair_applicable(a, b, dtype)) return PWR_EUNSUPPORTED;
+  return pwr::launch_conv_wstat(a, &b, (hipStream_t)stream);
+}
+
 // Two data gradients of stride-1 3x3 convs of ONE shape (pwr_conv_fwd_stats in its norm-backward form: x = dy, kind-1 pack, no bias, no
 // prologue; nb_partial = the reductions of the norm backward of the tensor the gradient belongs to) as one launch: the two regression
 // heads walk their three 128 -> 128 convs backwards in lock-step (model.py:54-65 / :103-114)

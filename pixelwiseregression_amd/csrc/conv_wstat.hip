@@ -845,6 +845,11 @@ int launch_conv_wstat(const ConvParams& pa, const ConvParams* pb, hipStream_t s)
   return (int)hipGetLastError();
 }
 
+bool conv_wstat_narrow_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype) {
+  return conv_wstat_narrow_applicable(a, dtype) && conv_wstat_narrow_applicable(b, dtype) && a.B == b.B && a.H == b.H && a.W == b.W &&
+         (a.in_norm != nullptr) == (b.in_norm != nullptr) && a.relu_in == b.relu_in && a.B * (a.H / 4) * (a.W / 32) >= 32;
+}
+
 bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype) {
   return conv_wstat_applicable(a, dtype) && conv_wstat_applicable(b, dtype) && a.B == b.B && a.H == b.H && a.W == b.W &&
          (a.in_norm != nullptr) == (b.in_norm != nullptr) && (a.st_partial != nullptr) == (b.st_partial != nullptr) &&

@@ -844,14 +844,21 @@ struct Engine {
     conv_fwd_pair(f, nullptr, hp.c0, hp.n0, hp.h1, f, nullptr, hd.c0, hd.n0, hd.h1, tr);
     conv_fwd_pair(hp.h1, &hp.n0, hp.c1, hp.n1, hp.h2, hd.h1, &hd.n0, hd.c1, hd.n1, hd.h2, tr);
     conv_fwd_pair(hp.h2, &hp.n1, hp.c2, hp.n2, hp.h3, hd.h2, &hd.n1, hd.c2, hd.n2, hd.h3, tr);
-    for (int k = 0; k < 2; ++k) {
-      const Head& h = *hs[k];
-      const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3;
-      const int out_sel = k;
+    {
+      // the two last convs (128 -> J, fp32 NCHW maps): ONE launch where the narrow weight-stationary kernel takes the shape, else two
+      const Tn ha = hp.h3, hb = hd.h3; const NormL na = hp.n2, nb = hd.n2; const ConvL ca = hp.c3, cb = hd.c3;
       fwd.push_back([=](Ctx& c) {
-        float* dst = out_sel == 0 ? (float*)(c.arena + z_off) : c.out_D[stage_idx];
-        return pwr_conv_fwd(c.arena + h3.off, c.packs + c3.pack_f, c.params + c3.b, (float*)(c.arena + n2.state),
-                            1, nullptr, nullptr, dst, Bc, h3.H, h3.W, c3.Cin, Jc, c3.k, 1, 0, dt, c.stream);
+        float* za = (float*)(c.arena + z_off);
+        float* zb = c.out_D[stage_idx];
+        int rc = pwr_conv_fwd_nchw_pair(c.arena + ha.off, c.packs + ca.pack_f, c.params + ca.b, (float*)(c.arena + na.state), za,
+                                        c.arena + hb.off, c.packs + cb.pack_f, c.params + cb.b, (float*)(c.arena + nb.state), zb,
+                                        1, Bc, ha.H, ha.W, ca.Cin, Jc, ca.k, dt, c.stream);
+        if (rc != PWR_EUNSUPPORTED) return rc;
+        rc = pwr_conv_fwd(c.arena + ha.off, c.packs + ca.pack_f, c.params + ca.b, (float*)(c.arena + na.state),
+                          1, nullptr, nullptr, za, Bc, ha.H, ha.W, ca.Cin, Jc, ca.k, 1, 0, dt, c.stream);
+        if (rc) return rc;
+        return pwr_conv_fwd(c.arena + hb.off, c.packs + cb.pack_f, c.params + cb.b, (float*)(c.arena + nb.state),
+                            1, nullptr, nullptr, zb, Bc, hb.H, hb.W, cb.Cin, Jc, cb.k, 1, 0, dt, c.stream);
       });
     }
     const int Jp = pad_narrow(J);

@@ -96,6 +96,21 @@ def conv_fwd(x, wpack, cout, ksize, stride=1, bias=None, norm=None, relu_in=True
     return y, yn
 
 
+def conv_fwd_nchw_pair(xa, wa, xb, wb, cout, ksize, bias_a=None, bias_b=None, norm_a=None, norm_b=None, relu_in=True):
+    """two conv_fwd(..., nhwc_out=False, nchw_out=True) of one shape as ONE launch (the heads' last convs); None where the shape has no such
+    launch (PWR_EUNSUPPORTED)"""
+    l = _lib.lib()
+    B, H, W, Cin = xa.shape
+    ya = torch.empty(B, cout, H, W, dtype=torch.float32, device=xa.device)
+    yb = torch.empty(B, cout, H, W, dtype=torch.float32, device=xa.device)
+    rc = l.pwr_conv_fwd_nchw_pair(_p(xa), _p(wa), _p(bias_a), _p(norm_a), _p(ya), _p(xb), _p(wb), _p(bias_b), _p(norm_b), _p(yb),
+                                  int(relu_in), B, H, W, Cin, cout, ksize, _dt(xa), _s(xa))
+    if rc == -2:          # PWR_EUNSUPPORTED
+        return None
+    _lib.check(rc, "pwr_conv_fwd_nchw_pair")
+    return ya, yb
+
+
 def conv_wgrad(x, dy, cout_real, ksize, stride=1, norm=None, relu_in=True, splits=8, dw=None, cin_real=None):
     l = _lib.lib()
     B, H, W, Cin = x.shape

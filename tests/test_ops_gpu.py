@@ -198,6 +198,29 @@ def test_conv_forward_nchw_out(dtype, J, H, Cin):
     assert_close(yn.double().cpu(), ref, fp32_out_tol(dtype), "conv nchw out")
 
 
+@pytest.mark.parametrize("J,B,H,W", [(14, 4, 64, 64), (21, 3, 36, 96), (32, 9, 8, 64)])
+def test_narrow_conv_pair_equals_two_single_launches(J, B, H, W):
+    """pwr_conv_fwd_nchw_pair: the two heads' last convs of a stage in one launch of the narrow weight-stationary kernel -- the bytes of
+    two pwr_conv_fwd launches; a shape the kernel does not take is reported, not computed some other way."""
+    from pixelwiseregression_amd import kernels as K
+    xa, xb = nhwc(rnd(B, 128, H, W, seed=1), torch.bfloat16), nhwc(rnd(B, 128, H, W, seed=2), torch.bfloat16)
+    wa, wb = rnd(J, 128, 3, 3, seed=3, scale=0.05).float().to(DEV), rnd(J, 128, 3, 3, seed=4, scale=0.05).float().to(DEV)
+    ba, bb = rnd(J, seed=5).float().to(DEV), rnd(J, seed=6).float().to(DEV)
+    g = torch.Generator().manual_seed(7)
+    sta = torch.stack([torch.randn(B, 128, generator=g) * 0.2, torch.ones(B, 128), torch.rand(B, 128, generator=g) + 0.5, torch.randn(B, 128, generator=g) * 0.2]).contiguous().to(DEV)
+    stb = torch.stack([torch.randn(B, 128, generator=g) * 0.2, torch.ones(B, 128), torch.rand(B, 128, generator=g) + 0.5, torch.randn(B, 128, generator=g) * 0.2]).contiguous().to(DEV)
+    pa, pb = K.pack_conv(wa, 0, K.BF16), K.pack_conv(wb, 0, K.BF16)
+    pair = K.conv_fwd_nchw_pair(xa, pa, xb, pb, J, 3, bias_a=ba, bias_b=bb, norm_a=sta, norm_b=stb)
+    assert pair is not None
+    _, ya = K.conv_fwd(xa, pa, J, 3, 1, bias=ba, norm=sta, nhwc_out=False, nchw_out=True)
+    _, yb = K.conv_fwd(xb, pb, J, 3, 1, bias=bb, norm=stb, nhwc_out=False, nchw_out=True)
+    assert float(ya.abs().max()) > 0 and torch.equal(pair[0], ya) and torch.equal(pair[1], yb)
+    # 64 input channels: not that kernel's shape
+    x64 = nhwc(rnd(B, 64, H, W, seed=1), torch.bfloat16)
+    p64 = K.pack_conv(rnd(J, 64, 3, 3, seed=3).float().to(DEV), 0, K.BF16)
+    assert K.conv_fwd_nchw_pair(x64, p64, x64, p64, J, 3) is None
+
+
 @pytest.mark.parametrize("J", [14, 21, 1, 32])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 64), (5, 36, 96), (1, 64, 32), (9, 8, 32)])
 @pytest.mark.parametrize("form", ["plain", "norm"])
