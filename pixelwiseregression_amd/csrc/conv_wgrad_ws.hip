@@ -13,21 +13,25 @@
 // issue no vector-memory instruction at all, so their LDS reads are ordinary compiler-visible loads (the wait-count pass has no
 // LDS-DMA in their path to fence with vmcnt(0)): no inline-asm read whose result arrives behind the compiler's back, which is what
 // conv_wgrad_dma.hip needs its code-object scan for.  The loader waves' LDS accesses ARE inline asm (they sit behind LDS-DMAs in
-// flight), but every read is one asm block that ends in its own s_waitcnt: an output is defined when the statement ends.
+// flight) and are SPLIT: tile_read() issues the reads of a landed tile without a wait, tile_wait() is the s_waitcnt lgkmcnt(0) that
+// defines their outputs -- the arithmetic of the tile before runs in between.  Nothing the compiler knows orders a use of those outputs
+// behind tile_wait(): that is what the code-object scan of the build (codeobj_scan.py: no use of an LDS read in flight) checks for
+// this kernel too.
 //
 // Same decomposition as conv_wgrad3_kernel / conv_wgrad3d_kernel -- workgroup = (split, kernel row ky), K step = 32 output pixels
 // of one image row with a 34-pixel input row segment serving kx = 0, 1, 2, per-accumulator MFMA sequence (step by step, K half
 // by K half) -- so the slabs are bit-identical to theirs at the same split count, and the same reduce finishes the job.
 //
-// LDS: a ring of NS = 6 stages of [34 px][128 ci] + [32 px][128 co] bf16 rows (17 KiB), 16-byte slots XOR-swizzled by (row & 3) so
+// LDS: a ring of NS = 7 stages (PWR_WS_NS; D = NS - 1 = 6) of [34 px][128 ci] + [32 px][128 co] bf16 rows (17 KiB each, 119 KiB + the norm
+// states of up to 8 samples = ~131 KiB per workgroup), 16-byte slots XOR-swizzled by (row & 3) so
 // that the four pixel rows of a ds_read_b64_tr_b16 group fall on different bank quarters; the swizzle and the halo go into the
 // per-lane SOURCE address of the DMA (cdna_hip_programming.md rule 21).  Per K step s, between barrier s and barrier s + 1:
 //   MFMA waves    read stage s (the first fragments were read ahead during step s - 1), 24 MFMAs each
-//   loader waves  issue the DMA of step s + 5 into the stage read during step s - 1; normalise the tile of step s + 2 in place;
-//                 wait until their own pieces of step s + 3 have landed (counted vmcnt: steps s + 4, s + 5 stay in flight)
-// so a DMA has three K steps to land (a ring of 8 stages -- five steps to land -- measured no faster in the step and 3 - 7 % slower
-// isolated: the loop is not latency-bound), a tile is normalised one full step before it is read, and a stage is overwritten only after
-// a barrier every MFMA wave reached with its reads retired.
+//   loader waves  issue the DMA of step s + D (= s + 6) into the stage read during step s - 1; normalise the tile of step s + 2 in place;
+//                 wait until their own pieces of step s + 3 have landed (counted vmcnt: the steps behind it stay in flight)
+// so a DMA has D - 3 K steps to land (the ring was 6 stages when the kernel was written; 7 measured 1 - 2 % faster in the step, 8 no
+// faster and 3 - 7 % slower isolated: the loop is not latency-bound), a tile is normalised one full step before it is read, and a stage is
+// overwritten only after a barrier every MFMA wave reached with its reads retired.
 #include <cstdlib>
 #include <type_traits>
 

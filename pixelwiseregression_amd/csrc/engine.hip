@@ -270,6 +270,9 @@ struct Engine {
     timed.push_back({phase, tag, ev});
   }
 #endif
+  // Bump allocation, once per plan: every activation / gradient buffer has its own arena range for the life of the plan (nothing is aliased
+  // across layers or backward segments).  The single join of the side streams after the LAST backward segment (pwr_engine_backward) relies
+  // on exactly that: a chain op of a later segment can never overwrite what a side-stream op of an earlier one still reads.
   size_t alloc(size_t bytes, const char* tag = "") {
     size_t o = arena_bytes;
     arena_bytes += (bytes + 255) / 256 * 256;
@@ -1415,7 +1418,11 @@ extern "C" int pwr_engine_backward(void* h, const void* const* gouts, int seg, l
 #ifdef PWR_DEBUG_BUILD
     if (e->timing) e->mark("backward segment " + std::to_string(seg), nullptr, st);
 #endif
-    const bool join_now = e->join_each_segment || seg + 1 == (int)e->bwd.size();
+    // INVARIANTS this rests on: (1) no chain op of segment k + 1 writes a buffer that a side-stream op of segment k still reads -- arena
+    // offsets are handed out once per plan by a bump allocator (alloc(): no gradient or activation buffer is ever aliased across segments)
+    // and each side stream has its own split-K slab; (2) every consumer of a segment's parameter gradients before the last segment calls
+    // pwr_engine_wait_segment.  A segment that FAILED joins at once: the next forward must not start beside side work still in flight.
+    const bool join_now = e->join_each_segment || seg + 1 == (int)e->bwd.size() || rc != 0;
     for (int k = 0; join_now && c.use_side && k < c.n_side; ++k) {
       hipEventRecord(c.ev_join[k], c.side[k]);
       hipStreamWaitEvent((hipStream_t)st, c.ev_join[k], 0);
