@@ -55,6 +55,11 @@ struct WstatArgs {
   ConvParams job[2];
   int njobs, wgs_per_job;
   int tiles_q, tiles_r;      // tiles / wgs_per_job and the remainder: workgroup c of a job takes tiles [c q + min(c, r), ... + q + (c < r))
+  // (everything a workgroup would have to DIVIDE for, precomputed: eight integer divisions were ~150 of the ~250 scalar instructions a
+  // workgroup issued before its first load)
+  int job_shift, nx_shift;   // njobs = 1 << job_shift; the workgroups of a job sit on nx = 8 >> job_shift XCD labels, nx = 1 << nx_shift
+  int xq, xr;                // wgs_per_job / nx and the remainder
+  unsigned magic_img, magic_x;   // ceil(2^32 / tiles_img), ceil(2^32 / tiles_x): n / d = mulhi(n, magic), one too large at most (fixed up)
 };
 
 #ifdef PWR_DEBUG_BUILD
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // the 16x16x32 build ran its K loops at 1.36x the matrix-pipe time.)  The plain LDS image (pixel pitch 272 B, channel slot c at 16 c)
   // is conflict-free for these reads: the 32 lanes of a half read ONE slot of 32 consecutive pixels.
   const int pc = lane & 31, hh = lane >> 5;
-  const int job = blockIdx.x % a.njobs, wgj = blockIdx.x / a.njobs;
+  const int job = blockIdx.x & (a.njobs - 1), wgj = blockIdx.x >> a.job_shift;
   const ConvParams& p = a.job[job];
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const int HW = p.H * p.W;
@@ -217,9 +222,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // this workgroup's tiles: a contiguous range (consecutive tiles share halo rows: L2 / L1 hits), ranges of one XCD's workgroups adjacent
   int t, t_end;
   {
-    const int NW = a.wgs_per_job, nx = 8 / a.njobs;              // workgroups of one job sit on `nx` XCD labels (blockIdx % 8: speed only)
-    const int q = NW / nx, r = NW % nx, xl = wgj % nx;
-    const int c = (xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q) + wgj / nx;
+    const int nx = 8 >> a.job_shift;                             // workgroups of one job sit on `nx` XCD labels (blockIdx % 8: speed only)
+    const int q = a.xq, r = a.xr, xl = wgj & (nx - 1);
+    const int c = (xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q) + (wgj >> a.nx_shift);
     t = c * a.tiles_q + (c < a.tiles_r ? c : a.tiles_r);          // (no 64-bit division in the prologue)
     t_end = t + a.tiles_q + (c < a.tiles_r ? 1 : 0);
   }
@@ -355,9 +360,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // ---- prologue: the first patch's loads go out FIRST, the 72 weight loads behind them; the patch is normalised and written while the
   // weights are still landing (vmcnt counts in order: its wait does not cover them), and only then does anything wait for the weights.
   TileCo cur;
-  cur.b = t / tiles_img;
   {
-    const int tr = t - cur.b * tiles_img, tyi = tr / tiles_x;
+    auto div = [](int n, int d, unsigned magic) __attribute__((always_inline)) {
+      int q = (int)__umulhi((unsigned)n, magic);
+      q -= q * d > n ? 1 : 0;                  // (the rounded-up reciprocal overshoots by one at most; d = 1 -- magic 2^32 - 1 -- undershoots by one)
+      return q + ((q + 1) * d <= n ? 1 : 0);
+    };
+    cur.b = div(t, tiles_img, a.magic_img);
+    const int tr = t - cur.b * tiles_img, tyi = div(tr, tiles_x, a.magic_x);
     cur.y0 = tyi * 4; cur.x0 = (tr - tyi * tiles_x) * 32;
   }
   TileCo nx1 = (t + 1 < t_end) ? tile_next(cur) : cur;            // (the last tiles re-stage themselves: branch-free K loops)
@@ -838,6 +848,11 @@ int launch_conv_wstat(const ConvParams& pa, const ConvParams* pb, hipStream_t s)
   if (per > tiles) per = tiles;
   a.wgs_per_job = per;
   a.tiles_q = tiles / per; a.tiles_r = tiles % per;
+  a.job_shift = pb ? 1 : 0; a.nx_shift = pb ? 2 : 3;
+  a.xq = per / (8 >> a.job_shift); a.xr = per % (8 >> a.job_shift);
+  const unsigned tiles_x = (unsigned)(pa.W / 32), tiles_img = tiles_x * (unsigned)(pa.H / 4);
+  a.magic_img = tiles_img > 1 ? (unsigned)(((1ull << 32) + tiles_img - 1) / tiles_img) : 0xFFFFFFFFu;
+  a.magic_x = tiles_x > 1 ? (unsigned)(((1ull << 32) + tiles_x - 1) / tiles_x) : 0xFFFFFFFFu;
   const int kind = pa.y_nchw ? 3 : (pa.st_partial ? 1 : (pa.nb_partial ? 2 : 0));
   dim3 grid(per * a.njobs);
   if (pa.in_norm) launch_kind<true>(a, kind, grid, s);
