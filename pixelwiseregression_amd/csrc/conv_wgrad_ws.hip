@@ -138,44 +138,55 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
     // pieces lw, lw + 4, ... -- five for wave 0 (it holds the halo pixels 0 and 33, pieces 0 and 8: one clamp delta each), four for the others
     constexpr int I_R = ((XROWS - 1) * RBX / 1024) / NLW;
     static_assert(((XROWS - 1) * RBX / 1024) % NLW == 0 && I_R != 0 && I_R < NCW && NCH == NLW * (NCW - 1) + 1, "wave 0: NCW pieces, the others NCW - 1");
-    int d_lds[NCW], d_off[NCW], d_dl = 0, d_dr = 0;
-    bool d_isx[NCW];
+    // (round 5: the pieces go out as RAW BUFFER loads to LDS -- a per-lane 32-bit byte offset that is constant over the steps, the step's
+    // tile origin as a scalar 32-bit soffset, the tensor base in a resource descriptor: two instructions per piece.  As 64-bit global
+    // pointers every piece cost eight -- a select of the base, a sign extension, a 64-bit vector add -- and the loader waves, which share
+    // their SIMD's issue port with an MFMA wave, were the longer side of every K step: ~300 instructions against 24 MFMAs.  Which tensor a
+    // piece belongs to is a compile-time property of (piece index, wave 0 or not).  The input resource's base lies one pixel BEFORE the
+    // tensor, so that the halo pixel's offset is not negative; tensors below 4 GiB: wgrad3w_applicable.)
+    static_assert(XCH % NLW == 1, "piece i of a loader wave is an input piece for every wave != 0 alike");
+    int d_lds[NCW], d_voff[NCW], d_dl = 0, d_dr = 0;
 #pragma unroll
     for (int i = 0; i < NCW; ++i) {
       int c = lw + NLW * i;
       if (c >= NCH) c = lw;                         // (not issued: only wave 0 has a fifth piece)
       d_lds[i] = c * 1024;
-      d_isx[i] = c < XCH;
+      const bool isx = c < XCH;
       const int cx_ = c < XCH ? c : c - XCH;
       const int q = 64 * cx_ + lane;
       // row and physical slot of this lane's 16 bytes, and the channel slot that belongs there (input tile: SPR slots per pixel; dy: 16)
       const int xr0 = q / SPR, xs1 = q % SPR, yr0 = q >> 4, ys1 = q & 15;
       const int xr = xr0 < XROWS ? xr0 : XROWS - 1;   // rows beyond the 34th: nobody reads them
-      const int xoff = (xr - 1) * p.Cin + ci0 + 8 * (xs1 ^ swzbits<RBX>(xr0));
+      const int xoff = xr * p.Cin + ci0 + 8 * (xs1 ^ swzbits<RBX>(xr0));            // (relative to the pixel before the tile's first)
       const int yoff = yr0 * p.Cout + co0 + 8 * (ys1 ^ swzbits<RBY>(yr0));
-      d_off[i] = d_isx[i] ? xoff : yoff;
-      if (i == 0) d_dl = (d_isx[i] && xr == 0) ? p.Cin : 0;              // out-of-image halo: clamped into the row, zeroed in LDS afterwards
-      if (i == I_R) d_dr = (d_isx[i] && xr == XROWS - 1) ? -p.Cin : 0;
+      d_voff[i] = (isx ? xoff : yoff) * 2;
+      if (i == 0) d_dl = (isx && xr == 0) ? p.Cin * 2 : 0;              // out-of-image halo: clamped into the row, zeroed in LDS afterwards
+      if (i == I_R) d_dr = (isx && xr == XROWS - 1) ? -p.Cin * 2 : 0;
     }
     const bool five = lw == 0;                          // (wave-uniform)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)) - (size_t)p.Cin * 2, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, -1, 0x00020000);
     // next step to ISSUE.  NHWC rows are contiguous, so the dy tile of step t starts at pixel 32 t and the input tile of kernel row ky at
     // pixel 32 t + (ky - 1) W (an out-of-image row: the dy tile's own pixels, zero-filled by the pass): one running pixel offset
     int ix = x0, iyy = y0, issued = 0;
-    long long ipix = (long long)step0 * KP;
-    const long long kyoff = (long long)(ky - 1) * p.W;
+    int ipix = step0 * KP;
+    const int kyoff = (ky - 1) * p.W;
     auto issue = [&](int soff, auto FIVE) {
+      constexpr bool F5 = decltype(FIVE)::value;
       const int iy = iyy + ky - 1;
       const bool rowok = iy >= 0 && iy < p.H;
-      const T* xrow = x + (ipix + (rowok ? kyoff : 0)) * p.Cin;
-      const T* drow = dy + ipix * p.Cout;
-      const int first = ix == 0 ? 1 : 0, last = ix == tiles_x - 1 ? 1 : 0;
+      const unsigned sx = (unsigned)((ipix + (rowok ? kyoff : 0)) * p.Cin) * 2u, sy = (unsigned)(ipix * p.Cout) * 2u;
+      const int first = ix == 0 ? d_dl : 0, last = ix == tiles_x - 1 ? d_dr : 0;
+      typedef __attribute__((address_space(3))) void* ldsp;
       char* base = smem + soff;
 #pragma unroll
       for (int i = 0; i < NCW; ++i) {
-        if (i == NCW - 1 && !decltype(FIVE)::value) break;
-        const T* src = (d_isx[i] ? xrow : drow) + (d_off[i] + (i == 0 ? first * d_dl : 0) + (i == I_R ? last * d_dr : 0));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(base + d_lds[i]), 16, 0, 0);
+        if (i == NCW - 1 && !F5) break;
+        constexpr int XP = (XCH + NLW - 1) / NLW;         // wave 0 has XP input pieces, the others XP - 1
+        const bool isx = i < (F5 ? XP : XP - 1);
+        const int vo = d_voff[i] + (i == 0 ? first : 0) + (i == I_R ? last : 0);
+        if (isx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (ldsp)(base + d_lds[i]), 16, vo, (int)sx, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (ldsp)(base + d_lds[i]), 16, vo, (int)sy, 0, 0);
       }
       ++issued;
       ipix += KP;
@@ -461,6 +472,7 @@ bool wgrad3w_applicable(const WgradParams& p) {
   const int on = PWR_DBG_ENV("PWR_WGRAD3W", 1);
   const bool cin_ok = p.Cin % 128 == 0 ? p.CinPad == p.Cin : (p.Cin == 64 && on == 3);
   if (!on || p.ksize != 3 || p.stride != 1 || p.W % 32 || p.M % 32 || !cin_ok || p.Cout % 128 || p.CoutPad != p.Cout) return false;
+  if (((long long)p.M + 2 * p.W) * (p.Cin > p.Cout ? p.Cin : p.Cout) * 2 >= (1ll << 32)) return false;      // (32-bit byte offsets of the buffer loads)
   if (on == 2 && p.in_norm) return false;      // (2: only the layers whose operand carries no norm; the norm-fed ones take the register-staged kernel)
   return p.steps_per_split <= (ws::MAXSB - 1) * (p.H * p.W / 32);
 }
