@@ -67,7 +67,7 @@ long long* wstat_stamps();        // conv_patch.hip: the buffer of pwr_debug_set
 #endif
 
 // (debug build variants, tools/build_debug.py -DWST_DBG=bits: timing by elimination, results WRONG -- 1 no staging in the K loops, 2 no epilogue
-// in the K loops, 4 no fragment reads in the K loops, 8 no MFMAs)
+// in the K loops, 4 no fragment reads in the K loops, 8 no MFMAs, 16 (KIND 2) the y loads of the statistics from one cache-hot row)
 #ifndef WST_DBG
 #define WST_DBG 0
 #endif
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       if (KIND == 2 && u == 0) {       // y of the NEXT row in processing order (rows 0, 1 of `cn` = the current tile; 2, 3 of the tile c)
         const int nr = (row + 1) & 3;
         const TileCo& cc = row == 3 ? cn : c;
-        const char* yr = reinterpret_cast<const char*>(p.nb_y) + ((size_t)cc.b * HW + (size_t)(cc.y0 + nr) * W + cc.x0) * (CIN * 2);
+        const char* yr = reinterpret_cast<const char*>(p.nb_y) + ((WST_DBG & 16) ? (size_t)0 : ((size_t)cc.b * HW + (size_t)(cc.y0 + nr) * W + cc.x0) * (CIN * 2));   // (16: always the tensor's first row -- cache-hot: what the loads' latency costs)
         const unsigned o16 = (unsigned)((lane & 15) * CIN + slot_ch) * 2u;
         if (nr & 1) { yvB0 = *reinterpret_cast<const u32x4*>(yr + o16); yvB1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2); }
         else { yvA0 = *reinterpret_cast<const u32x4*>(yr + o16); yvA1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2); }
@@ -665,10 +665,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // xor 4 = row_shl:4 into banks 0 and 2 + row_shr:4 into banks 1 and 3 (two moves and an add).  A micro-op handles one pair of sums
   // 2 j, 2 j + 1 of (s1[0 .. 7], s2[0 .. 7]).
   float bt0_ = 0.f, bt1_ = 0.f, bt2 = 0.f, bt3 = 0.f;
-  auto dpp = [](float old, float src, auto CTRL, auto BANK) __attribute__((always_inline)) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), decltype(CTRL)::value, 0xF,
-                                                                  decltype(BANK)::value, false));
-  };
+  // As inline asm: through __builtin_amdgcn_update_dpp hipcc emitted v_mov_b32 (a copy), s_nop, v_mov_b32_dpp, v_add_f32 for what ONE
+  // v_add_f32_dpp does (the DPP operand on the add itself) -- 13 instructions per sum where 6 do, and every instruction of this loop costs
+  // issue time.  The hazard the compiler's s_nop covered -- a DPP operand read needs two wait states behind a vector write of that
+  // register -- is kept by the ORDER of the items: the same pair of sums comes up again eight items later (xor 1 -> xor 2 -> xor 4, xor 4
+  // -> xor 8), the three xor-4 items of a pair alternate with another pair's (two instructions in between).
+#define PWR_DPP_ADD(x, ctrl) asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
+#define PWR_DPP_MOV(d, x, ctrl, bank) asm volatile("v_mov_b32_dpp %0, %1 " ctrl " row_mask:0xf bank_mask:" bank : "+v"(d) : "v"(x))
   auto bfly_micro = [&](const int b) __attribute__((always_inline)) {
     if constexpr (KIND != 0) {
       // (b = 0 .. 15: xor 1, xor 2 over the eight pairs; 16 .. 39: per pair its three xor-4 ops in a row -- they share the two temporaries --;
@@ -679,15 +682,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       float& x0 = j < 4 ? s1[2 * j] : s2[2 * (j - 4)];
       float& x1 = j < 4 ? s1[2 * j + 1] : s2[2 * (j - 4) + 1];
       float& bt0 = (j & 1) ? bt2 : bt0_; float& bt1 = (j & 1) ? bt3 : bt1_;
-      typedef std::integral_constant<int, 0xF> ALL;
-      if (step == 0) { x0 += dpp(x0, x0, std::integral_constant<int, 0xB1>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0xB1>{}, ALL{}); }
-      else if (step == 1) { x0 += dpp(x0, x0, std::integral_constant<int, 0x4E>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0x4E>{}, ALL{}); }
-      else if (step == 2) { bt0 = dpp(x0, x0, std::integral_constant<int, 0x104>{}, std::integral_constant<int, 0x5>{}); bt1 = dpp(x1, x1, std::integral_constant<int, 0x104>{}, std::integral_constant<int, 0x5>{}); }
-      else if (step == 3) { bt0 = dpp(bt0, x0, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xA>{}); bt1 = dpp(bt1, x1, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xA>{}); }
+      if (step == 0) { PWR_DPP_ADD(x0, "quad_perm:[1,0,3,2]"); PWR_DPP_ADD(x1, "quad_perm:[1,0,3,2]"); }
+      else if (step == 1) { PWR_DPP_ADD(x0, "quad_perm:[2,3,0,1]"); PWR_DPP_ADD(x1, "quad_perm:[2,3,0,1]"); }
+      else if (step == 2) { PWR_DPP_MOV(bt0, x0, "row_shl:4", "0x5"); PWR_DPP_MOV(bt1, x1, "row_shl:4", "0x5"); }
+      else if (step == 3) { PWR_DPP_MOV(bt0, x0, "row_shr:4", "0xa"); PWR_DPP_MOV(bt1, x1, "row_shr:4", "0xa"); }
       else if (step == 4) { x0 += bt0; x1 += bt1; }
-      else { x0 += dpp(x0, x0, std::integral_constant<int, 0x128>{}, ALL{}); x1 += dpp(x1, x1, std::integral_constant<int, 0x128>{}, ALL{}); }
+      else { PWR_DPP_ADD(x0, "row_ror:8"); PWR_DPP_ADD(x1, "row_ror:8"); }
     }
   };
+#undef PWR_DPP_ADD
+#undef PWR_DPP_MOV
   // the finished sums of tile c: lane li = 0 of every row writes its slot's slab entries; then the sums restart
   auto stats_write = [&](const TileCo& c, const bool write) __attribute__((always_inline)) {
     if constexpr (KIND != 0) {
@@ -756,7 +760,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
           // (half B finishes tile rows 0 - 1 of this tile -- row 0 carries the E_A0 extra ops --, half A rows 2 - 3 of the previous one and
           // then the butterfly of its sums)
           constexpr int r0n = E_ROW + (half ? E_A0 : 0);
-          constexpr bool bf_any = (half ? e1 - 1 - EHA : e1 - 1) - r0n >= E_ROW;
           static_for<e1 - e0>([&](auto J) __attribute__((always_inline)) {
             constexpr int ea = e0 + decltype(J)::value, eu = half ? ea - EHA : ea;
             if (eu < r0n) epi_micro(half ? 0 : 2, eu, half ? cur : prev, cur);
@@ -768,10 +771,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
           if (KIND != 0) {
             asm volatile("" : "+v"(oL), "+v"(oH), "+v"(bt0_), "+v"(bt1_), "+v"(bt2), "+v"(bt3));
             if (KIND == 2) asm volatile("" : "+v"(g0), "+v"(g1));
-            if (bf_any) {
-              asm volatile("" : "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
-              asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(s2[4]), "+v"(s2[5]), "+v"(s2[6]), "+v"(s2[7]));
-            }
+            // (the butterfly's DPP instructions are volatile asm themselves: they stay where they are written without a tie)
           }
         }
         __builtin_amdgcn_sched_barrier(0);
