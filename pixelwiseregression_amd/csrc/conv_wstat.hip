@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // per-lane constant offset.
   const unsigned yoff = (unsigned)(pc * CIN + n) * 2u;
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rnb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.nb_y), 0, -1, 0x00020000);      // (KIND 2)
   // KIND 1 (forward statistics of the norm that follows, conv_common.h EpiStats): per 8-channel slot and pixel column li = col % 16 the old
   // kernel's thread adds the pixels (it, li), it = 0 .. 7 (= tile row it / 2, column 16 (it % 2) + li), IN THAT ORDER, then a butterfly over
   // li.  Here lane (col, h) holds 16 channels of the pixels (row, col): the lanes col and col ^ 16 (rows 16 lanes apart in the wave) exchange
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
   u32x4 eo, oL, oH;
   float s1[8], s2[8], a0[8];
+  bool gc0 = false, gc1 = false;
   float a1[8], a2[8], a3[8], g0 = 0.f, g1 = 0.f;                  // (KIND 2: rstd, scale, beta of the slot's channels; the masked gradients of a pair)
   // (KIND 2: y of the slot's channels at a row's two pixels, two sets: a row's loads are issued with the FIRST micro-op of the row before it --
   // some 45 slots = 1400 cycles ahead; issued with its own row they arrived ~1000 cycles late, 4 x per tile: the tensor comes from HBM)
@@ -599,10 +601,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       if (KIND == 2 && u == 0) {       // y of the NEXT row in processing order (rows 0, 1 of `cn` = the current tile; 2, 3 of the tile c)
         const int nr = (row + 1) & 3;
         const TileCo& cc = row == 3 ? cn : c;
-        const char* yr = reinterpret_cast<const char*>(p.nb_y) + ((WST_DBG & 16) ? (size_t)0 : ((size_t)cc.b * HW + (size_t)(cc.y0 + nr) * W + cc.x0) * (CIN * 2));   // (16: always the tensor's first row -- cache-hot: what the loads' latency costs)
-        const unsigned o16 = (unsigned)((lane & 15) * CIN + slot_ch) * 2u;
-        if (nr & 1) { yvB0 = *reinterpret_cast<const u32x4*>(yr + o16); yvB1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2); }
-        else { yvA0 = *reinterpret_cast<const u32x4*>(yr + o16); yvA1 = *reinterpret_cast<const u32x4*>(yr + o16 + 16 * CIN * 2); }
+        // (16: always the tensor's first row -- cache-hot: what the loads' latency costs.  Measured: nothing)
+        const int yso = (WST_DBG & 16) ? 0 : (int)((unsigned)((cc.b * H + cc.y0 + nr) * W + cc.x0) * (CIN * 2));
+        const int o16 = (int)((unsigned)((lane & 15) * CIN + slot_ch) * 2u);
+        if (nr & 1) { yvB0 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16, yso, 0); yvB1 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16 + 16 * CIN * 2, yso, 0); }
+        else { yvA0 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16, yso, 0); yvA1 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16 + 16 * CIN * 2, yso, 0); }
       }
       return;
     }
@@ -624,8 +627,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       else if (o == 1) { g0 = lo_f(gp); g1 = hi_f(gp); }
       else if (o == 2) { f0 = f0 - a0[2 * j]; f1 = f1 - a0[2 * j + 1]; }
       else if (o == 3) { f2 = fmaf(f0, a2[2 * j], a3[2 * j]); f3 = fmaf(f1, a2[2 * j + 1], a3[2 * j + 1]); }
-      else if (o == 4) { g0 = (!nb_relu || f2 > 0.f) ? g0 : 0.f; }
-      else if (o == 5) { g1 = (!nb_relu || f3 > 0.f) ? g1 : 0.f; }
+      // (the two compares in one item, the two selects in the next: a select right behind the compare that wrote its mask register waits
+      // two states for it.  No ReLU: nb_state_load made f2, f3 = 1)
+      else if (o == 4) { gc0 = f2 > 0.f; gc1 = f3 > 0.f; }
+      else if (o == 5) { g0 = gc0 ? g0 : 0.f; g1 = gc1 ? g1 : 0.f; }
       else if (o == 6) { s1[2 * j] += g0; s1[2 * j + 1] += g1; }
       else if (o == 7) { f0 = f0 * a1[2 * j]; f1 = f1 * a1[2 * j + 1]; }
       else { s2[2 * j] = fmaf(g0, f0, s2[2 * j]); s2[2 * j + 1] = fmaf(g1, f1, s2[2 * j + 1]); }
@@ -712,7 +717,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       const size_t plane = (size_t)p.B * CIN;
       const float* st = p.nb_state + (size_t)b * CIN + slot_ch;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { a0[e] = st[e]; a1[e] = st[plane + e]; a2[e] = st[2 * plane + e]; a3[e] = st[3 * plane + e]; }
+      for (int e = 0; e < 8; ++e) {
+        a0[e] = st[e]; a1[e] = st[plane + e];
+        // (no ReLU on that norm: scale 0, beta 1 make the sign test of the masked gradient pass for every element -- one compare + select
+        // per element instead of compare + scalar and + select)
+        a2[e] = nb_relu ? st[2 * plane + e] : 0.f; a3[e] = nb_relu ? st[3 * plane + e] : 1.f;
+      }
     }
   };
 #pragma unroll
