@@ -331,24 +331,34 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       landed(issued - 4);
       int stg = 0, s = 0;                                            // ring stage of step s
       // steady part: s + D < nsteps, so step s + D is issued, tile s + 2 finished, and exactly D - 4 later steps stay in flight
-#pragma nounroll
-      for (; s + D < nsteps; ++s) {
+      // (two steps per trip, the raw tile alternating between two register sets: a copy of twelve registers per step was six of the step's
+      // ~250 instructions, and every instruction of this loop is issue time the MFMA waves wait for)
+      auto steady = [&](f32x4& c0, f32x4& c1, f32x4& c2, f32x4& n0, f32x4& n1, f32x4& n2) __attribute__((always_inline)) {
         __builtin_amdgcn_s_barrier();                                // barrier s: every loader's pieces of tile s + 3 have landed
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         const int s2 = stg + 2 >= NS ? stg + 2 - NS : stg + 2, s3 = stg + 3 >= NS ? stg + 3 - NS : stg + 3;
-        tile_read(s3 * STAGE, rn0, rn1, rn2);
+        tile_read(s3 * STAGE, n0, n1, n2);
         const int istg = stg == 0 ? NS - 1 : stg - 1;                // (s + D) % NS: the stage read during step s - 1
 #ifdef PWR_DEBUG_BUILD
         if (!(p.dbg & 16))                                           // (elimination: no DMA after the prologue)
 #endif
         issue(istg * STAGE, FIVE);
-        tile_finish(s2 * STAGE, rc0, rc1, rc2);
+        tile_finish(s2 * STAGE, c0, c1, c2);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_s_waitcnt(vmwait((D - 4) * NPW));           // step s + 4 landed (own pieces), every LDS access retired
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        tile_wait(rn0, rn1, rn2);
-        rc0 = rn0; rc1 = rn1; rc2 = rn2;
+        tile_wait(n0, n1, n2);
         stg = stg + 1 == NS ? 0 : stg + 1;
+      };
+#pragma nounroll
+      for (; s + D + 1 < nsteps; s += 2) {
+        steady(rc0, rc1, rc2, rn0, rn1, rn2);
+        steady(rn0, rn1, rn2, rc0, rc1, rc2);
+      }
+      if (s + D < nsteps) {
+        steady(rc0, rc1, rc2, rn0, rn1, rn2);
+        rc0 = rn0; rc1 = rn1; rc2 = rn2;
+        ++s;
       }
       // the last D steps: nothing left to issue, the pipeline drains
 #pragma nounroll
