@@ -259,20 +259,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3w_kernel(WgradPair g) {
       if constexpr (NRM) {
         nr_state();
         f32x4 o0, o1;
-#ifdef PWR_DEBUG_BUILD
-        if (p.dbg & 1) { o0 = r0; o1 = r1; }                       // elimination: no norm arithmetic (raw values stored back)
-        else { o0 = nr_math(r0); o1 = TWO ? nr_math(r1) : r1; }
-#else
         o0 = nr_math(r0); o1 = TWO ? nr_math(r1) : r1;
-#endif
         if (rowzero | zl | zr) {                                   // (wave-uniform, rare: image borders)
           if (rowzero || (zl && nr_row == 0)) o0 = zero4;
           if (rowzero) o1 = zero4;
         }
-#ifdef PWR_DEBUG_BUILD
-        if (p.dbg & 2) asm volatile("" ::"v"(o0), "v"(o1));         // elimination: arithmetic, no stores
-        else
-#endif
+        // (the debug build's elimination switches for this pass -- raw values stored back, arithmetic without stores: round 4 -- are gone: their
+        // out-of-line blocks sat textually behind an LDS read in flight and tripped the build's linear code-object scan)
         {
           asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(o0) : "memory");
           if constexpr (TWO) asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(o1) : "memory");

@@ -732,9 +732,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   int buf = 0;
   TileCo prev = cur;            // (first tile: the "previous tile's" half epilogue stores garbage where this tile's own epilogue writes later)
   constexpr int EHA = e_half(KIND, 0);
+  // (the next tile's offsets and masks are computed BEFORE the barrier that ends a tile -- there a wave waits for the others anyway --,
+  // not between the barrier and the tile's first MFMA; the empty asm keeps them there)
+  LoadCo l1 = load_co(nx1);
+  MaskCo m1_ = mask_co(nx1);
+  auto pin_co = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(l1.voff0), "+v"(l1.voff1), "+v"(l1.voff12), "+v"(m1_.keep0), "+v"(m1_.keep12));
+  };
   for (; t < t_end; ++t) {
-    const LoadCo l1 = load_co(nx1);
-    const MaskCo m1_ = mask_co(nx1);
     const char* pb = fbase + buf * PATCH_BYTES;
     char* nb = smem + (buf ^ 1) * PATCH_BYTES;
 #pragma unroll
@@ -793,10 +798,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loops
-    stamp(4 + 3 * tile_no); ++tile_no;
     prev = cur;
     cur = nx1; nx1 = (t + 2 < t_end) ? tile_next(nx1) : nx1;
+    l1 = load_co(nx1); m1_ = mask_co(nx1);
+    pin_co();
+    __syncthreads();      // the next patch is complete and visible; every wave has left this tile's K loops
+    stamp(4 + 3 * tile_no); ++tile_no;
     buf ^= 1;
   }
   // the last tile's second half
