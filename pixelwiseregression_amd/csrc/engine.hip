@@ -145,13 +145,13 @@ static int elim_mask() {
 // the step takes 0.33 ms less -- but batching several ops behind one event (fewer markers in the chain's queue, each op issued a few
 // chain kernels later) made the step SLOWER, 6.47 ms at one op per event against 6.8 - 7.1 ms at 2 .. 12: what counts is that the
 // parameter-gradient work starts as early as it can, because the chain waits for it at the end of every segment.
-static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op) {
+static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op, bool forked = false) {
   if (elim_mask() & 1) return 0;
   if (!c.use_side || c.n_side == 0) return op(c);
   if (c.defer) { c.deferred.push_back(op); return 0; }
   const int k = c.side_rr;
   c.side_rr = (k + 1) % c.n_side;
-  if (!(elim_mask() & 8)) {     // (bit 3, debug build: side ops NOT ordered behind the chain)
+  if (!forked && !(elim_mask() & 8)) {     // (bit 3, debug build: side ops NOT ordered behind the chain; forked: the caller has ordered the side streams behind the chain already)
     hipEvent_t ev = c.ev_fork[c.fork_rr];
     c.fork_rr = (c.fork_rr + 1) % c.n_fork;
     hipEventRecord(ev, (hipStream_t)c.stream);
@@ -1043,7 +1043,17 @@ struct Engine {
       std::vector<std::function<int(Ctx&)>> d;
       d.swap(c.deferred);
       int rc = 0;
-      for (size_t i = 0; i < d.size() && !rc; ++i) rc = run_on_side(c, d[i]);
+      // ONE fork for the whole batch: every held-back op depends on the chain as it stands here, so both side streams wait for one event
+      // and the ops go out without an event pair each (a dozen ops: ~25 API calls less in a stretch where the host has just issued the
+      // heads' chain and the hourglass backward's small kernels are next)
+      const bool batch = PWR_DBG_ENV("PWR_FLUSH_BATCH", 1) != 0 && c.use_side && c.n_side > 0 && !(elim_mask() & 9) && !d.empty();
+      if (batch) {
+        hipEvent_t ev = c.ev_fork[c.fork_rr];
+        c.fork_rr = (c.fork_rr + 1) % c.n_fork;
+        hipEventRecord(ev, (hipStream_t)c.stream);
+        for (int k = 0; k < c.n_side; ++k) hipStreamWaitEvent(c.side[k], ev, 0);
+      }
+      for (size_t i = 0; i < d.size() && !rc; ++i) rc = run_on_side(c, d[i], batch);
       return rc;
     };
   }
