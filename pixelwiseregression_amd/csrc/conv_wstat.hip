@@ -82,9 +82,19 @@ long long* wstat_stamps();        // conv_patch.hip: the buffer of pwr_debug_set
 #endif
 
 namespace wst {
-constexpr int CIN = 128, KCH = 4, ITERS = 36, PW = 34, PP = 6 * 34, PITCH = CIN * 2 + 16;
-constexpr int NITP = 13;                 // staging vectors per thread: 204 pixels x 16 slots / 256 threads ...
-constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 208 pixels: the last round's 4 surplus pixels are written (never read), no branch
+constexpr int PW = 34, PP = 6 * 34, COUT = 128;
+// Everything that depends on the INPUT channel count CI (128: the heads' convs; 64: the stem's 64 -> 128 conv, model.py:174-176): K steps
+// of 32 channels per tap, the patch pixel's pitch (padded by 16 B), the staging vectors per thread -- 204 pixels x CI / 8 slots / 256
+// threads: 13 (a buffer holds 208 pixels: the last round's surplus pixels are written, never read, no branch) or 7 (224 pixels).
+// A thread stages one 16-byte channel slot of PXR consecutive pixels' worth per round: vectors k < KX are patch row k / VPR, columns
+// PXR (k % VPR) + st_pl; vector KX is the patch's two right columns.
+template <int CI> struct Shape {
+  static_assert(CI == 64 || CI == 128, "input channels");
+  static constexpr int KCH = CI / 32, ITERS = 9 * KCH, PITCH = CI * 2 + 16, SPP = CI / 8, PXR = 256 / SPP, VPR = 32 / PXR, KX = 6 * VPR, NITP = KX + 1;
+  static constexpr int PATCH_BYTES = NITP * PXR * PITCH;
+  static constexpr int SLOTS = ITERS * 8, HSLOTS = ITERS * 4, NSLOTS = ITERS * 2;
+};
+constexpr int MAX_SLOTS = Shape<128>::SLOTS, MAX_NITP = Shape<128>::NITP;
 // Schedule inside the K loops.  A SLOT is one v_mfma_f32_32x32x16_bf16 (288 per tile, 72 in the narrow form; 32 matrix-pipe cycles).  With ONE
 // wave per SIMD the wave that issues the MFMAs issues everything else too, one instruction per four cycles, and the MFMA itself occupies
 // the issue port for a while: measured (tools/csrc_debug/issue_probe.cpp, profiles/r5_issue_probe.jsonl) a slot of MFMA + fragment read +
@@ -93,7 +103,7 @@ constexpr int PATCH_BYTES = NITP * 16 * PITCH;       // ... so a buffer holds 20
 // than three extra instructions: the staging of the next patch (13 vectors x SV items) and the epilogue of the finished half tile are
 // ITEMS with an instruction cost, dealt out to the slots by the compile-time table below -- the epilogue proportionally over its half, the
 // staging in order over what the epilogue leaves of three instructions per slot -- instead of by item count.
-constexpr int SLOTS = ITERS * 8, HSLOTS = ITERS * 4, NSLOTS = ITERS * 2, S_START = 40, LEAD = 40;
+constexpr int S_START = 40, LEAD = 40;
 // staging items of a vector.  Norm form, per channel pair j (i = 5 j + o): {unpack lo, unpack hi (+ the vector's keep value, i = 0)}
 // {- mean x 2} {fma x 2} {ReLU-and-mask x 2: v_med3_f32(x, 0, keep), keep = +inf or 0} {round + pack}; i = 20: the 16-byte LDS store.
 // Plain form: i = 0 .. 3 the mask of one dword, i = 4 the store.
@@ -105,42 +115,47 @@ __host__ __device__ constexpr int s_cost(bool nrm, bool nar, int i) {
 }
 // epilogue items per tile row (see epi_micro): 14 base items (6 x two vector instructions, a store) per 16 channels, then the statistics
 __host__ __device__ constexpr int e_st(int kind) { return kind == 1 ? 34 : (kind == 2 ? 2 + 72 : 0); }
-__host__ __device__ constexpr int e_a0(int kind) { return kind == 1 ? 6 : 0; }
-__host__ __device__ constexpr int e_bf(int kind) { return (kind == 1 || kind == 2) ? 48 : 0; }
+// (the shift of the forward statistics: 128 input channels -- the ROUNDED output at the tile's first pixel, like the patch kernel's one-pass
+// epilogue; 64 -- its fp32 value, like the two-pass epilogue of the patch kernel form that layer ran on: the sums are bit-identical to
+// the kernel they replace in both cases)
+__host__ __device__ constexpr int e_a0(int kind, int ci = 128) { return kind == 1 ? (ci == 64 ? 8 : 6) : 0; }
+__host__ __device__ constexpr int e_bf(int kind, int ci = 128) { return (kind == 1 || kind == 2) ? (ci == 64 ? 40 : 48) : 0; }
 __host__ __device__ constexpr int e_row(int kind) { return 14 + e_st(kind); }
-__host__ __device__ constexpr int e_half(int kind, int half) { return kind == 3 ? 0 : 2 * e_row(kind) + (half ? e_a0(kind) : e_bf(kind)); }
-__host__ __device__ constexpr int e_cost(int kind, int half, int eu) {
-  const int r0n = e_row(kind) + (half ? e_a0(kind) : 0);
+__host__ __device__ constexpr int e_half(int kind, int half, int ci = 128) { return kind == 3 ? 0 : 2 * e_row(kind) + (half ? e_a0(kind, ci) : e_bf(kind, ci)); }
+__host__ __device__ constexpr int e_cost(int kind, int half, int eu, int ci = 128) {
+  const int r0n = e_row(kind) + (half ? e_a0(kind, ci) : 0);
   const int u = eu < r0n ? eu : (eu - r0n < e_row(kind) ? eu - r0n : 99);
+  if (ci == 64 && half && eu >= 16 && eu < 16 + e_a0(kind, ci)) return 6;      // (an fp32 shift item: two adds, two lane reads, a select)
   return (u < 14 && u % 7 == 6) ? 3 : 2;             // (a store: its scalar address arithmetic rides with it)
 }
 struct Deal {
-  short s_lo[SLOTS + 1];        // staging items [s_lo[g], s_lo[g + 1]) run in slot g (item m = vector m / SV, step m % SV)
-  short e_lo[SLOTS + 1];        // epilogue items likewise; items >= e_half(kind, 0) belong to the second half (index - e_half(kind, 0))
-  signed char ld[SLOTS];        // the vector whose global load is issued in slot g, or -1
+  short s_lo[MAX_SLOTS + 1];    // staging items [s_lo[g], s_lo[g + 1]) run in slot g (item m = vector m / SV, step m % SV)
+  short e_lo[MAX_SLOTS + 1];    // epilogue items likewise; items >= e_half(kind, 0) belong to the second half (index - e_half(kind, 0))
+  signed char ld[MAX_SLOTS];    // the vector whose global load is issued in slot g, or -1
   short max_s, max_e, max_cost; // (for the static_asserts and the fixed-trip loops of the kernel)
 };
-__host__ __device__ constexpr Deal make_deal(bool nrm, int kind) {
+__host__ __device__ constexpr Deal make_deal(bool nrm, int kind, int ci = 128) {
   Deal d{};
   const bool nar = kind == 3;
+  const int ITERS = 9 * (ci / 32), SLOTS = ITERS * 8, HSLOTS = ITERS * 4, NSLOTS = ITERS * 2, NITP = ci == 128 ? 13 : 7;
   const int nslots = nar ? NSLOTS : SLOTS;
   const int sv = sv_items(nrm), ns = NITP * sv;
-  int ecost[SLOTS] = {};
-  const int eha = e_half(kind, 0);
+  int ecost[MAX_SLOTS] = {};
+  const int eha = e_half(kind, 0, ci);
   for (int half = 0; half < 2 && !nar; ++half) {
-    const int eh = e_half(kind, half);
+    const int eh = e_half(kind, half, ci);
     int ce = 0;
-    for (int i = 0; i < eh; ++i) ce += e_cost(kind, half, i);
+    for (int i = 0; i < eh; ++i) ce += e_cost(kind, half, i, ci);
     int idx = 0, cum = 0;
     for (int sl = 0; sl < HSLOTS; ++sl) {
       const int g = half * HSLOTS + sl;
       d.e_lo[g] = (short)((half ? eha : 0) + idx);
-      while (idx < eh && (2 * cum + e_cost(kind, half, idx)) * HSLOTS < 2 * ce * (sl + 1)) {     // the item's midpoint falls into this slot
-        ecost[g] += e_cost(kind, half, idx); cum += e_cost(kind, half, idx); ++idx;
+      while (idx < eh && (2 * cum + e_cost(kind, half, idx, ci)) * HSLOTS < 2 * ce * (sl + 1)) {     // the item's midpoint falls into this slot
+        ecost[g] += e_cost(kind, half, idx, ci); cum += e_cost(kind, half, idx, ci); ++idx;
       }
     }
   }
-  for (int g = nar ? 0 : SLOTS; g <= SLOTS; ++g) d.e_lo[g] = (short)(nar ? 0 : eha + e_half(kind, 1));
+  for (int g = nar ? 0 : SLOTS; g <= MAX_SLOTS; ++g) d.e_lo[g] = (short)(nar ? 0 : eha + e_half(kind, 1, ci));
   // staging: in order, proportionally over the slots from s_start on, never lifting a slot above `cap` instructions; cap = the smallest that
   // fits.  (Wide forms: a vector's global load goes out LEAD slots before its first item and the first S_START slots of a tile carry no
   // staging, so that even the first vector's load -- issued in slot 0, from L2 / the Infinity Cache -- has ~1300 cycles to land.  The
@@ -162,8 +177,8 @@ __host__ __device__ constexpr Deal make_deal(bool nrm, int kind) {
     }
     if (idx == ns) break;
   }
-  for (int g = nslots; g <= SLOTS; ++g) d.s_lo[g] = (short)ns;
-  for (int g = 0; g < SLOTS; ++g) d.ld[g] = -1;
+  for (int g = nslots; g <= MAX_SLOTS; ++g) d.s_lo[g] = (short)ns;
+  for (int g = 0; g < MAX_SLOTS; ++g) d.ld[g] = -1;
   if (!nar) {
     int g = 0;
     for (int k = 0; k < NITP; ++k) {
@@ -182,27 +197,31 @@ __host__ __device__ constexpr Deal make_deal(bool nrm, int kind) {
   }
   return d;
 }
-template <bool NRM, int KIND> struct DealOf { static constexpr Deal v = make_deal(NRM, KIND); };
+template <bool NRM, int KIND, int CI> struct DealOf { static constexpr Deal v = make_deal(NRM, KIND, CI); };
 constexpr int MAXS = 8, MAXE = 4;
 // the K loops are written as compile-time loops: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), every slot number a
 // constant expression that indexes the deal table (as `#pragma unroll` loops over table look-ups the file took 20+ minutes to compile)
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-static_assert(make_deal(true, 0).s_lo[SLOTS] == NITP * 21 && make_deal(false, 1).s_lo[SLOTS] == NITP * 5 && make_deal(true, 3).s_lo[NSLOTS] == NITP * 21, "deal");
-static_assert(make_deal(true, 0).max_s <= MAXS && make_deal(true, 1).max_s <= MAXS && make_deal(false, 0).max_s <= MAXS && make_deal(true, 3).max_s <= MAXS, "deal");
-static_assert(make_deal(true, 0).max_e <= MAXE && make_deal(true, 1).max_e <= MAXE && make_deal(false, 2).max_e <= MAXE, "deal");
+static_assert(make_deal(true, 0).s_lo[288] == 13 * 21 && make_deal(false, 1).s_lo[288] == 13 * 5 && make_deal(true, 3).s_lo[72] == 13 * 21 && make_deal(true, 1, 64).s_lo[144] == 7 * 21, "deal");
+static_assert(make_deal(true, 0).max_s <= MAXS && make_deal(true, 1).max_s <= MAXS && make_deal(false, 0).max_s <= MAXS && make_deal(true, 3).max_s <= MAXS && make_deal(true, 1, 64).max_s <= MAXS, "deal");
+static_assert(make_deal(true, 0).max_e <= MAXE && make_deal(true, 1).max_e <= MAXE && make_deal(false, 2).max_e <= MAXE && make_deal(true, 1, 64).max_e <= MAXE + 2, "deal");
 static_assert(make_deal(true, 0).max_cost <= 4 && make_deal(false, 0).max_cost <= 3 && make_deal(true, 1).max_cost <= 6, "deal: no slot above four (statistics form: six) extra instructions");
 }  // namespace wst
 
 // NRM: the input carries a pending norm + ReLU (forward); KIND: 0 no statistics, 1 forward statistics, 2 norm-backward sums (data gradient),
 // 3 the NARROW form: Cout <= 32 (the heads' last conv, 128 -> J, model.py:64 / :113), fp32 NCHW output -- see the block behind the prologue
-template <bool NRM, int KIND>
+template <bool NRM, int KIND, int CI = 128>
 __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a) {
   using namespace wst;
   typedef bf16_t T;
   typedef bf16x8 V;
+  typedef Shape<CI> SH;
+  constexpr int CIN = CI, KCH = SH::KCH, ITERS = SH::ITERS, PITCH = SH::PITCH, NITP = SH::NITP, PATCH_BYTES = SH::PATCH_BYTES, SLOTS = SH::SLOTS,
+                HSLOTS = SH::HSLOTS, NSLOTS = SH::NSLOTS, SPP = SH::SPP, VPR = SH::VPR, KX = SH::KX, PXR = SH::PXR;
   constexpr int EP = 8;
   constexpr bool NAR = KIND == 3;
+  static_assert(!NAR || CI == 128, "the narrow form exists for 128 input channels");
   __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
   __shared__ float sbias[NAR ? 32 : 1];
 
@@ -248,9 +267,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // per-thread column offset, its LDS address a per-thread base plus a constant, its validity a scalar row test and a per-thread column
   // test: next to no vector arithmetic per load (the norm arithmetic is what has to ride beside the MFMAs).
   const int H = p.H, W = p.W;
-  const int st_pl = tid >> 4, st_slot = tid & 15;
+  const int st_pl = tid / SPP, st_slot = tid % SPP;
   const int r12 = st_pl >> 1, c12 = 32 + (st_pl & 1);                      // vector 12's patch pixel
-  const int lds_st = (st_pl * PITCH) + st_slot * 16;                  // + (row * PW + 16 (k % 2)) * PITCH
+  const int lds_st = (st_pl * PITCH) + st_slot * 16;                  // + (row * PW + PXR (k % VPR)) * PITCH
   const int lds_st12 = (st_pl < 12 ? (r12 * PW + c12) : (PP + st_pl - 12)) * PITCH + st_slot * 16;
   V sv[NITP];
   float mu[EP], sc[EP], be[EP];
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     q.row[0] = q.row[1] - (c.y0 > 0 ? RS : 0u);
     q.row[5] = q.row[4] + (c.y0 + 4 < H ? RS : 0u);
     q.voff0 = (unsigned)(max(c.x0 + st_pl - 1, 0) * (CIN * 2) + st_slot * 16);          // even k: columns x0 - 1 ... x0 + 14
-    q.voff1 = (unsigned)((c.x0 + 15 + st_pl) * (CIN * 2) + st_slot * 16);               // odd k: columns x0 + 15 ... x0 + 30, always inside
+    q.voff1 = VPR == 2 ? (unsigned)((c.x0 + 15 + st_pl) * (CIN * 2) + st_slot * 16) : 0u;   // (VPR = 2) odd k: columns x0 + 15 ... x0 + 30, always inside
     const int ix12 = c.x0 + c12 - 1, iy12 = c.y0 + r12 - 1;
     q.voff12 = (unsigned)(c.b * H + min(max(iy12, 0), H - 1)) * RS + (unsigned)(min(ix12, W - 1) * (CIN * 2) + st_slot * 16);
     return q;
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
     return q;
   };
   auto stage_load = [&](const int k, const LoadCo& q) __attribute__((always_inline)) {
-    if (k < 12) sv[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((k & 1) ? q.voff1 : q.voff0), (int)q.row[k >> 1], 0));
+    if (k < KX) sv[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((VPR == 2 && (k & 1)) ? q.voff1 : q.voff0), (int)q.row[k / VPR], 0));
     else sv[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)q.voff12, 0, 0));
   };
   auto stage_norm_load = [&](const TileCo& c) __attribute__((always_inline)) {
@@ -319,14 +338,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   auto keep_of = [&](const int k, const MaskCo& q) __attribute__((always_inline)) {
     // (an arithmetic mask, not a select that hipcc turns into an exec-masked branch -- that would cut the K loop's scheduling region in
     // two; row validity is a scalar)
-    if (k < 12) return (k & 1) ? q.rowm[k >> 1] : (q.keep0 & q.rowm[k >> 1]);
+    if (k < KX) return (VPR == 2 && (k & 1)) ? q.rowm[k / VPR] : (q.keep0 & q.rowm[k / VPR]);
     return q.keep12;
   };
   // item i of vector k.  The two vector instructions of an item never depend on each other (a dependent instruction issued right behind
   // its producer waits four more cycles in the slot it was supposed to hide in).
   auto stage_item = [&](const int k, const int i, const MaskCo& q, char* patch) __attribute__((always_inline)) {
     if (i == SV - 1) {
-      const int off = k < 12 ? lds_st + ((k >> 1) * PW + 16 * (k & 1)) * PITCH : lds_st12;
+      const int off = k < KX ? lds_st + ((k / VPR) * PW + PXR * (k % VPR)) * PITCH : lds_st12;
       *reinterpret_cast<u32x4*>(patch + off) = so;
       return;
     }
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   auto load_tap = [&](const int tap, const int z) __attribute__((always_inline)) {
     const char* wb = reinterpret_cast<const char*>(p.w) + z;
 #pragma unroll
-    for (int q = 8 * tap; q < 8 * tap + 8; ++q) wreg[q] = *reinterpret_cast<const V*>(wb + ((q >> 1) * qs0 + (q & 1) * qs1) + wvoff);
+    for (int q = 2 * KCH * tap; q < 2 * KCH * (tap + 1); ++q) wreg[q] = *reinterpret_cast<const V*>(wb + ((q >> 1) * qs0 + (q & 1) * qs1) + wvoff);
   };
 #pragma unroll
   for (int tap = 0; tap < TAPS_AHEAD; ++tap) load_tap(tap, 0);
@@ -454,10 +473,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // not in front of the loop -- the first tile starts on tap 0 while taps 1 .. 8 are still streaming in from L2 (288 KiB per CU; waiting
   // for all of it before the first MFMA was ~5 k of a workgroup's ~60 k cycles).  In later tiles the waits they imply are already satisfied.
   auto pin_tap = [&](const int tap) __attribute__((always_inline)) {
-    if (tap < WST_AGPR_STEPS / 4) {
 #pragma unroll
-      for (int q = 8 * tap; q < 8 * tap + 8; ++q) asm volatile("" : "+a"(wreg[q]));
-    }
+    for (int q = 2 * KCH * tap; q < 2 * KCH * (tap + 1); ++q)
+      if (q < 2 * WST_AGPR_STEPS) asm volatile("" : "+a"(wreg[q]));
   };
   stamp(1);
   int tile_no = 0;
@@ -494,10 +512,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       __builtin_amdgcn_sched_barrier(0);
       static_for<NSLOTS>([&](auto SL) __attribute__((always_inline)) {
         constexpr int sl = decltype(SL)::value;
-        constexpr int m0 = DealOf<NRM, KIND>::v.s_lo[sl], m1 = DealOf<NRM, KIND>::v.s_lo[sl + 1];
-        if constexpr ((sl & 7) == 0) {
-          if ((sl >> 3) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap((sl >> 3) + TAPS_AHEAD, z); }
-          pin_tap(sl >> 3);
+        constexpr int m0 = DealOf<NRM, KIND, CI>::v.s_lo[sl], m1 = DealOf<NRM, KIND, CI>::v.s_lo[sl + 1];
+        if constexpr (sl % (2 * KCH) == 0) {
+          if (sl / (2 * KCH) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap(sl / (2 * KCH) + TAPS_AHEAD, z); }
+          pin_tap(sl / (2 * KCH));
         }
         if (WST_DBG & 8) asm volatile("" : "+v"(pf[sl % RING]));
         else if (sl == 0) accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[sl], pf[sl % RING], f32x16{}, 0, 0, 0);
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // ---- epilogue: lane (col, h) holds channels n .. n + 15 of the pixels (row, col) of the tile: bias, one rounding, two 16-byte NHWC stores
   // per row, as micro-ops of two independent vector instructions (E_ROW per tile row).  A store's address is a scalar base (tile, row) plus a
   // per-lane constant offset.
-  const unsigned yoff = (unsigned)(pc * CIN + n) * 2u;
+  const unsigned yoff = (unsigned)(pc * COUT + n) * 2u;
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, -1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rnb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.nb_y), 0, -1, 0x00020000);      // (KIND 2)
   // KIND 1 (forward statistics of the norm that follows, conv_common.h EpiStats): per 8-channel slot and pixel column li = col % 16 the old
@@ -570,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // (wst::e_st: per tile row 2 swaps + 2 pixels x 4 channel pairs x (4 | 9) items; e_a0: tile row 0, the shift (the tile's first pixel) to every
   // lane of the slot; e_bf: the butterfly over the 16 lanes of a row, 6 steps x 8 pairs of sums; half A = rows 2 - 3 of the previous tile + its
   // butterfly, half B = rows 0 - 1)
-  constexpr int E_A0 = e_a0(KIND), E_BF = e_bf(KIND), E_ROW = e_row(KIND);
+  constexpr int E_A0 = e_a0(KIND, CI), E_BF = e_bf(KIND, CI), E_ROW = e_row(KIND);
   float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
   u32x4 eo, oL, oH;
   float s1[8], s2[8], a0[8];
@@ -595,17 +613,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       else if (v == 4) { f2 = acc[row][c0 + 6] + bias_r[c0 + 6]; f3 = acc[row][c0 + 7] + bias_r[c0 + 7]; }
       else if (v == 5) { eo[2] = pk2(f0, f1); eo[3] = pk2(f2, f3); }
       else {
-        __builtin_amdgcn_raw_buffer_store_b128(eo, ry, (int)(yoff + e8 * 16), (int)((unsigned)((c.b * H + c.y0 + row) * W + c.x0) * (CIN * 2)), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(eo, ry, (int)(yoff + e8 * 16), (int)((unsigned)((c.b * H + c.y0 + row) * W + c.x0) * (COUT * 2)), 0);
         if (KIND != 0) { if (e8 == 0) oL = eo; else oH = eo; }
       }
       if (KIND == 2 && u == 0) {       // y of the NEXT row in processing order (rows 0, 1 of `cn` = the current tile; 2, 3 of the tile c)
         const int nr = (row + 1) & 3;
         const TileCo& cc = row == 3 ? cn : c;
         // (16: always the tensor's first row -- cache-hot: what the loads' latency costs.  Measured: nothing)
-        const int yso = (WST_DBG & 16) ? 0 : (int)((unsigned)((cc.b * H + cc.y0 + nr) * W + cc.x0) * (CIN * 2));
-        const int o16 = (int)((unsigned)((lane & 15) * CIN + slot_ch) * 2u);
-        if (nr & 1) { yvB0 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16, yso, 0); yvB1 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16 + 16 * CIN * 2, yso, 0); }
-        else { yvA0 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16, yso, 0); yvA1 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16 + 16 * CIN * 2, yso, 0); }
+        const int yso = (WST_DBG & 16) ? 0 : (int)((unsigned)((cc.b * H + cc.y0 + nr) * W + cc.x0) * (COUT * 2));
+        const int o16 = (int)((unsigned)((lane & 15) * COUT + slot_ch) * 2u);
+        if (nr & 1) { yvB0 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16, yso, 0); yvB1 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16 + 16 * COUT * 2, yso, 0); }
+        else { yvA0 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16, yso, 0); yvA1 = __builtin_amdgcn_raw_buffer_load_b128(rnb, o16 + 16 * COUT * 2, yso, 0); }
       }
       return;
     }
@@ -648,8 +666,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       }
       if (w < 2 + E_A0 && row == 0) {    // (tile row 0 only) the shift = the slot's values at the tile's first pixel: from lane li = 0 of this row
         const int z = w - 2;
-        if (z < 2) { eo[2 * z] = __shfl(oL[2 * z], lane & 48, 64); eo[2 * z + 1] = __shfl(oL[2 * z + 1], lane & 48, 64); }
-        else { const int j = z - 2; a0[2 * j] = lo_f(eo[j]); a0[2 * j + 1] = hi_f(eo[j]); }
+        if constexpr (CI == 64) {
+          // the fp32 value (accumulator + bias) of channel z of the lane's slot at pixel (0, 0): lane col = 0 of the same K half holds the
+          // 16 channels n .. n + 15 of that pixel; the slot of the lanes 16 .. 31 / 48 .. 63 is its upper eight
+          const float lo = __shfl(acc[0][z] + bias_r[z], lane & 32, 64), hi = __shfl(acc[0][8 + z] + bias_r[8 + z], lane & 32, 64);
+          a0[z] = (lane & 16) ? hi : lo;
+        } else {
+          if (z < 2) { eo[2 * z] = __shfl(oL[2 * z], lane & 48, 64); eo[2 * z + 1] = __shfl(oL[2 * z + 1], lane & 48, 64); }
+          else { const int j = z - 2; a0[2 * j] = lo_f(eo[j]); a0[2 * j + 1] = hi_f(eo[j]); }
+        }
         return;
       }
       // 0 .. 31: channel pair j = v / 8; inside it the four micro-ops {unpack, - shift, s1, s2} of the row's two pixels ALTERNATE (x = v % 2),
@@ -677,6 +702,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // -> xor 8), the three xor-4 items of a pair alternate with another pair's (two instructions in between).
 #define PWR_DPP_ADD(x, ctrl) asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(x))
 #define PWR_DPP_MOV(d, x, ctrl, bank) asm volatile("v_mov_b32_dpp %0, %1 " ctrl " row_mask:0xf bank_mask:" bank : "+v"(d) : "v"(x))
+#define PWR_DPP_ADD3(d, x, y, ctrl) asm volatile("v_add_f32_dpp %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(x), "v"(y))       // d = x[shifted lane] + y
   auto bfly_micro = [&](const int b) __attribute__((always_inline)) {
     if constexpr (KIND != 0) {
       // (b = 0 .. 15: xor 1, xor 2 over the eight pairs; 16 .. 39: per pair its three xor-4 ops in a row -- they share the two temporaries --;
@@ -687,6 +713,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
       float& x0 = j < 4 ? s1[2 * j] : s2[2 * (j - 4)];
       float& x1 = j < 4 ? s1[2 * j + 1] : s2[2 * (j - 4) + 1];
       float& bt0 = (j & 1) ? bt2 : bt0_; float& bt1 = (j & 1) ? bt3 : bt1_;
+      if constexpr (CI == 64) {
+        // The kernel this form replaces (conv_patch.hip's two-pass epilogue, EpiStats::finish) adds the four groups of four columns ONE AFTER
+        // THE OTHER -- ((g0 + g1) + g2) + g3 -- where the one-pass epilogue's butterfly pairs them: after xor 1 and xor 2 every lane holds
+        // its group's sum; lane 0 of the row collects the others with three shifted adds (only that lane's result is written).  40 items.
+        if (step == 0) { PWR_DPP_ADD(x0, "quad_perm:[1,0,3,2]"); PWR_DPP_ADD(x1, "quad_perm:[1,0,3,2]"); }
+        else if (step == 1) { PWR_DPP_ADD(x0, "quad_perm:[2,3,0,1]"); PWR_DPP_ADD(x1, "quad_perm:[2,3,0,1]"); }
+        else if (step == 2) { PWR_DPP_ADD3(bt0, x0, x0, "row_shl:4"); PWR_DPP_ADD3(bt1, x1, x1, "row_shl:4"); }
+        else if (step == 3) { PWR_DPP_ADD3(bt0, x0, bt0, "row_shl:8"); PWR_DPP_ADD3(bt1, x1, bt1, "row_shl:8"); }
+        else if (step == 4) { PWR_DPP_ADD3(x0, x0, bt0, "row_shl:12"); PWR_DPP_ADD3(x1, x1, bt1, "row_shl:12"); }
+        return;
+      }
       if (step == 0) { PWR_DPP_ADD(x0, "quad_perm:[1,0,3,2]"); PWR_DPP_ADD(x1, "quad_perm:[1,0,3,2]"); }
       else if (step == 1) { PWR_DPP_ADD(x0, "quad_perm:[2,3,0,1]"); PWR_DPP_ADD(x1, "quad_perm:[2,3,0,1]"); }
       else if (step == 2) { PWR_DPP_MOV(bt0, x0, "row_shl:4", "0x5"); PWR_DPP_MOV(bt1, x1, "row_shl:4", "0x5"); }
@@ -697,15 +734,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   };
 #undef PWR_DPP_ADD
 #undef PWR_DPP_MOV
+#undef PWR_DPP_ADD3
   // the finished sums of tile c: lane li = 0 of every row writes its slot's slab entries; then the sums restart
   auto stats_write = [&](const TileCo& c, const bool write) __attribute__((always_inline)) {
     if constexpr (KIND != 0) {
       if (write && (lane & 15) == 0) {       // (not for the garbage the first tile's stand-in "previous half" produced)
         const int tr = (c.y0 >> 2) * tiles_x + (c.x0 >> 5);
         const size_t srow = (size_t)c.b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
-        float* out = (KIND == 1 ? p.st_partial + (srow * 3) * CIN : p.nb_partial + (srow * 2) * CIN) + slot_ch;
+        float* out = (KIND == 1 ? p.st_partial + (srow * 3) * COUT : p.nb_partial + (srow * 2) * COUT) + slot_ch;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { out[e] = s1[e]; out[CIN + e] = s2[e]; if (KIND == 1) out[2 * CIN + e] = a0[e]; }
+        for (int e = 0; e < 8; ++e) { out[e] = s1[e]; out[COUT + e] = s2[e]; if (KIND == 1) out[2 * COUT + e] = a0[e]; }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -714,8 +752,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
   // (KIND 2) mean, rstd, scale, beta of sample b for the slot's channels (conv_common.h: nb_state = [4][B][C])
   auto nb_state_load = [&](const int b) __attribute__((always_inline)) {
     if constexpr (KIND == 2) {
-      const size_t plane = (size_t)p.B * CIN;
-      const float* st = p.nb_state + (size_t)b * CIN + slot_ch;
+      const size_t plane = (size_t)p.B * COUT;
+      const float* st = p.nb_state + (size_t)b * COUT + slot_ch;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         a0[e] = st[e]; a1[e] = st[plane + e];
@@ -731,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
 
   int buf = 0;
   TileCo prev = cur;            // (first tile: the "previous tile's" half epilogue stores garbage where this tile's own epilogue writes later)
-  constexpr int EHA = e_half(KIND, 0);
+  constexpr int EHA = e_half(KIND, 0, CI);
   // (the next tile's offsets and masks are computed BEFORE the barrier that ends a tile -- there a wave waits for the others anyway --,
   // not between the barrier and the tile's first MFMA; the empty asm keeps them there)
   LoadCo l1 = load_co(nx1);
@@ -753,17 +791,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wstat_kernel(const WstatArgs a
         // epilogue (the deal table), a full scheduling barrier: the emitted order IS this order
         constexpr int sl = decltype(SL)::value;
         constexpr int g = half * HSLOTS + sl, it = sl >> 2, ss = (sl >> 1) & 1, row = 2 * half + (sl & 1);
-        constexpr int m0 = DealOf<NRM, KIND>::v.s_lo[g], m1 = DealOf<NRM, KIND>::v.s_lo[g + 1];
-        constexpr int e0 = DealOf<NRM, KIND>::v.e_lo[g], e1 = DealOf<NRM, KIND>::v.e_lo[g + 1];
-        if constexpr (half == 0 && (sl & 15) == 0) {
-          if ((sl >> 4) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap((sl >> 4) + TAPS_AHEAD, z); }     // (first tile only: a uniform branch)
-          pin_tap(sl >> 4);
+        constexpr int m0 = DealOf<NRM, KIND, CI>::v.s_lo[g], m1 = DealOf<NRM, KIND, CI>::v.s_lo[g + 1];
+        constexpr int e0 = DealOf<NRM, KIND, CI>::v.e_lo[g], e1 = DealOf<NRM, KIND, CI>::v.e_lo[g + 1];
+        if constexpr (half == 0 && sl % (4 * KCH) == 0) {
+          if (sl / (4 * KCH) + TAPS_AHEAD < 8 && tile_no == 0) { int z = tile_no; asm volatile("" : "+s"(z)); load_tap(sl / (4 * KCH) + TAPS_AHEAD, z); }     // (first tile only: a uniform branch)
+          pin_tap(sl / (4 * KCH));
         }
         if (WST_DBG & 8) asm volatile("" : "+v"(pf[g % RING]));
         else if (it == 0 && ss == 0) acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g % RING], f32x16{}, 0, 0, 0);
         else acc[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[2 * it + ss], pf[g % RING], acc[row], 0, 0, 0);
         if (g + RING < SLOTS && !(WST_DBG & 4)) frag_load1(g + RING, pb);
-        if constexpr (DealOf<NRM, KIND>::v.ld[g] >= 0 && !(WST_DBG & 1)) stage_load(DealOf<NRM, KIND>::v.ld[g], l1);
+        if constexpr (DealOf<NRM, KIND, CI>::v.ld[g] >= 0 && !(WST_DBG & 1)) stage_load(DealOf<NRM, KIND, CI>::v.ld[g], l1);
         if constexpr (m1 > m0 && !(WST_DBG & 1)) {
           static_for<m1 - m0>([&](auto J) __attribute__((always_inline)) {
             constexpr int m = m0 + decltype(J)::value, k = m / SV, i = m - k * SV;
@@ -827,7 +865,9 @@ bool conv_wstat_applicable(const ConvParams& p, int dtype) {
   const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) &&          // (debug build: read on every call, so one process can A/B the two kernels)
                   (long long)p.B * p.H * p.W * 256 < (1ll << 32);            // (32-bit byte offsets into x and y)
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
-  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Cin == 128 && p.Cout == 128 &&
+  // (64 input channels -- the stem's 64 -> 128 conv -- from the standard pack, forward forms only)
+  const bool cin_ok = p.Cin == 128 || (p.Cin == 64 && !p.w_frag && !p.nb_partial && PWR_DBG_ENV("PWR_WSTAT_C64", 1) != 0);
+  return on && dtype == PWR_BF16 && p.mode == 0 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && cin_ok && p.Cout == 128 &&
          p.CoutPad == 128 && p.W % 32 == 0 && p.H % 4 == 0 && p.y != nullptr && !p.y_nchw && !p.residual && (!p.in_norm || p.relu_in) &&
          !(p.st_partial && p.nb_partial) && !(p.nb_partial && (p.in_norm || p.bias || !PWR_DBG_ENV("PWR_WSTAT_NB", 0))) && p.B * (p.H / 4) * (p.W / 32) >= min_tiles;
 }
@@ -842,6 +882,11 @@ bool conv_wstat_narrow_applicable(const ConvParams& p, int dtype) {
 
 template <bool NRM>
 static void launch_kind(const WstatArgs& a, int kind, dim3 grid, hipStream_t s) {
+  if (a.job[0].Cin == 64) {
+    if (kind == 0) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 0, 64>), grid, dim3(256), 0, s, a);
+    else if (kind == 1) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 1, 64>), grid, dim3(256), 0, s, a);
+    return;
+  }
   if (kind == 0) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 0>), grid, dim3(256), 0, s, a);
   else if (kind == 1) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 1>), grid, dim3(256), 0, s, a);
   else if (kind == 3) hipLaunchKernelGGL((conv3x3_wstat_kernel<NRM, 3>), grid, dim3(256), 0, s, a);
@@ -883,7 +928,7 @@ bool conv_wstat_narrow_pair_applicable(const ConvParams& a, const ConvParams& b,
 }
 
 bool conv_wstat_pair_applicable(const ConvParams& a, const ConvParams& b, int dtype) {
-  return conv_wstat_applicable(a, dtype) && conv_wstat_applicable(b, dtype) && a.B == b.B && a.H == b.H && a.W == b.W &&
+  return conv_wstat_applicable(a, dtype) && conv_wstat_applicable(b, dtype) && a.B == b.B && a.H == b.H && a.W == b.W && a.Cin == b.Cin &&
          (a.in_norm != nullptr) == (b.in_norm != nullptr) && (a.st_partial != nullptr) == (b.st_partial != nullptr) &&
          (a.nb_partial != nullptr) == (b.nb_partial != nullptr) && a.relu_in == b.relu_in;
 }
