@@ -770,6 +770,30 @@ def test_conv_epilogue_forward_stats(case, dtype):
         assert_close(st.double().cpu(), ref.double().cpu(), 2e-5 if dtype == torch.float32 else 2e-4, "state (mode %d)" % mode)
 
 
+@pytest.mark.parametrize("form", ["plain", "norm"])
+@pytest.mark.parametrize("case", [(2, 64, 64, 128), (3, 36, 96, 128), (2, 64, 64, 64), (3, 36, 96, 64), (1, 128, 128, 64), (5, 8, 64, 64)])
+def test_weight_stationary_conv_statistics_against_the_standalone_ones(case, form):
+    """The shapes csrc/conv_wstat.hip takes (3x3, 128 / 64 -> 128 channels, no residual) with the forward statistics from its epilogue:
+    the conv equals the plain launch bit for bit, and the statistics -- finalised -- equal the standalone norm statistics of the stored
+    tensor.  The 64-channel form sums its column groups in another order and takes an fp32 shift (the order of the kernel it replaced):
+    both orders have to give the same statistics to summation noise."""
+    from pixelwiseregression_amd import kernels as K
+    B, H, W, Cin = case
+    x = nhwc(rnd(B, Cin, H, W, seed=1), torch.bfloat16)
+    w = rnd(128, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    bias = (rnd(128, seed=3) * 20).float().to(DEV)          # means far from 0: the sums must be shifted
+    gamma, beta = (1 + 0.2 * rnd(128, seed=4)).float().to(DEV), (0.2 * rnd(128, seed=5)).float().to(DEV)
+    st = K.norm_stats(x, torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV), mode=0) if form == "norm" else None
+    pack = K.pack_conv(w.float().to(DEV), 0, K.BF16)
+    y0, _ = K.conv_fwd(x, pack, 128, 3, 1, bias=bias, norm=st)
+    y1, partial, chunks = K.conv_fwd_stats(x, pack, 128, 3, 1, bias=bias, norm=st)
+    assert float(y0.float().abs().max()) > 0 and torch.equal(y0, y1) and not torch.isnan(partial).any()
+    for mode in (0, 1):
+        ref = K.norm_stats(y0, gamma, beta, mode=mode)
+        got = K.norm_finalize_partial(partial, chunks, gamma, beta, B, H * W, mode=mode)
+        assert_close(got.double().cpu(), ref.double().cpu(), 2e-4, "state (mode %d)" % mode)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", STATS_CASES)
 def test_conv_epilogue_norm_backward_sums(case, dtype):
