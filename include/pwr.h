@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 5   /* 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_finalize_partial_pair; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -191,6 +191,10 @@ int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* 
 int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float* state, int B, int HW, int C, int mode, float eps,
                               float momentum, void* stream);
+/* two pwr_norm_finalize_partial calls of ONE shape (instance norm: the two regression heads' norms of one depth) as one launch. */
+int pwr_norm_finalize_partial_pair(const float* partial_a, const float* gamma_a, const float* beta_a, float* state_a, const float* partial_b,
+                                   const float* gamma_b, const float* beta_b, float* state_b, int chunks, int B, int HW, int C, float eps,
+                                   void* stream);
 /* two pwr_norm_bwd_from_partial calls of ONE shape (instance norm, no addend: the two regression heads' norms of one depth, model.py:54-65 /
  * :103-114) as two launches instead of four; S1 / S2: 2 x B x C floats of scratch.  Bit-identical to the two single calls. */
 int pwr_norm_bwd_from_partial_pair(const void* ga, const void* ya, const float* state_a, const float* partial_a, void* dya, float* dgamma_a,
@@ -201,6 +205,17 @@ int pwr_norm_bwd_from_partial_pair(const void* ga, const void* ya, const float* 
 int pwr_norm_bwd_from_partial(const void* g, const void* y, const float* state, const float* partial, int chunks, float* S1, float* S2,
                               const void* addend, void* dy, float* dgamma, float* dbeta, int accumulate, int relu, int B, int HW,
                               int C, int mode, int dtype, void* stream);
+/* Round 6, instance norm: pwr_norm_bwd_from_partial with the reduction launch taken off the caller's stream.  ONE launch: every workgroup
+ * of the apply step sums the `chunks` slab rows of its sample itself (all loads in flight at once, added in pwr_norm_bwd_from_partial's
+ * order -- dy is the same bits); gb != NULL: a second tensor of the same shape in the same launch (the two regression heads' norms of one
+ * depth, model.py:54-65 / :103-114; no addend).  C <= 512.  The parameter gradients: pwr_norm_bwd_params_from_partial on the same slab. */
+int pwr_norm_bwd_apply_from_partial(const void* ga, const void* ya, const float* state_a, const float* partial_a, const void* addend_a, void* dya,
+                                    const void* gb, const void* yb, const float* state_b, const float* partial_b, void* dyb, int chunks,
+                                    int relu, int B, int HW, int C, int dtype, void* stream);
+/* dgamma / dbeta [C] (+)= from the slab of pwr_conv_fwd_stats (nb_partial), instance norm: the reduction launch of
+ * pwr_norm_bwd_from_partial without its per-sample outputs (same order, same bits); partial_b != NULL: a second job in the same launch. */
+int pwr_norm_bwd_params_from_partial(const float* partial_a, float* dgamma_a, float* dbeta_a, const float* partial_b, float* dgamma_b,
+                                     float* dbeta_b, int chunks, int accumulate, int B, int HW, int C, void* stream);
 /* dy = d/dy relu(norm(y)) applied to g (+ addend); dgamma/dbeta [C] (+)=.  S1,S2: [B,C] scratch. */
 int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);

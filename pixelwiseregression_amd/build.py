@@ -31,7 +31,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.
 # (a warning, and a kernel whose register arrays live in scratch)
 # -amdgpu-mfma-vgpr-form: its accumulators live in VGPRs (the epilogue reads them with vector instructions; the AGPR file holds weights)
 PER_FILE_FLAGS = {"conv_wstat.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Werror=pass-failed"]}
-DEBUG_SRC = os.path.join(ROOT, "tools", "csrc_debug")   # experiments that only the debug build compiles (never part of the product)
+# experiment KERNELS that only the debug build compiles and links (never part of the product).  Standalone probes with a main() of their
+# own live in tools/probes/ and are built by their scripts (tools/issue_probe.sh), not into any library.
+DEBUG_SRC = os.path.join(ROOT, "tools", "csrc_debug")
 _debug_sources = False
 
 
@@ -39,7 +41,7 @@ def _sources():
     """source paths: csrc/*.hip, and in the debug build tools/csrc_debug/*.hip as well"""
     out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
     if _debug_sources and os.path.isdir(DEBUG_SRC):
-        out += [os.path.join(DEBUG_SRC, f) for f in sorted(os.listdir(DEBUG_SRC)) if f.endswith((".hip", ".cpp"))]
+        out += [os.path.join(DEBUG_SRC, f) for f in sorted(os.listdir(DEBUG_SRC)) if f.endswith(".hip")]
     return out
 
 

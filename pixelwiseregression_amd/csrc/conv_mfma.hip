@@ -1054,7 +1054,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
       size_t unit = i8;
-      if (d.order == 1) {        // (rows_pad == 128, KE8 == 4: checked on the host)
+      // the descriptors are device-resident (the host cannot check them at this call): order 1 is honoured only for the one shape it is
+      // defined for -- kind 0, 128 x 128, 3x3, bf16 (rows_pad 128, KCH 4) -- and any other record falls back to the standard order, inside
+      // its own allocation
+      if (d.order == 1 && d.kind == 0 && d.rows_pad == 128 && d.KCH == 4 && d.ksize == 3 && d.Cout == 128 && d.Cin == 128) {
         const int slot = i8 % KE8, wave = row >> 5, c = row & 31;
         const int r = (c & 3) | (((c >> 4) & 1) << 2) | (((c >> 2) & 3) << 3);       // inverse of chan(r)
         unit = (size_t)(tap * d.KCH + kch) * 512 + wave * 128 + (slot >> 1) * 64 + r + 32 * (slot & 1);
@@ -1073,8 +1076,10 @@ template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int bn = pick_bn(p.Cout);
   if (p.CoutPad % bn) return PWR_EINVAL;
+  if (p.w_frag && p.mode != 0) return PWR_EINVAL;      // (no kernel below the patch dispatch reads a fragment-order pack)
   if (conv_tr2_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_tr2(p, s);
   if (conv_patch_applicable(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32)) return launch_conv_patch(p, sizeof(T) == 2 ? PWR_BF16 : PWR_F32, s);
+  if (p.w_frag) return PWR_EINVAL;
   // mode 1: four parity classes of M/4 rows each, every class padded to whole tiles
   const int mtiles = p.mode == 0 ? (p.M + 127) / 128 : 4 * ((p.M / 4 + 127) / 128);
   dim3 grid(mtiles, p.CoutPad / bn), block(256);
@@ -1220,7 +1225,9 @@ static int conv_params_fill(pwr::ConvParams& p, const void* x, const void* wpack
   p.x = x; p.bias = bias; p.in_norm = in_norm; p.residual = residual;
   p.w_frag = (int)((uintptr_t)wpack & 1);                       // (a fragment-order pack: only the shapes conv_wstat.hip takes may carry one)
   p.w = reinterpret_cast<const void*>((uintptr_t)wpack & ~(uintptr_t)1);
-  if (p.w_frag && !pwr::conv_wstat_shape(B, H, W, Cin, Cout, ksize, stride, dtype)) return PWR_EINVAL;
+  // (conv_wstat_shape prices mode 0 only: a tagged pack on the transposed mode would reach launch_conv_tr2 / the universal kernel, which
+  // read the standard order)
+  if (p.w_frag && (mode != 0 || !pwr::conv_wstat_shape(B, H, W, Cin, Cout, ksize, stride, dtype))) return PWR_EINVAL;
   p.y = y; p.y_nchw = y_nchw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.ksize = ksize; p.pad = ksize / 2; p.mode = mode; p.relu_in = relu_in;
   if (mode == 0) {

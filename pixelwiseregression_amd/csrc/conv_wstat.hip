@@ -25,7 +25,7 @@
 //     instructions that are handed out per MFMA slot by a compile-time table (wst::make_deal) under a budget of three extra instructions
 //     per slot; a full scheduling barrier closes every slot and an empty asm ties each slot's temporaries into it (left alone hipcc emits a
 //     vector's 40 staging instructions as one lump and the pipe drains).  Why three: with ONE wave per SIMD everything issues from the wave
-//     that issues the MFMAs, one instruction per four cycles; tools/csrc_debug/issue_probe.cpp measured a slot of MFMA + fragment read + wait
+//     that issues the MFMAs, one instruction per four cycles; tools/probes/issue_probe.cpp measured a slot of MFMA + fragment read + wait
 //     at 32.5 cycles, 33.5 / 34 / 35 with one / two / three more instructions, +4 ... 5 for each one beyond, 8 for a scalar instruction
 //     beyond two, 22 for a v_pk_add_f32 (profiles/r5_issue_probe.jsonl).
 //   * Addresses are raw buffer loads / stores: a scalar 32-bit row offset in soffset, a per-thread 32-bit offset, the tensor base in a
@@ -97,7 +97,7 @@ template <int CI> struct Shape {
 constexpr int MAX_SLOTS = Shape<128>::SLOTS, MAX_NITP = Shape<128>::NITP;
 // Schedule inside the K loops.  A SLOT is one v_mfma_f32_32x32x16_bf16 (288 per tile, 72 in the narrow form; 32 matrix-pipe cycles).  With ONE
 // wave per SIMD the wave that issues the MFMAs issues everything else too, one instruction per four cycles, and the MFMA itself occupies
-// the issue port for a while: measured (tools/csrc_debug/issue_probe.cpp, profiles/r5_issue_probe.jsonl) a slot of MFMA + fragment read +
+// the issue port for a while: measured (tools/probes/issue_probe.cpp, profiles/r5_issue_probe.jsonl) a slot of MFMA + fragment read +
 // its wait runs in 32.5 cycles, with 1 / 2 / 3 more instructions of ANY kind (vector, s_nop) in 33.5 / 34 / 35, and every further one
 // costs 4 - 5 (39, 44, 49); a scalar instruction beyond two costs 8, a v_pk_add_f32 22.  So what matters is that NO slot carries more
 // than three extra instructions: the staging of the next patch (13 vectors x SV items) and the epilogue of the finished half tile are
@@ -862,7 +862,7 @@ bool conv_wstat_shape(int B, int H, int W, int Cin, int Cout, int ksize, int str
 }
 
 bool conv_wstat_applicable(const ConvParams& p, int dtype) {
-  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) &&          // (debug build: read on every call, so one process can A/B the two kernels)
+  const bool on = (PWR_DBG_ENV("PWR_WSTAT", 1) != 0) &&          // (debug build: read on every call, so one process can A/B the two kernels THROUGH THE KERNEL ENTRY POINTS with standard packs; an engine plan bakes fragment-order packs in when it is built, so the switch must be set before the plan is created -- toggling it on a live plan makes the heads' launches return PWR_EINVAL)
                   (long long)p.B * p.H * p.W * 256 < (1ll << 32);            // (32-bit byte offsets into x and y)
   const int min_tiles = PWR_DBG_ENV("PWR_WSTAT_MIN_TILES", 16);
   // (64 input channels -- the stem's 64 -> 128 conv -- from the standard pack, forward forms only)

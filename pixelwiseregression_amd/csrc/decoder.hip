@@ -26,22 +26,49 @@ __device__ __forceinline__ float grid_coord(int idx, int P) {
   return __fdiv_rn((float)(idx - (P >> 1)), (float)(P - 1));
 }
 
+// Round 6 -- which map a workgroup owns.  L and m ([B,1,P,P]) are shared by the J maps of a sample and are meant to be served by L2, but
+// workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one: MI355X_MICROARCH.md, Workgroup dispatch) and every XCD has
+// an L2 of its own: with map = blockIdx the J maps of a sample are spread over all eight, and each L2 fetches that sample's L and m from HBM
+// again -- 8 x 16.8 MB at the C5 shape, the 1.12 x of round 5's forward counters.  With Bx > 0 the block index is read as (slot, xcd) and XCD
+// x owns the samples b = 8 g + x: all J maps of a sample run on ONE XCD, back to back (grid = 8 ceil(B / 8) J; a block whose sample does
+// not exist leaves).  Placement is a speed matter only: every map is computed by exactly one workgroup either way, same arithmetic.
+__device__ __forceinline__ int dec_map(int bid, int J, int Bx) {
+  if (Bx <= 0) return bid;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int g = slot / J, j = slot - g * J;
+  const int b = g * 8 + xcd;
+  return b < Bx ? b * J + j : -1;
+}
+// a 16-byte load of a tensor that is read ONCE (z, D, p, gH, gD): NTL = non-temporal (bypasses the vector L1, L2-served)
+template <bool NTL>
+__device__ __forceinline__ f32x4 dec_ld(const float* q) {
+  if constexpr (NTL) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+  else return *reinterpret_cast<const f32x4*>(q);
+}
+template <bool NTL>
+__device__ __forceinline__ void dec_st(float* q, const f32x4& v) {
+  if constexpr (NTL) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q));
+  else *reinterpret_cast<f32x4*>(q) = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register-resident path: N == NT*NV*4, P % 4 == 0 and (NT*4) % P == 0, so a thread's four
 // columns are the same for all of its NV vectors.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int NV, int MINW = 1>
+template <int NT, int NV, int MINW = 1, bool NTL = false>
 __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __restrict__ z, const float* __restrict__ D,
                                                         const float* __restrict__ L, const float* __restrict__ m,
                                                         const float* __restrict__ w, float* __restrict__ p_out,
-                                                        float* __restrict__ uvd, int J, int P, int method) {
+                                                        float* __restrict__ uvd, int J, int P, int method, int Bx) {
   // ONE dependent memory phase: every thread exponentiates against its OWN maximum (all its logits are in registers), so the
   // loads of D, L and m are not held back behind a workgroup-wide max reduction; the two block reductions (max of the thread
   // maxima, then the sums rescaled by exp(m_thread - M)) sit back to back at the end with no memory access between them.
   //   p = exp(e - m_t) * exp(m_t - M) / S      (one extra rounding vs exp(e - M) / S: ~1e-7 relative)
   constexpr int NW = NT / 64;
   __shared__ float red[8 * NW];
-  const int map = blockIdx.x, b = map / J, j = map - b * J;
+  const int map = dec_map(blockIdx.x, J, Bx);
+  if (map < 0) return;
+  const int b = map / J, j = map - b * J;
   const int N = P * P;
   const size_t mo = (size_t)map * N, bo = (size_t)b * N;
   const int tid = threadIdx.x;
@@ -53,7 +80,7 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
   float mt = -INFINITY;
   const float wj = (method == 0) ? w[j] : 1.f;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) e[k] = *reinterpret_cast<const f32x4*>(z + mo + (size_t)(k * NT + tid) * 4);
+  for (int k = 0; k < NV; ++k) e[k] = dec_ld<NTL>(z + mo + (size_t)(k * NT + tid) * 4);
   if (method == 0) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -67,7 +94,7 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const size_t off = (size_t)(k * NT + tid) * 4;
-    f32x4 dv = *reinterpret_cast<const f32x4*>(D + mo + off);
+    f32x4 dv = dec_ld<NTL>(D + mo + off);
     f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
     f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
     f32x4 ev;
@@ -108,7 +135,7 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
     f32x4 pv;
     pv.x = __fdiv_rn(e[k].x * f, r[0]); pv.y = __fdiv_rn(e[k].y * f, r[0]);
     pv.z = __fdiv_rn(e[k].z * f, r[0]); pv.w = __fdiv_rn(e[k].w * f, r[0]);
-    *reinterpret_cast<f32x4*>(p_out + mo + (size_t)(k * NT + tid) * 4) = pv;
+    dec_st<NTL>(p_out + mo + (size_t)(k * NT + tid) * 4, pv);
   }
   if (tid == 0) {
     uvd[(size_t)map * 3 + 0] = r[1] * inv;
@@ -186,18 +213,20 @@ __device__ __forceinline__ float uniform_load(const float* p) {
 // and all operands of a map are loaded in one dependent phase (the two-reduction form read m, D, L, z behind the first barrier).
 // RELOAD (softmax only; used for the 128x128 maps where NV = 8): only p and Bm stay in registers, gH and m are fetched again
 // (L2) in the tail -- 100 instead of 256 VGPRs, so that two 512-thread workgroups share a CU and overlap their phases.
-template <int NT, int NV, bool RELOAD = false, bool SC1 = false>
+template <int NT, int NV, bool RELOAD = false, bool SC1 = false, bool NTL = false>
 __global__ __launch_bounds__(NT, RELOAD ? (2 * NT) / 256 : 1) void decode_bwd_cached(const float* __restrict__ p, const float* __restrict__ z,
                                                         const float* __restrict__ D, const float* __restrict__ L,
                                                         const float* __restrict__ m, const float* __restrict__ w,
                                                         const float* __restrict__ uvd, const float* __restrict__ gH,
                                                         const float* __restrict__ gDin, const float* __restrict__ gU,
                                                         float* __restrict__ gz, float* __restrict__ gDout,
-                                                        float* __restrict__ gw_part, int J, int P, int method) {
+                                                        float* __restrict__ gw_part, int J, int P, int method, int Bx) {
   constexpr int NW = NT / 64;
   constexpr int NK = RELOAD ? 1 : NV;      // vectors of A / p*m^2 kept in registers
   __shared__ float red[8 * NW];
-  const int map = blockIdx.x, b = map / J, j = map - b * J;
+  const int map = dec_map(blockIdx.x, J, Bx);
+  if (map < 0) return;
+  const int b = map / J, j = map - b * J;
   const int N = P * P;
   const size_t mo = (size_t)map * N, bo = (size_t)b * N;
   const int tid = threadIdx.x;
@@ -216,15 +245,15 @@ __global__ __launch_bounds__(NT, RELOAD ? (2 * NT) / 256 : 1) void decode_bwd_ca
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const size_t off = (size_t)(k * NT + tid) * 4;
-    const f32x4 pk = *reinterpret_cast<const f32x4*>(p + mo + off);
+    const f32x4 pk = dec_ld<NTL>(p + mo + off);
     const f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
-    const f32x4 dv = *reinterpret_cast<const f32x4*>(D + mo + off);
+    const f32x4 dv = dec_ld<NTL>(D + mo + off);
     const f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
-    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + mo + off);
+    const f32x4 zv = dec_ld<NTL>(z + mo + off);
     const float gyv = gv * grid_coord(row0 + k * rows_per_step, P);
     f32x4 A;
     A.x = gxc[0] + gyv; A.y = gxc[1] + gyv; A.z = gxc[2] + gyv; A.w = gxc[3] + gyv;
-    if (gH) A += *reinterpret_cast<const f32x4*>(gH + mo + off);
+    if (gH) A += dec_ld<NTL>(gH + mo + off);
     f32x4 Bm;
     Bm.x = mv.x * (mv.x * (dv.x + lv.x) - d); Bm.y = mv.y * (mv.y * (dv.y + lv.y) - d);
     Bm.z = mv.z * (mv.z * (dv.z + lv.z) - d); Bm.w = mv.w * (mv.w * (dv.w + lv.w) - d);
@@ -273,10 +302,10 @@ __global__ __launch_bounds__(NT, RELOAD ? (2 * NT) / 256 : 1) void decode_bwd_ca
     f32x4 gzv;
     if (method == 0) gzv = wj * (pv[k] * (g - A1));
     else gzv = pv[k] * ((g - A1) * invT);
-    *reinterpret_cast<f32x4*>(gz + mo + off) = gzv;
+    dec_st<NTL>(gz + mo + off, gzv);
     f32x4 gdv = gdS * q2;
-    if (gDin) gdv += *reinterpret_cast<const f32x4*>(gDin + mo + off);
-    *reinterpret_cast<f32x4*>(gDout + mo + off) = gdv;
+    if (gDin) gdv += dec_ld<NTL>(gDin + mo + off);
+    dec_st<NTL>(gDout + mo + off, gdv);
   }
   if (tid == 0 && gw_part) gw_part[map] = (method == 0) ? ((r[3] + gdS * r[4]) - A1 * r[5]) : 0.f;
 }
@@ -345,26 +374,39 @@ __global__ void decode_gw_reduce(const float* __restrict__ gw_part, float* __res
 // ---------------------------------------------------------------------------------------------
 // C ABI (declared in include/pwr.h)
 // ---------------------------------------------------------------------------------------------
+// XCD-aware map order (dec_map) and non-temporal accesses of the once-read tensors: switches of the debug build (tools/bench_decoder.py
+// A/B); the product's values are the measured best (decoder)
+static inline int dec_grid(int B, int J, int* Bx) {
+  static const int xcd = PWR_DBG_ENV("PWR_DEC_XCD", 1);
+  *Bx = xcd ? B : 0;
+  return xcd ? 8 * ((B + 7) / 8) * J : B * J;
+}
 extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, const float* m, const float* w,
                               float* p_out, float* uvd_out, int B, int J, int P, int method, void* stream) {
   if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int N = P * P, maps = B * J;
-  if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
-  else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+  int Bx = 0;
+  const int grid = dec_grid(B, J, &Bx);
+  static const int nt = PWR_DBG_ENV("PWR_DEC_NT", 0);
+  if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0) {
+    if (nt) hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4, 1, true>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+  } else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
   else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
     // 128x128 maps.  A/B switch (tools/bench_decoder.py), measured at B=128, J=42 on MI355X (profiles/r2_decoder_bench.jsonl):
     // 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU: 4.28 TB/s (default); 1 = 1024 threads x 4 vectors: 4.24 TB/s;
     // 2 = 512 x 8 held to 128 VGPRs (two workgroups per CU, a few spilled registers): 3.87 TB/s
     static const int v = PWR_DBG_ENV("PWR_DEC_FWD128", 0);
     if (v == 1 && 4096 % P == 0)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(grid), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
     else if (v == 2)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4>), dim3(maps), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (nt)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
     else
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
   }
   else
     hipLaunchKernelGGL((pwr::decode_fwd_generic<256>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);
@@ -378,24 +420,30 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
   if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int N = P * P, maps = B * J;
+  int Bx = 0;
+  const int grid = dec_grid(B, J, &Bx);
+  static const int nt = PWR_DBG_ENV("PWR_DEC_NT", 0);
   static const int sc1 = PWR_DBG_ENV("PWR_DEC_SCALAR_SC1", 0);   // experiment switch (tools/race_hunt.py)
   if (sc1 && P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, false, true>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
-  else if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
-  else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 1>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, false, true>), dim3(grid), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
+  else if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0) {
+    if (nt) hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, false, false, true>), dim3(grid), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
+    else hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4>), dim3(grid), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
+  } else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
+    hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 1>), dim3(grid), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
   else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
     // 128x128 maps.  A/B switch, measured like the forward: 0 = 512 x 8 with everything in registers (204 VGPRs, one workgroup per
     // CU): 4.74 TB/s (default; the two-reduction form of round 1: 3.04); 1 = 1024 x 4 (108 VGPRs, one 16-wave workgroup per CU): 4.38;
     // 2 = 512 x 8 RELOAD (softmax only; 128 VGPRs with spills, two workgroups per CU): 2.51
     static const int v = PWR_DBG_ENV("PWR_DEC_BWD128", 0);
     if (v == 1 && 4096 % P == 0)
-      hipLaunchKernelGGL((pwr::decode_bwd_cached<1024, 4>), dim3(maps), dim3(1024), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<1024, 4>), dim3(grid), dim3(1024), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
     else if (v == 2 && method == 0)
-      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8, true>), dim3(maps), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8, true>), dim3(grid), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
+    else if (nt)
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8, false, false, true>), dim3(grid), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
     else
-      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8>), dim3(maps), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);
+      hipLaunchKernelGGL((pwr::decode_bwd_cached<512, 8>), dim3(grid), dim3(512), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);
   }
   else
     hipLaunchKernelGGL((pwr::decode_bwd_generic<256>), dim3(maps), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method);

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -65,7 +66,8 @@ struct Ctx {
   // Side ops held back while `defer` is set (run_on_side appends them here), issued by the op that clears it: the heads' weight gradients
   // wait until the heads' data-gradient chain -- full-chip kernels -- has been issued and then run beside the hourglass backward, whose
   // kernels are small (Engine::heads_bwd)
-  std::vector<std::function<int(Ctx&)>> deferred;
+  struct Deferred { std::function<int(Ctx&)> fn; bool light; };
+  std::vector<Deferred> deferred;
   bool defer = false;
 };
 
@@ -145,12 +147,15 @@ static int elim_mask() {
 // the step takes 0.33 ms less -- but batching several ops behind one event (fewer markers in the chain's queue, each op issued a few
 // chain kernels later) made the step SLOWER, 6.47 ms at one op per event against 6.8 - 7.1 ms at 2 .. 12: what counts is that the
 // parameter-gradient work starts as early as it can, because the chain waits for it at the end of every segment.
-static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op, bool forked = false) {
+// light: a launch of a few microseconds (the parameter sums of a norm backward, round 6) goes BEHIND the op issued last -- onto that op's
+// stream -- and does not advance the round-robin: in the hourglass / stem sequences weight gradients and norm backwards alternate, so with
+// two side streams a light op that took its own turn put EVERY weight gradient on one stream (measured: +0.25 ms per step).
+static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op, bool forked = false, bool light = false) {
   if (elim_mask() & 1) return 0;
   if (!c.use_side || c.n_side == 0) return op(c);
-  if (c.defer) { c.deferred.push_back(op); return 0; }
-  const int k = c.side_rr;
-  c.side_rr = (k + 1) % c.n_side;
+  if (c.defer) { c.deferred.push_back(Ctx::Deferred{op, light}); return 0; }
+  const int k = light ? (c.side_rr + c.n_side - 1) % c.n_side : c.side_rr;
+  if (!light) c.side_rr = (k + 1) % c.n_side;
   if (!forked && !(elim_mask() & 8)) {     // (bit 3, debug build: side ops NOT ordered behind the chain; forked: the caller has ordered the side streams behind the chain already)
     hipEvent_t ev = c.ev_fork[c.fork_rr];
     c.fork_rr = (c.fork_rr + 1) % c.n_fork;
@@ -169,14 +174,23 @@ static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op, bool f
 // A launch op, tagged with the scope (network part: "stem", "s0.hg3", "s1.heads", "s1.plane.bwd" ...) that was current when it was built --
 // the backward lists are built in reverse and spliced, so the tag travels with the op.  Used by the debug build's per-scope timing
 // (pwr_engine_set_timing / pwr_engine_timing_report, include/pwr_debug.h); free otherwise.
-static std::vector<std::string*> g_scope_names;
-static const char* g_scope_tag = "";
+// The tags exist in the DEBUG build only.  There the current tag is a thread-local pointer into strings owned by the Engine being built
+// (ScopeName::names, freed with the plan): two plans built concurrently on different threads do not see each other's tags, and nothing
+// outlives its plan.  The product build carries no tag, allocates nothing per scope change and has no global to race on.
+#ifdef PWR_DEBUG_BUILD
+static thread_local const char* g_scope_tag = "";
+#endif
 struct ScopeName {
   std::string s;
+#ifdef PWR_DEBUG_BUILD
+  std::vector<std::unique_ptr<std::string>> names;
+#endif
   ScopeName& operator=(const std::string& v) {
     s = v;
-    g_scope_names.push_back(new std::string(v));          // (a handful per plan; they live as long as the library)
-    g_scope_tag = g_scope_names.back()->c_str();
+#ifdef PWR_DEBUG_BUILD
+    names.emplace_back(new std::string(v));
+    g_scope_tag = names.back()->c_str();
+#endif
     return *this;
   }
 };
@@ -185,7 +199,11 @@ struct Op {
   const char* tag;
   Op() : tag("") {}
   template <class F, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, Op>::value>::type>
+#ifdef PWR_DEBUG_BUILD
   Op(F&& fn) : f(std::forward<F>(fn)), tag(g_scope_tag) {}
+#else
+  Op(F&& fn) : f(std::forward<F>(fn)), tag("") {}
+#endif
   int operator()(Ctx& c) const { return f(c); }
 };
 
@@ -411,20 +429,43 @@ struct Engine {
   }
   // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
   // chunks > 0: the data-gradient conv that produced g already wrote the two reductions (conv_bwd's return value)
-  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0, bool handoff = false, size_t cpart_off = 0) {
+  // Round 6 (fold): with instance norm and a slab of its OWN (own_off: conv_bwd allocated it for this layer; or the hand-off buffer), the
+  // reduction launch leaves the chain: ONE apply launch that sums the slab rows of its sample itself (pwr_norm_bwd_apply_from_partial,
+  // bit-identical dy) and the parameter sums on a side stream from the same slab (nothing else ever writes it within a step).
+  static constexpr size_t kNoOwn = ~(size_t)0;
+  bool fold_ok(int C) const {
+    static const bool on = PWR_DBG_ENV("PWR_NORM_BWD_FOLD", 1) != 0;
+    return on && norm_mode == 0 && 2 * C <= 1024;
+  }
+  void norm_bwd(const Tn& t, const NormL& n, size_t addend_goff, bool has_addend, int chunks = 0, bool handoff = false, size_t cpart_off = 0,
+                size_t own_off = kNoOwn) {
     const int HW = t.H * t.W, C = t.C, Bc = B, dt = dtype, nm = norm_mode;
     Engine* E = this;
     const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
     if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
+    const bool own = own_off != kNoOwn;
+    const bool fold = chunks > 0 && (own || handoff) && fold_ok(C);
     // (Measured and dropped, DESIGN.md section 4: one-block-per-sample, split and deferred-dgamma forms of this step.)
     bwd_cur.push_back([=](Ctx& c) {
       if (elim_mask() & 2) return 0;
       const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
-      if (chunks > 0 && mode != 2)   // (eval-mode batch norm: statistics are constants, the plain path handles it)
-        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->*cpart + cpart_off),
+      if (chunks > 0 && mode != 2) {  // (eval-mode batch norm: statistics are constants, the plain path handles it)
+        float* part = own ? (float*)(c.arena + own_off) : (float*)(c.arena + E->*cpart + cpart_off);
+        if (fold) {
+          int rc = pwr_norm_bwd_apply_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), part,
+                                                   has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, nullptr, nullptr, nullptr, nullptr,
+                                                   nullptr, chunks, 1, Bc, HW, C, dt, c.stream);
+          if (rc) return rc;
+          return run_on_side(c, [=](Ctx& c2) {
+            float* part2 = own ? (float*)(c2.arena + own_off) : (float*)(c2.arena + E->*cpart + cpart_off);
+            return pwr_norm_bwd_params_from_partial(part2, c2.grads + n.gamma, c2.grads + n.beta, nullptr, nullptr, nullptr, chunks, 0, Bc, HW, C, c2.stream);
+          }, false, true);
+        }
+        return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), part,
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                                          has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma,
                                          c.grads + n.beta, 0, 1, Bc, HW, C, mode, dt, c.stream);
+      }
       return pwr_norm_bwd(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), (float*)(c.arena + E->scr_partial),
                           (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
                           has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, c.grads + n.gamma, c.grads + n.beta, 0,
@@ -434,21 +475,37 @@ struct Engine {
 
   // the norm backwards of the two heads' tensors of one depth (instance norm, reductions already written by the paired data gradient at
   // cpartial + 0 / + off_b): two launches instead of four on a stretch where the chain runs alone
-  void norm_bwd_pair(const Tn& ta, const NormL& na, const Tn& tb, const NormL& nb, int chunks, size_t off_b) {
+  // own_off != kNoOwn: the two slabs live at own_off / own_off + off_b in a buffer of this depth's own -> the fold (see norm_bwd)
+  void norm_bwd_pair(const Tn& ta, const NormL& na, const Tn& tb, const NormL& nb, int chunks, size_t off_b, size_t own_off = kNoOwn) {
     static const bool on = PWR_DBG_ENV("PWR_NORM_BWD_PAIR", 1) != 0;
     if (!on || norm_mode != 0 || chunks <= 0 || ta.H != tb.H || ta.W != tb.W || ta.C != tb.C) {
-      norm_bwd(ta, na, 0, false, chunks, false, 0);
-      norm_bwd(tb, nb, 0, false, chunks, false, off_b);
+      norm_bwd(ta, na, 0, false, chunks, false, 0, own_off);
+      norm_bwd(tb, nb, 0, false, chunks, false, off_b, own_off == kNoOwn ? kNoOwn : own_off + off_b);
       return;
     }
     const int HW = ta.H * ta.W, C = ta.C, Bc = B, dt = dtype;
     Engine* E = this;
     if ((size_t)2 * B * C * 4 > need_sc) need_sc = (size_t)2 * B * C * 4;
+    const bool own = own_off != kNoOwn;
+    const bool fold = own && fold_ok(C);
     bwd_cur.push_back([=](Ctx& c) {
       if (elim_mask() & 2) return 0;
-      return pwr_norm_bwd_from_partial_pair(c.arena + ta.goff, c.arena + ta.off, (float*)(c.arena + na.state), (float*)(c.arena + E->scr_cpartial),
+      float* pa = own ? (float*)(c.arena + own_off) : (float*)(c.arena + E->scr_cpartial);
+      float* pb = own ? (float*)(c.arena + own_off + off_b) : (float*)(c.arena + E->scr_cpartial + off_b);
+      if (fold) {
+        int rc = pwr_norm_bwd_apply_from_partial(c.arena + ta.goff, c.arena + ta.off, (float*)(c.arena + na.state), pa, nullptr, c.arena + ta.goff,
+                                                 c.arena + tb.goff, c.arena + tb.off, (float*)(c.arena + nb.state), pb, c.arena + tb.goff, chunks, 1, Bc,
+                                                 HW, C, dt, c.stream);
+        if (rc) return rc;
+        return run_on_side(c, [=](Ctx& c2) {
+          return pwr_norm_bwd_params_from_partial((float*)(c2.arena + own_off), c2.grads + na.gamma, c2.grads + na.beta,
+                                                  (float*)(c2.arena + own_off + off_b), c2.grads + nb.gamma, c2.grads + nb.beta, chunks, 0, Bc, HW, C,
+                                                  c2.stream);
+        }, false, true);
+      }
+      return pwr_norm_bwd_from_partial_pair(c.arena + ta.goff, c.arena + ta.off, (float*)(c.arena + na.state), pa,
                                             c.arena + ta.goff, c.grads + na.gamma, c.grads + na.beta, c.arena + tb.goff, c.arena + tb.off,
-                                            (float*)(c.arena + nb.state), (float*)(c.arena + E->scr_cpartial + off_b), c.arena + tb.goff,
+                                            (float*)(c.arena + nb.state), pb, c.arena + tb.goff,
                                             c.grads + nb.gamma, c.grads + nb.beta, chunks, (float*)(c.arena + E->scr_S1),
                                             (float*)(c.arena + E->scr_S2), 0, 1, Bc, HW, C, dt, c.stream);
     });
@@ -542,11 +599,9 @@ struct Engine {
                                 c.arena + tb.off, Bc, xb.H, xb.W, cb.Cin, cb.Cout, cb.k, 1, 0, pb, nullptr, nullptr, nullptr, 1, dt, c.stream);
       }
       if (rc) return rc;
-      rc = pwr_norm_finalize_partial(pa, chunks, c.params + ona.gamma, c.params + ona.beta, nullptr, nullptr, (float*)(c.arena + ona.state), Bc,
-                                     HWo, ca.Cout, 0, 1e-5f, 0.1f, c.stream);
-      if (rc) return rc;
-      return pwr_norm_finalize_partial(pb, chunks, c.params + onb.gamma, c.params + onb.beta, nullptr, nullptr, (float*)(c.arena + onb.state), Bc,
-                                       HWo, cb.Cout, 0, 1e-5f, 0.1f, c.stream);
+      // (round 6: ONE finalisation launch for the two heads' norms)
+      return pwr_norm_finalize_partial_pair(pa, c.params + ona.gamma, c.params + ona.beta, (float*)(c.arena + ona.state), pb, c.params + onb.gamma,
+                                            c.params + onb.beta, (float*)(c.arena + onb.state), chunks, Bc, HWo, ca.Cout, 1e-5f, c.stream);
     });
   }
 
@@ -558,8 +613,11 @@ struct Engine {
     if (!nr || accumulate_dx || cv.stride > 2 || !(stats_mask() & 2)) return 0;
     return pwr_conv_stats_chunks(y.H, y.W, cv.Cout, cv.Cin, cv.k, 1, cv.stride == 2 ? 1 : 0, dtype);
   }
+  // own_out != null: where the norm backward of `nr` can take the fold (norm_bwd), the slab is a buffer of this layer's own and *own_out is
+  // its arena offset (kNoOwn otherwise): pass it on to norm_bwd
   int conv_bwd(const Tn& x, const NormL* nr, const ConvL& cv, const Tn& y, bool bias_grad, bool need_dx, bool accumulate_dx,
-               bool handoff = false) {
+               bool handoff = false, size_t* own_out = nullptr) {
+    if (own_out) *own_out = kNoOwn;
     const int Bc = B, dt = dtype;
     const bool has_nr = nr != nullptr;
     const NormL n = has_nr ? *nr : NormL{};
@@ -585,7 +643,9 @@ struct Engine {
     const int chunks = dgrad_stats_chunks(nr, cv, y, accumulate_dx);
     if (chunks > 0) {
       const size_t need = (size_t)B * chunks * 2 * cv.Cin * 4;
+      size_t own = kNoOwn;
       if (handoff) { if (need > need_handoff) need_handoff = need; }
+      else if (own_out && fold_ok(cv.Cin)) { own = alloc(need, "nbpart"); *own_out = own; }
       else if (need > need_cpartial) need_cpartial = need;
       const int nm = norm_mode;
       const size_t Engine::*cpart = handoff ? &Engine::scr_handoff : &Engine::scr_cpartial;
@@ -597,7 +657,7 @@ struct Engine {
                               cv.Cout, cv.Cin, cv.k, 1, cv.stride == 2 ? 1 : 0, dt, c.stream);
         return pwr_conv_fwd_stats(c.arena + y.goff, c.packs + cv.pack_d, nullptr, nullptr, 0, nullptr, c.arena + x.goff, Bc, y.H, y.W,
                                   cv.Cout, cv.Cin, cv.k, 1, cv.stride == 2 ? 1 : 0, nullptr, c.arena + x.off, (float*)(c.arena + n.state),
-                                  (float*)(c.arena + E->*cpart), 1, dt, c.stream);
+                                  own != kNoOwn ? (float*)(c.arena + own) : (float*)(c.arena + E->*cpart), 1, dt, c.stream);
       });
       return chunks;
     }
@@ -659,12 +719,13 @@ struct Engine {
       // reverse order: pushed first = executed last
       std::vector<Op> blk;
       std::swap(blk, bwd_cur);
-      int ch = conv_bwd(r.t2, &r.nc, r.cc, out, true, true, false);
-      norm_bwd(r.t2, r.nc, 0, false, ch);
-      ch = conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, true, false);
-      norm_bwd(r.t1, r.nb, 0, false, ch);
-      ch = conv_bwd(x, &r.na, r.ca, r.t1, false, true, false);
-      norm_bwd(x, r.na, out.goff, true, ch);  // x.g = out.g (skip) + NRbwd(g)
+      size_t own = kNoOwn;
+      int ch = conv_bwd(r.t2, &r.nc, r.cc, out, true, true, false, false, &own);
+      norm_bwd(r.t2, r.nc, 0, false, ch, false, 0, own);
+      ch = conv_bwd(r.t1, &r.nb, r.cb, r.t2, false, true, false, false, &own);
+      norm_bwd(r.t1, r.nb, 0, false, ch, false, 0, own);
+      ch = conv_bwd(x, &r.na, r.ca, r.t1, false, true, false, false, &own);
+      norm_bwd(x, r.na, out.goff, true, ch, false, 0, own);  // x.g = out.g (skip) + NRbwd(g)
       append_block(blk);
     }
     return out;
@@ -879,7 +940,8 @@ struct Engine {
     const Tn h3 = h.h3; const NormL n2 = h.n2; const ConvL c3 = h.c3; const size_t gT = h.gT;
     const int nm = norm_mode;
     const int ch3 = (stats_mask() & 2) ? pwr_conv_stats_chunks(P, P, Jp, c3.Cin, c3.k, 1, 0, dtype) : 0;
-    if (ch3 > 0 && (size_t)B * ch3 * 2 * c3.Cin * 4 > need_cpartial) need_cpartial = (size_t)B * ch3 * 2 * c3.Cin * 4;
+    const size_t own3 = (ch3 > 0 && fold_ok(c3.Cin)) ? alloc((size_t)B * ch3 * 2 * c3.Cin * 4, "nbpart") : kNoOwn;
+    if (ch3 > 0 && own3 == kNoOwn && (size_t)B * ch3 * 2 * c3.Cin * 4 > need_cpartial) need_cpartial = (size_t)B * ch3 * 2 * c3.Cin * 4;
     bwd_cur.push_back([=](Ctx& c) {
       int rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + g_nchw_off), c.arena + gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
       if (rc) return rc;
@@ -893,16 +955,17 @@ struct Engine {
       const int mode = nm == 0 ? 0 : (c.training ? 1 : 2);
       if (ch3 > 0 && mode != 2)
         return pwr_conv_fwd_stats(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, Bc, Pc, Pc, Jp, c3.Cin,
-                                  c3.k, 1, 0, nullptr, c.arena + h3.off, (float*)(c.arena + n2.state), (float*)(c.arena + E->scr_cpartial),
-                                  1, dt, c.stream);
+                                  c3.k, 1, 0, nullptr, c.arena + h3.off, (float*)(c.arena + n2.state),
+                                  own3 != kNoOwn ? (float*)(c.arena + own3) : (float*)(c.arena + E->scr_cpartial), 1, dt, c.stream);
       return pwr_conv_fwd(c.arena + gT, c.packs + c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + h3.goff, nullptr, Bc, Pc, Pc,
                           Jp, c3.Cin, c3.k, 1, 0, dt, c.stream);
     });
-    norm_bwd(h.h3, h.n2, 0, false, ch3);
-    int ch = conv_bwd(h.h2, &h.n1, h.c2, h.h3, false, true, false);
-    norm_bwd(h.h2, h.n1, 0, false, ch);
-    ch = conv_bwd(h.h1, &h.n0, h.c1, h.h2, false, true, false);
-    norm_bwd(h.h1, h.n0, 0, false, ch);
+    norm_bwd(h.h3, h.n2, 0, false, ch3, false, 0, own3);
+    size_t own = kNoOwn;
+    int ch = conv_bwd(h.h2, &h.n1, h.c2, h.h3, false, true, false, false, &own);
+    norm_bwd(h.h2, h.n1, 0, false, ch, false, 0, own);
+    ch = conv_bwd(h.h1, &h.n0, h.c1, h.h2, false, true, false, false, &own);
+    norm_bwd(h.h1, h.n0, 0, false, ch, false, 0, own);
     conv_bwd(f, nullptr, h.c0, h.h1, false, true, accumulate_df);
   }
 
@@ -925,7 +988,12 @@ struct Engine {
     const int Bc = B, dt = dtype, Jc = J, Pc = P, Fc = F, kk = ks;
     const int M = B * P * P;
     const size_t half = ((size_t)B * ch * 2 * F * 4 + 255) / 256 * 256;
-    if (2 * half > need_cpartial) need_cpartial = 2 * half;
+    // the norm-backward slabs of the three depths: buffers of their own where the fold applies (norm_bwd), else the shared scratch
+    const bool fold = fold_ok(F);
+    size_t own[3] = {kNoOwn, kNoOwn, kNoOwn};
+    for (int q = 0; q < 3 && fold; ++q) own[q] = alloc(2 * half, "nbpart2");
+    const size_t own0 = own[0];
+    if (!fold && 2 * half > need_cpartial) need_cpartial = 2 * half;
     const int splits3 = splits_for(M, F, Jp, ks);
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits3));
     want_slab((size_t)B * J * 4);
@@ -966,8 +1034,8 @@ struct Engine {
         });
       }
       if (rc) return rc;
-      float* pa = (float*)(c.arena + E->scr_cpartial);
-      float* pb = (float*)(c.arena + E->scr_cpartial + half);
+      float* pa = (float*)(c.arena + (fold ? own0 : E->scr_cpartial));
+      float* pb = (float*)(c.arena + (fold ? own0 : E->scr_cpartial) + half);
       rc = pwr_conv_dgrad_stats_pair(c.arena + P_.gT, c.packs + P_.c3.pack_d, c.arena + P_.h3.goff, c.arena + P_.h3.off, (float*)(c.arena + P_.n2.state), pa,
                                      c.arena + D_.gT, c.packs + D_.c3.pack_d, c.arena + D_.h3.goff, c.arena + D_.h3.off, (float*)(c.arena + D_.n2.state), pb,
                                      1, Bc, Pc, Pc, Jp, Fc, kk, dt, c.stream);
@@ -978,12 +1046,13 @@ struct Engine {
       return pwr_conv_fwd_stats(c.arena + D_.gT, c.packs + D_.c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + D_.h3.goff, Bc, Pc, Pc, Jp, Fc, kk, 1, 0,
                                 nullptr, c.arena + D_.h3.off, (float*)(c.arena + D_.n2.state), pb, 1, dt, c.stream);
     });
-    norm_bwd_pair(hp.h3, hp.n2, hd.h3, hd.n2, ch, half);
+    norm_bwd_pair(hp.h3, hp.n2, hd.h3, hd.n2, ch, half, own[0]);
     // ---- conv depth 2, 1: (x, its norm, conv, y) per head
     struct Lvl { Tn xp, xd, yp, yd; NormL np, nd; ConvL cp, cd; };
     const Lvl lv[2] = {{hp.h2, hd.h2, hp.h3, hd.h3, hp.n1, hd.n1, hp.c2, hd.c2}, {hp.h1, hd.h1, hp.h2, hd.h2, hp.n0, hd.n0, hp.c1, hd.c1}};
     for (int q = 0; q < 2; ++q) {
       const Lvl L = lv[q];
+      const size_t ownq = own[q + 1];
       bwd_cur.push_back([=](Ctx& c) {
         int rc = run_on_side(c, [=](Ctx& c2) {
           float* slab = (float*)(c2.arena + E->scr_slab + c2.slab_off);
@@ -1000,8 +1069,8 @@ struct Engine {
         });
         if (rc) return rc;
         if (elim_mask() & 4) return 0;
-        float* pa = (float*)(c.arena + E->scr_cpartial);
-        float* pb = (float*)(c.arena + E->scr_cpartial + half);
+        float* pa = (float*)(c.arena + (fold ? ownq : E->scr_cpartial));
+        float* pb = (float*)(c.arena + (fold ? ownq : E->scr_cpartial) + half);
         rc = pwr_conv_dgrad_stats_pair(c.arena + L.yp.goff, c.packs + L.cp.pack_d, c.arena + L.xp.goff, c.arena + L.xp.off, (float*)(c.arena + L.np.state), pa,
                                        c.arena + L.yd.goff, c.packs + L.cd.pack_d, c.arena + L.xd.goff, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb,
                                        1, Bc, Pc, Pc, Fc, Fc, kk, dt, c.stream);
@@ -1012,7 +1081,7 @@ struct Engine {
         return pwr_conv_fwd_stats(c.arena + L.yd.goff, c.packs + L.cd.pack_d, nullptr, nullptr, 0, nullptr, c.arena + L.xd.goff, Bc, Pc, Pc, Fc, Fc, kk, 1, 0,
                                   nullptr, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb, 1, dt, c.stream);
       });
-      norm_bwd_pair(L.xp, L.np, L.xd, L.nd, ch, half);
+      norm_bwd_pair(L.xp, L.np, L.xd, L.nd, ch, half, ownq);
     }
     // (PWR_DEFER_FLUSH=1, debug build: release the held-back side work one op earlier, beside the two first-conv data gradients)
     if (defer_mode && PWR_DBG_ENV("PWR_DEFER_FLUSH", 0) == 1) bwd_cur.push_back(flush_deferred_op());
@@ -1040,7 +1109,7 @@ struct Engine {
   static Op flush_deferred_op() {
     return [](Ctx& c) {
       c.defer = false;
-      std::vector<std::function<int(Ctx&)>> d;
+      std::vector<Ctx::Deferred> d;
       d.swap(c.deferred);
       int rc = 0;
       // ONE fork for the whole batch: every held-back op depends on the chain as it stands here, so both side streams wait for one event
@@ -1053,7 +1122,7 @@ struct Engine {
         hipEventRecord(ev, (hipStream_t)c.stream);
         for (int k = 0; k < c.n_side; ++k) hipStreamWaitEvent(c.side[k], ev, 0);
       }
-      for (size_t i = 0; i < d.size() && !rc; ++i) rc = run_on_side(c, d[i], batch);
+      for (size_t i = 0; i < d.size() && !rc; ++i) rc = run_on_side(c, d[i].fn, batch, d[i].light);
       return rc;
     };
   }
@@ -1198,11 +1267,12 @@ struct Engine {
       // the gradient of the stem output comes from stage 0's 1x1 input conv (built above, run in the previous segment):
       // stem_in_chunks is what that launch really writes (its conv_bwd's return value), in the hand-off buffer
       int ch = stem_in_chunks;
+      size_t own = kNoOwn;
       for (int i = ns - 1; i >= 1; --i) {
-        norm_bwd(sy[i], sn[i], 0, false, ch, /*handoff=*/i == ns - 1);
-        ch = conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false);
+        norm_bwd(sy[i], sn[i], 0, false, ch, /*handoff=*/i == ns - 1, 0, own);
+        ch = conv_bwd(sy[i - 1], &sn[i - 1], sc[i], sy[i], false, true, false, false, &own);
       }
-      norm_bwd(sy[0], sn[0], 0, false, ch);
+      norm_bwd(sy[0], sn[0], 0, false, ch, false, 0, own);
       const Tn y0 = sy[0]; const ConvL c0 = sc[0];
       bwd_cur.push_back([=](Ctx& c) {
         return run_on_side(c, [=](Ctx& c2) {

@@ -434,6 +434,88 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_pair_kernel(NormBwdPair q,
                                 blockIdx.y);
 }
 
+// Round 6 -- the reduction launch taken off the chain (instance norm).  norm_bwd_sum_kernel is a 16-block launch of ~8 us whose only
+// consumer on the critical path is the apply launch behind it (S1, S2); its other outputs -- dgamma, dbeta -- feed the flat gradient only.
+// Here every workgroup of the apply launch sums the `pchunks` slab rows of ITS sample itself: 2 C sums, one per thread, every load of a sum
+// issued before the first add (32 in flight: ONE L2 round trip instead of 32 dependent ones -- round 5's experiment 13 walked them one
+// after the other in every one of the 1024 workgroups and lost 3.5 % of the step), added in norm_bwd_sum_body's order (k ascending), divided
+// by HW like there: S1, S2 and therefore dy are the same bits.  The parameter sums run on a side stream (norm_bwd_sum_kernel with
+// S1 = null) from the same slab, which therefore has to be the layer's own (the engine allocates one per norm).
+template <typename T>
+__device__ __forceinline__ void norm_bwd_apply_fold_body(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ state, int B,
+                                                         const float* __restrict__ partial, int pchunks, const T* __restrict__ addend,
+                                                         T* __restrict__ dy, int HW, int C, int nchunks, int relu, int chunk, int b) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  __shared__ float ssum[1024];     // [2][C], C <= 512
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int qq = i >= C ? 1 : 0, c = i - qq * C;
+    const float* pp = partial + ((size_t)b * pchunks * 2 + qq) * C + c;      // slab row k of this sum: pp[k * 2 C]
+    const size_t st = (size_t)2 * C;
+    float sacc = 0.f;
+    int k = 0;
+    for (; k + 32 <= pchunks; k += 32) {
+      float a[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) a[u] = pp[(size_t)(k + u) * st];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) sacc += a[u];
+    }
+    for (; k + 8 <= pchunks; k += 8) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = pp[(size_t)(k + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sacc += a[u];
+    }
+    for (; k < pchunks; ++k) sacc += pp[(size_t)k * st];
+    ssum[i] = sacc / (float)HW;
+  }
+  __syncthreads();
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  if (pj >= pl) return;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const size_t base = (size_t)b * HW * C;
+  const size_t plane = (size_t)B * C;
+  float mu[EP], rs[EP], sc[EP], sh[EP], s1[EP], s2[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int c = b * C + cq * EP + e;
+    mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
+    s1[e] = ssum[cq * EP + e]; s2[e] = ssum[C + cq * EP + e];
+  }
+#pragma unroll 4
+  for (int pp = p0 + pj; pp < p1; pp += pl) {
+    const size_t off = base + (size_t)pp * C + cq * EP;
+    V gv = *reinterpret_cast<const V*>(g + off);
+    V yv = *reinterpret_cast<const V*>(y + off);
+    V av = {};
+    if (addend) av = *reinterpret_cast<const V*>(addend + off);
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const float yy = Elem<T>::to_f(yv[e]);
+      float gg = Elem<T>::to_f(gv[e]);
+      if (relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
+      const float xn = (yy - mu[e]) * rs[e];
+      float r = sc[e] * (gg - s1[e] - xn * s2[e]);     // scale = gamma*rstd  (norm_bwd_apply_body's expression)
+      if (addend) r += Elem<T>::to_f(av[e]);
+      o[e] = Elem<T>::from_f(r);
+    }
+    *reinterpret_cast<V*>(dy + off) = o;
+  }
+}
+struct NormBwdFoldJob { const void* g; const void* y; const float* state; const float* partial; const void* addend; void* dy; };
+struct NormBwdFoldPair { NormBwdFoldJob j[2]; };
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_fold_kernel(NormBwdFoldPair q, int B, int HW, int C, int nchunks, int pchunks, int relu) {
+  const NormBwdFoldJob& j = q.j[blockIdx.z];
+  norm_bwd_apply_fold_body<T>((const T*)j.g, (const T*)j.y, j.state, B, j.partial, pchunks, (const T*)j.addend, (T*)j.dy, HW, C, nchunks, relu,
+                              blockIdx.x, blockIdx.y);
+}
+
 static inline int norm_chunks(int B, int HW) {
   int n = (1024 + B - 1) / B;
   int maxc = (HW + 31) / 32;
@@ -565,12 +647,12 @@ __global__ void norm_finalize_chunks_kernel(const float* __restrict__ partial, c
 // grid = (C/32, B).  Each thread merges its contiguous share of the chunks (equal sizes), the 8 group results are combined through LDS
 // in group order with the general pairwise formula.  One thread per (b, c) walking 128 chunks through two dependent divisions each
 // took 6.2 us on the critical chain 52 times per step.
-__global__ __launch_bounds__(256) void norm_finalize_chunks_par_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                                       const float* __restrict__ beta, float* __restrict__ state, int B, int HW,
-                                                                       int C, int chunks, float eps) {
+__device__ __forceinline__ void norm_finalize_chunks_par_body(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ state, int B, int HW,
+                                                              int C, int chunks, float eps, int bx, int b) {
   __shared__ float smean[8][33], sm2[8][33];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int b = blockIdx.y, c = blockIdx.x * 32 + cl;
+  const int c = bx * 32 + cl;
   const int per = chunks / 8;
   const float nper = (float)(HW / chunks), inv = 1.f / nper;
   float mean = 0.f, m2 = 0.f, cnt = 0.f;
@@ -612,6 +694,18 @@ __global__ __launch_bounds__(256) void norm_finalize_chunks_par_kernel(const flo
     state[idx] = M; state[plane + idx] = rstd; state[2 * plane + idx] = gamma[c] * rstd; state[3 * plane + idx] = beta[c];
   }
 }
+__global__ __launch_bounds__(256) void norm_finalize_chunks_par_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float* __restrict__ state, int B, int HW,
+                                                                       int C, int chunks, float eps) {
+  norm_finalize_chunks_par_body(partial, gamma, beta, state, B, HW, C, chunks, eps, blockIdx.x, blockIdx.y);
+}
+// two such finalisations of one shape in one launch (blockIdx.z picks the job): the two regression heads' norms of one depth (round 6: the
+// heads' stretch of the forward runs alone on the chain, every launch boundary there is exposed)
+struct FinalizePair { const float* partial[2]; const float* gamma[2]; const float* beta[2]; float* state[2]; };
+__global__ __launch_bounds__(256) void norm_finalize_chunks_par_pair_kernel(FinalizePair q, int B, int HW, int C, int chunks, float eps) {
+  const int z = blockIdx.z;
+  norm_finalize_chunks_par_body(q.partial[z], q.gamma[z], q.beta[z], q.state[z], B, HW, C, chunks, eps, blockIdx.x, blockIdx.y);
+}
 
 }  // namespace pwr
 
@@ -627,6 +721,21 @@ extern "C" int pwr_norm_finalize_partial(const float* partial, int chunks, const
   else
     hipLaunchKernelGGL(norm_finalize_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, state,
                        running_mean, running_var, B, HW, C, chunks, mode, eps, momentum);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pwr_norm_finalize_partial_pair(const float* partial_a, const float* gamma_a, const float* beta_a, float* state_a,
+                                              const float* partial_b, const float* gamma_b, const float* beta_b, float* state_b, int chunks,
+                                              int B, int HW, int C, float eps, void* stream) {
+  if (chunks < 1 || HW % chunks) return PWR_EINVAL;
+  static const bool par = (PWR_DBG_ENV("PWR_NORM_PAR", 1) != 0);
+  if (!(par && chunks % 8 == 0 && chunks >= 16)) {       // (the shapes pwr_norm_finalize_partial runs on its one-thread-per-channel kernel)
+    int rc = pwr_norm_finalize_partial(partial_a, chunks, gamma_a, beta_a, nullptr, nullptr, state_a, B, HW, C, 0, eps, 0.1f, stream);
+    if (rc) return rc;
+    return pwr_norm_finalize_partial(partial_b, chunks, gamma_b, beta_b, nullptr, nullptr, state_b, B, HW, C, 0, eps, 0.1f, stream);
+  }
+  pwr::FinalizePair q{{partial_a, partial_b}, {gamma_a, gamma_b}, {beta_a, beta_b}, {state_a, state_b}};
+  hipLaunchKernelGGL(pwr::norm_finalize_chunks_par_pair_kernel, dim3((C + 31) / 32, B, 2), dim3(256), 0, (hipStream_t)stream, q, B, HW, C, chunks, eps);
   return (int)hipGetLastError();
 }
 
@@ -701,6 +810,44 @@ extern "C" int pwr_norm_bwd_from_partial(const void* g, const void* y, const flo
   } else {
     hipLaunchKernelGGL((norm_bwd_apply_kernel<float, false>), dim3(nch, B), dim3(256), 0, s, (const float*)g, (const float*)y, state, B,
                        S1, S2, (const float*)addend, (float*)dy, HW, C, nch, relu);
+  }
+  return (int)hipGetLastError();
+}
+
+// Round 6 (instance norm): pwr_norm_bwd_from_partial as ONE launch on the caller's stream -- the apply kernel sums the slab rows of its
+// sample itself (norm_bwd_apply_fold_body) -- for one tensor, or for the two heads' tensors of one depth (gb != NULL: blockIdx.z picks the
+// job).  dy is bit-identical to pwr_norm_bwd_from_partial's.  The parameter gradients come from pwr_norm_bwd_params_from_partial on the
+// same slab (any stream ordered behind the launch that wrote the slab).
+extern "C" int pwr_norm_bwd_apply_from_partial(const void* ga, const void* ya, const float* state_a, const float* partial_a, const void* addend_a,
+                                               void* dya, const void* gb, const void* yb, const float* state_b, const float* partial_b, void* dyb,
+                                               int chunks, int relu, int B, int HW, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256 || 2 * C > 1024 || chunks < 1) return PWR_EUNSUPPORTED;
+  if (!ga || !ya || !state_a || !partial_a || !dya || (gb && (!yb || !state_b || !partial_b || !dyb))) return PWR_EINVAL;
+  const int nch = norm_chunks(B, HW);
+  NormBwdFoldPair q;
+  q.j[0] = NormBwdFoldJob{ga, ya, state_a, partial_a, addend_a, dya};
+  q.j[1] = NormBwdFoldJob{gb, yb, state_b, partial_b, nullptr, dyb};
+  const dim3 grid(nch, B, gb ? 2 : 1);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
+  else hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
+  return (int)hipGetLastError();
+}
+
+// dgamma / dbeta (+)= from the slab of pwr_conv_fwd_stats (nb_partial): the reduction launch of pwr_norm_bwd_from_partial without its
+// S1 / S2 outputs (same kernel, same order, same bits); partial_b != NULL: a second job of the same shape in the same launch.
+extern "C" int pwr_norm_bwd_params_from_partial(const float* partial_a, float* dgamma_a, float* dbeta_a, const float* partial_b, float* dgamma_b,
+                                                float* dbeta_b, int chunks, int accumulate, int B, int HW, int C, void* stream) {
+  if (!partial_a || !dgamma_a || !dbeta_a || chunks < 1 || (partial_b && (!dgamma_b || !dbeta_b))) return PWR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (!partial_b) {
+    hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial_a, (float*)nullptr, (float*)nullptr, dgamma_a, dbeta_a, B, HW,
+                       C, chunks, 0, accumulate);
+  } else {
+    NormBwdPair q;
+    q.j[0] = NormBwdJob{nullptr, nullptr, nullptr, partial_a, nullptr, nullptr, nullptr, dgamma_a, dbeta_a};
+    q.j[1] = NormBwdJob{nullptr, nullptr, nullptr, partial_b, nullptr, nullptr, nullptr, dgamma_b, dbeta_b};
+    hipLaunchKernelGGL(norm_bwd_sum_pair_kernel, dim3((C + 7) / 8, 2), dim3(256), 0, s, q, B, HW, C, chunks, accumulate);
   }
   return (int)hipGetLastError();
 }

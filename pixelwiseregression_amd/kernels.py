@@ -69,8 +69,8 @@ def pack_conv(weight, kind, dtype, frag=False):
     """weight: OIHW fp32 cuda tensor -> packed uint8 buffer for pwr_conv_fwd.  frag: the fragment-order pack (bf16 128 x 128 3x3 only)."""
     l = _lib.lib()
     cout, cin, k, _ = weight.shape
-    if frag and not (dtype == BF16 and cout == 128 and cin == 128 and k == 3 and kind in (0, 1)):
-        raise ValueError("fragment-order packs exist for bf16 128 x 128 3x3 stride-1 weights")
+    if frag and not (dtype == BF16 and cout == 128 and cin == 128 and k == 3 and kind == 0):
+        raise ValueError("fragment-order packs exist for the forward (kind 0) bf16 128 x 128 3x3 stride-1 weights only (include/pwr.h)")
     nbytes = l.pwr_conv_pack_bytes(cout, cin, k, kind, dtype)
     packs = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     flat = weight.contiguous().float().view(-1)
@@ -491,3 +491,32 @@ def norm_bwd_from_partial(g, y, state, partial, chunks, relu=True, addend=None, 
     return dy, dgamma, dbeta
 
 
+def norm_bwd_fold(g, y, state, partial, chunks, relu=True, addend=None, pair=None):
+    """Round 6: pwr_norm_bwd_from_partial as ONE launch on the stream (the apply step sums the slab rows itself) + the parameter sums as a
+    launch of their own (pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial).  pair = (g_b, y_b, state_b, partial_b): a second
+    tensor of the same shape in the same launches.  Returns (dy, dgamma, dbeta) or, with `pair`, two such tuples."""
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    dev = y.device
+    outs = [(torch.empty_like(y), torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev))]
+    gb = yb = sb = pb = None
+    if pair is not None:
+        gb, yb, sb, pb = pair
+        outs.append((torch.empty_like(yb), torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)))
+    _lib.check(l.pwr_norm_bwd_apply_from_partial(_p(g), _p(y), _p(state), _p(partial), _p(addend), _p(outs[0][0]), _p(gb), _p(yb), _p(sb), _p(pb),
+                                                 _p(outs[1][0]) if pair is not None else None, chunks, int(relu), B, H * W, C, _dt(y), _s(y)),
+               "pwr_norm_bwd_apply_from_partial")
+    _lib.check(l.pwr_norm_bwd_params_from_partial(_p(partial), _p(outs[0][1]), _p(outs[0][2]), _p(pb), _p(outs[1][1]) if pair is not None else None,
+                                                  _p(outs[1][2]) if pair is not None else None, chunks, 0, B, H * W, C, _s(y)),
+               "pwr_norm_bwd_params_from_partial")
+    return outs if pair is not None else outs[0]
+
+
+def norm_finalize_partial_pair(partial_a, gamma_a, beta_a, partial_b, gamma_b, beta_b, chunks, B, HW, eps=1e-5):
+    """two norm_finalize_partial (instance norm) of one shape as one launch.  Returns state_a, state_b."""
+    l = _lib.lib()
+    C = gamma_a.numel()
+    sa, sb = (torch.empty(4, B, C, dtype=torch.float32, device=partial_a.device) for _ in range(2))
+    _lib.check(l.pwr_norm_finalize_partial_pair(_p(partial_a), _p(gamma_a), _p(beta_a), _p(sa), _p(partial_b), _p(gamma_b), _p(beta_b), _p(sb), chunks, B, HW,
+                                                C, eps, _s(partial_a)), "pwr_norm_finalize_partial_pair")
+    return sa, sb

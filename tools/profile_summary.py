@@ -1,4 +1,4 @@
-"""Summaries of tools/profile_r5.sh's (earlier rounds: profile_r2.sh ... profile_r4.sh) rocprofv3 output -> small csv / json files for profiles/ (run on the GPU
+"""Summaries of tools/profile_r6.sh's (earlier rounds: profile_r2.sh ... profile_r5.sh) rocprofv3 output -> small csv / json files for profiles/ (run on the GPU
 box, right after).   python tools/profile_summary.py <raw dir> <out dir> [prefix = r3]"""
 import collections, csv, glob, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
@@ -47,33 +47,51 @@ fe, wr = mean_by_kernel("pmc_fetch", "FETCH_SIZE"), mean_by_kernel("pmc_write", 
 fe.update(mean_by_kernel("pmc_fetch24", "FETCH_SIZE")); wr.update(mean_by_kernel("pmc_write24", "WRITE_SIZE"))
 
 
-def entry(table_f, table_w, match, grid, alg, label):
-    ks = [k for k in table_f if match in k[0] and (grid is None or k[1] == str(grid))]
+MISSING = []      # named kernels without a counter row although their PMC pass ran: reported and the script exits non-zero
+
+
+def entry(table_f, table_w, match, grid, alg, label, required=True):
+    """One row of <PRE>_traffic.json.  `match` is a PREFIX-free substring of the kernel name that must pin down ONE kernel (give template
+    arguments up to a comma, e.g. "conv3x3_wstat_kernel<true, 0," -- a further template parameter then still matches); `grid` selects among
+    launches of that kernel at several grid sizes.  Several (kernel, grid) keys matching with grid = None is an ERROR (round 5 averaged
+    whichever came first: the 80-split reduce against round 4's 24-split one), so is no match when the pass has data at all."""
+    ks = sorted(k for k in table_f if match in k[0] and (grid is None or k[1] == str(grid)))
     if not ks:
+        if table_f and required:
+            MISSING.append("%s (match %r, grid %s): no such kernel in the FETCH_SIZE pass" % (label, match, grid))
+        return
+    if len(ks) > 1:
+        MISSING.append("%s (match %r): %d (kernel, grid) keys match -- give a grid: %s" % (label, match, len(ks), [(short(k[0])[:60], k[1]) for k in ks]))
         return
     k = ks[0]
     w = table_w.get(k, 0.0)
-    out[label] = {"FETCH_SIZE_KB": table_f[k], "WRITE_SIZE_KB": w, "hbm_bytes_corrected": int(2 * table_f[k] * 1024 + w * 1024)}
+    out[label] = {"kernel": short(k[0]), "grid_size": k[1], "FETCH_SIZE_KB": table_f[k], "WRITE_SIZE_KB": w,
+                  "hbm_bytes_corrected": int(2 * table_f[k] * 1024 + w * 1024)}
     if alg:
         out[label]["algorithmic_bytes"] = alg
         out[label]["ratio"] = out[label]["hbm_bytes_corrected"] / alg
 
 
-entry(fe, wr, "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_patch_kernel<bf16,128,2,2,2,2> B=32 64x64 128->128")
-entry(fe, wr, "conv3x3_wstat_kernel<true, 0>", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_wstat_kernel<norm prologue, no statistics> B=32 64x64 128->128")
-entry(fe, wr, "conv3x3_wstat_kernel<false, 0>", None, 2 * act + 128 * 128 * 9 * 2, "conv3x3_wstat_kernel<plain> B=32 64x64 128->128")
-entry(fe, wr, "conv_wgrad3d_kernel<64, 128>", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3d_kernel<64,128> same shape")
-entry(fe, wr, "conv_wgrad3_kernel<2, 2, 1, 2", None, 2 * act + 128 * 128 * 9 * 4, "conv_wgrad3_kernel<2,2,1,2> same shape")
-entry(fe, wr, "wgrad_reduce_fast_kernel<9", None, None, "wgrad_reduce_fast_kernel<9,3> same shape (80 slabs)")
+wts = 128 * 128 * 9 * 2
+# (tools/bench_kernels.py launches the patch kernel as the DATA GRADIENT with the norm-backward sums: it reads dy AND the forward activations y
+# and writes dx -- three activation tensors, not two.  Round 5's file priced it at two and showed "1.59 x"; round 4's 1.05 x was the forward form.)
+entry(fe, wr, "conv3x3_patch_kernelIDF16bLi128ELi2ELi2ELi2ELi2ELb1", None, 3 * act + wts + B * 32 * 2 * 128 * 4,
+      "conv3x3_patch_kernel<bf16,128,2,2,2,2> data gradient + norm-backward sums (reads dy and y, writes dx) B=32 64x64 128->128")
+entry(fe, wr, "conv3x3_wstat_kernel<true, 0,", None, 2 * act + wts, "conv3x3_wstat_kernel<norm prologue, no statistics> B=32 64x64 128->128")
+entry(fe, wr, "conv3x3_wstat_kernel<false, 0,", None, 2 * act + wts, "conv3x3_wstat_kernel<plain> B=32 64x64 128->128")
+entry(fe, wr, "conv3x3_wstat_kernel<true, 3,", None, act + B * P * P * 14 * 4 + 32 * 128 * 9 * 2, "conv3x3_wstat_kernel<narrow form 128 -> 14, fp32 NCHW out> B=32 64x64", required=False)
 # round 4: the wave-specialised kernel, at the isolated comparison's 80 splits (240 workgroups of 512 threads) and at the engine's 24 (72)
 for sp, grid in ((80, 240 * 512), (24, 72 * 512)):
-    entry(fe, wr, "conv_wgrad3w_kernel<true, true>", grid, 2 * act + sp * 128 * 128 * 9 * 4, "conv_wgrad3w_kernel<norm> same shape, %d splits (algorithmic bytes incl. its split-K slabs)" % sp)
-    entry(fe, wr, "conv_wgrad3w_kernel<false, false>", grid, 2 * act + sp * 128 * 128 * 9 * 4, "conv_wgrad3w_kernel<no norm> same shape, %d splits (algorithmic bytes incl. its split-K slabs)" % sp)
+    entry(fe, wr, "conv_wgrad3w_kernel<true, true,", grid, 2 * act + sp * 128 * 128 * 9 * 4, "conv_wgrad3w_kernel<norm> same shape, %d splits (algorithmic bytes incl. its split-K slabs)" % sp, required=False)
+    entry(fe, wr, "conv_wgrad3w_kernel<false, false,", grid, 2 * act + sp * 128 * 128 * 9 * 4, "conv_wgrad3w_kernel<no norm> same shape, %d splits (algorithmic bytes incl. its split-K slabs)" % sp, required=False)
+entry(fe, wr, "wgrad_reduce_fast_kernel<9", None, None, "wgrad_reduce_fast_kernel<9,3> same shape (the split count of the pass: 80 slabs = 47 MB)", required=False)
 fd, wd = mean_by_kernel("pmc_fetch_dec", "FETCH_SIZE"), mean_by_kernel("pmc_write_dec", "WRITE_SIZE")
 for (Bd, Jd, Pd, nt) in ((32, 14, 64, 256), (64, 21, 64, 256), (128, 42, 128, 512)):
     grid = Bd * Jd * nt
     entry(fd, wd, "decode_fwd_cached", grid, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
     entry(fd, wd, "decode_bwd_cached", grid, 28 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd, "decode_bwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+if MISSING:
+    out["ERRORS"] = MISSING
 json.dump(out, open(os.path.join(dst, PRE + "_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 
@@ -127,3 +145,5 @@ for nm in ("step_bench.json", "trainsteps.json", "iso_bench.jsonl", "iso24_bench
     p = os.path.join(src, nm)
     if os.path.exists(p):
         open(os.path.join(dst, PRE + "_" + nm), "w").write(open(p).read())
+if MISSING:
+    sys.exit("profile_summary: %d traffic rows could not be produced:\n  " % len(MISSING) + "\n  ".join(MISSING))
