@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_finalize_partial_pair; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -216,6 +216,12 @@ int pwr_norm_bwd_apply_from_partial(const void* ga, const void* ya, const float*
  * pwr_norm_bwd_from_partial without its per-sample outputs (same order, same bits); partial_b != NULL: a second job in the same launch. */
 int pwr_norm_bwd_params_from_partial(const float* partial_a, float* dgamma_a, float* dbeta_a, const float* partial_b, float* dgamma_b,
                                      float* dbeta_b, int chunks, int accumulate, int B, int HW, int C, void* stream);
+/* the same for the norms of several layers in ONE launch (a backward segment's worth: the engine issues it once per segment on a side stream) */
+typedef struct { const float* partial; float* dgamma; float* dbeta; int HW, C, chunks; } pwr_norm_param_job;
+int pwr_norm_bwd_params_group(const pwr_norm_param_job* jobs, int njobs, int accumulate, int B, void* stream);
+/* out [B,HW,C] (activation dtype) = relu(norm(y)) as the convs / weight gradients build it on operand load (fmaf(y - mean, scale, beta), ReLU,
+ * one rounding): the engine materialises the heads' operands once for their weight gradients (round 6) */
+int pwr_norm_apply(const void* y, const float* state, void* out, int relu, int B, int HW, int C, int dtype, void* stream);
 /* dy = d/dy relu(norm(y)) applied to g (+ addend); dgamma/dbeta [C] (+)=.  S1,S2: [B,C] scratch. */
 int pwr_norm_bwd(const void* g, const void* y, const float* state, float* partial, float* S1, float* S2, const void* addend, void* dy, float* dgamma,
                  float* dbeta, int accumulate, int relu, int B, int HW, int C, int mode, int dtype, void* stream);
@@ -317,6 +323,10 @@ int pwr_engine_num_launch_ops(void* engine, int which); /* 0 forward, 1 backward
 /* arena, packs, flat params, flat grads, flat BN buffers (device pointers, owned by the caller) */
 int pwr_engine_bind(void* engine, void* arena, void* packs, const float* params, float* grads, float* buffers);
 int pwr_engine_pack(void* engine, void* stream);
+/* the same re-pack as part of the NEXT pwr_engine_forward (round 6): on a side stream beside the stem's first conv -- which reads the fp32
+ * parameters -- and its norm statistics, ordered behind everything already on the forward's stream; the forward waits for it in front of
+ * the first launch that reads a pack */
+int pwr_engine_pack_beside_forward(void* engine);
 /* img [B,1,S,S], label_img / mask [B,1,P,P] fp32.  outs: HOST array of 3*stage device pointers
  * {heatmaps [B,J,P,P], depthmaps [B,J,P,P], uvd [B,J,3]} per stage (fp32), written by the call. */
 int pwr_engine_forward(void* engine, const float* img, const float* label, const float* mask, void* const* outs,

@@ -55,7 +55,11 @@ __device__ __forceinline__ void dec_st(float* q, const f32x4& v) {
 // Register-resident path: N == NT*NV*4, P % 4 == 0 and (NT*4) % P == 0, so a thread's four
 // columns are the same for all of its NV vectors.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int NV, int MINW = 1, bool NTL = false>
+// MPW > 1 (round 6, the 128x128 maps): a workgroup owns MPW consecutive maps of one sample and software-pipelines them -- the logits of
+// map i + 1 are requested before map i's block reductions and its p stores, so the CU (one workgroup of this size fits) has loads in flight
+// during what used to be a load-free third of every map.  Same arithmetic per map.
+// PFD: the next map's depth maps D are requested with its logits (another NV vectors of registers).
+template <int NT, int NV, int MINW = 1, bool NTL = false, int MPW = 1, bool PFD = false>
 __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __restrict__ z, const float* __restrict__ D,
                                                         const float* __restrict__ L, const float* __restrict__ m,
                                                         const float* __restrict__ w, float* __restrict__ p_out,
@@ -66,81 +70,107 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
   //   p = exp(e - m_t) * exp(m_t - M) / S      (one extra rounding vs exp(e - M) / S: ~1e-7 relative)
   constexpr int NW = NT / 64;
   __shared__ float red[8 * NW];
-  const int map = dec_map(blockIdx.x, J, Bx);
-  if (map < 0) return;
-  const int b = map / J, j = map - b * J;
+  const int map0 = dec_map(blockIdx.x, J / MPW, Bx) ;      // (group index: MPW maps per group)
+  if (map0 < 0) return;
   const int N = P * P;
-  const size_t mo = (size_t)map * N, bo = (size_t)b * N;
   const int tid = threadIdx.x;
   const int col0 = (tid * 4) % P;
   const int rows_per_step = (NT * 4) / P;
   const int row0 = (tid * 4) / P;
 
   f32x4 e[NV];
-  float mt = -INFINITY;
-  const float wj = (method == 0) ? w[j] : 1.f;
+  f32x4 dcur[PFD ? NV : 1];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) e[k] = dec_ld<NTL>(z + mo + (size_t)(k * NT + tid) * 4);
-  if (method == 0) {
+  for (int k = 0; k < NV; ++k) e[k] = dec_ld<NTL>(z + (size_t)map0 * MPW * N + (size_t)(k * NT + tid) * 4);
+  if constexpr (PFD) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) dcur[k] = dec_ld<NTL>(D + (size_t)map0 * MPW * N + (size_t)(k * NT + tid) * 4);
+  }
+#pragma unroll 1
+  for (int mi = 0; mi < MPW; ++mi) {
+    const int map = map0 * MPW + mi, b = map / J, j = map - b * J;
+    const size_t mo = (size_t)map * N, bo = (size_t)b * N;
+    float mt = -INFINITY;
+    const float wj = (method == 0) ? w[j] : 1.f;
+    if (method == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        e[k] *= wj;
+        mt = fmaxf(mt, fmaxf(fmaxf(e[k].x, e[k].y), fmaxf(e[k].z, e[k].w)));
+      }
+    }
+
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // per-column sums of e
+    float sv = 0.f, sm = 0.f, sd = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      e[k] *= wj;
-      mt = fmaxf(mt, fmaxf(fmaxf(e[k].x, e[k].y), fmaxf(e[k].z, e[k].w)));
+      const size_t off = (size_t)(k * NT + tid) * 4;
+      f32x4 dv;
+      if constexpr (PFD) dv = dcur[k];
+      else dv = dec_ld<NTL>(D + mo + off);
+      f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
+      f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
+      f32x4 ev;
+      if (method == 0) {
+        ev.x = expf(e[k].x - mt); ev.y = expf(e[k].y - mt); ev.z = expf(e[k].z - mt); ev.w = expf(e[k].w - mt);
+      } else {
+        ev.x = fmaxf(e[k].x, 0.f) + PWR_DEC_EPS; ev.y = fmaxf(e[k].y, 0.f) + PWR_DEC_EPS;
+        ev.z = fmaxf(e[k].z, 0.f) + PWR_DEC_EPS; ev.w = fmaxf(e[k].w, 0.f) + PWR_DEC_EPS;
+      }
+      e[k] = ev;
+      cs[0] += ev.x; cs[1] += ev.y; cs[2] += ev.z; cs[3] += ev.w;
+      const float gy = grid_coord(row0 + k * rows_per_step, P);
+      sv += gy * ((ev.x + ev.y) + (ev.z + ev.w));
+      f32x4 em = ev * mv;              // p*m (unnormalised)
+      f32x4 mr = mv * (dv + lv);       // m*(D+L)
+      sm += (em.x + em.y) + (em.z + em.w);
+      sd += (em.x * mr.x + em.y * mr.y) + (em.z * mr.z + em.w * mr.w);
+      // 128x128 maps (NV = 8): keep at most two iterations' loads in flight per thread, otherwise the scheduler hoists all 24 and
+      // the kernel needs 144 VGPRs = one workgroup per CU; with <= 128 two workgroups overlap their phases
+      if (MINW > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);
     }
-  }
-
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};  // per-column sums of e
-  float sv = 0.f, sm = 0.f, sd = 0.f;
+    // the next map's logits: requested here, consumed at the top of the next trip
+    f32x4 en[MPW > 1 ? NV : 1];
+    if constexpr (MPW > 1) {
+      if (mi + 1 < MPW) {
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const size_t off = (size_t)(k * NT + tid) * 4;
-    f32x4 dv = dec_ld<NTL>(D + mo + off);
-    f32x4 lv = *reinterpret_cast<const f32x4*>(L + bo + off);
-    f32x4 mv = *reinterpret_cast<const f32x4*>(m + bo + off);
-    f32x4 ev;
+        for (int k = 0; k < NV; ++k) en[k] = dec_ld<NTL>(z + mo + (size_t)N + (size_t)(k * NT + tid) * 4);
+        if constexpr (PFD) {       // (dcur is dead here: every vector of it was consumed in the loop above)
+#pragma unroll
+          for (int k = 0; k < NV; ++k) dcur[k] = dec_ld<NTL>(D + mo + (size_t)N + (size_t)(k * NT + tid) * 4);
+        }
+      }
+    }
+    float r[5];
+    r[0] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
+    r[1] = (cs[0] * grid_coord(col0, P) + cs[1] * grid_coord(col0 + 1, P)) +
+           (cs[2] * grid_coord(col0 + 2, P) + cs[3] * grid_coord(col0 + 3, P));
+    r[2] = sv; r[3] = sm; r[4] = sd;
+    float f = 1.f;
     if (method == 0) {
-      ev.x = expf(e[k].x - mt); ev.y = expf(e[k].y - mt); ev.z = expf(e[k].z - mt); ev.w = expf(e[k].w - mt);
-    } else {
-      ev.x = fmaxf(e[k].x, 0.f) + PWR_DEC_EPS; ev.y = fmaxf(e[k].y, 0.f) + PWR_DEC_EPS;
-      ev.z = fmaxf(e[k].z, 0.f) + PWR_DEC_EPS; ev.w = fmaxf(e[k].w, 0.f) + PWR_DEC_EPS;
+      const float M = block_max<NW>(mt, red);
+      f = expf(mt - M);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) r[i] *= f;
     }
-    e[k] = ev;
-    cs[0] += ev.x; cs[1] += ev.y; cs[2] += ev.z; cs[3] += ev.w;
-    const float gy = grid_coord(row0 + k * rows_per_step, P);
-    sv += gy * ((ev.x + ev.y) + (ev.z + ev.w));
-    f32x4 em = ev * mv;              // p*m (unnormalised)
-    f32x4 mr = mv * (dv + lv);       // m*(D+L)
-    sm += (em.x + em.y) + (em.z + em.w);
-    sd += (em.x * mr.x + em.y * mr.y) + (em.z * mr.z + em.w * mr.w);
-    // 128x128 maps (NV = 8): keep at most two iterations' loads in flight per thread, otherwise the scheduler hoists all 24 and
-    // the kernel needs 144 VGPRs = one workgroup per CU; with <= 128 two workgroups overlap their phases
-    if (MINW > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);
-  }
-  float r[5];
-  r[0] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
-  r[1] = (cs[0] * grid_coord(col0, P) + cs[1] * grid_coord(col0 + 1, P)) +
-         (cs[2] * grid_coord(col0 + 2, P) + cs[3] * grid_coord(col0 + 3, P));
-  r[2] = sv; r[3] = sm; r[4] = sd;
-  float f = 1.f;
-  if (method == 0) {
-    const float M = block_max<NW>(mt, red);
-    f = expf(mt - M);
+    block_sum<5, NW>(r, red);
+    const float inv = __fdiv_rn(1.f, r[0]);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) r[i] *= f;
-  }
-  block_sum<5, NW>(r, red);
-  const float inv = __fdiv_rn(1.f, r[0]);
+    for (int k = 0; k < NV; ++k) {
+      f32x4 pv;
+      pv.x = __fdiv_rn(e[k].x * f, r[0]); pv.y = __fdiv_rn(e[k].y * f, r[0]);
+      pv.z = __fdiv_rn(e[k].z * f, r[0]); pv.w = __fdiv_rn(e[k].w * f, r[0]);
+      dec_st<NTL>(p_out + mo + (size_t)(k * NT + tid) * 4, pv);
+    }
+    if (tid == 0) {
+      uvd[(size_t)map * 3 + 0] = r[1] * inv;
+      uvd[(size_t)map * 3 + 1] = r[2] * inv;
+      uvd[(size_t)map * 3 + 2] = __fdiv_rn(r[4] * inv, r[3] * inv + PWR_DEC_EPS);
+    }
+    if constexpr (MPW > 1) {
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    f32x4 pv;
-    pv.x = __fdiv_rn(e[k].x * f, r[0]); pv.y = __fdiv_rn(e[k].y * f, r[0]);
-    pv.z = __fdiv_rn(e[k].z * f, r[0]); pv.w = __fdiv_rn(e[k].w * f, r[0]);
-    dec_st<NTL>(p_out + mo + (size_t)(k * NT + tid) * 4, pv);
-  }
-  if (tid == 0) {
-    uvd[(size_t)map * 3 + 0] = r[1] * inv;
-    uvd[(size_t)map * 3 + 1] = r[2] * inv;
-    uvd[(size_t)map * 3 + 2] = __fdiv_rn(r[4] * inv, r[3] * inv + PWR_DEC_EPS);
+      for (int k = 0; k < NV; ++k) e[k] = en[k];
+    }
   }
 }
 
@@ -376,11 +406,16 @@ __global__ void decode_gw_reduce(const float* __restrict__ gw_part, float* __res
 // ---------------------------------------------------------------------------------------------
 // XCD-aware map order (dec_map) and non-temporal accesses of the once-read tensors: switches of the debug build (tools/bench_decoder.py
 // A/B); the product's values are the measured best (decoder)
-static inline int dec_grid(int B, int J, int* Bx) {
+static inline int dec_grid(int B, int J, int* Bx, int mpw = 1) {
   static const int xcd = PWR_DBG_ENV("PWR_DEC_XCD", 1);
   *Bx = xcd ? B : 0;
-  return xcd ? 8 * ((B + 7) / 8) * J : B * J;
+  return xcd ? 8 * ((B + 7) / 8) * (J / mpw) : B * (J / mpw);
 }
+// Measured (MI355X, tools/bench_decoder.py, three interleaved runs each; profiles/r6_experiments.md): the XCD-aware order takes the forward's
+// fetched bytes at the C5 shape from 853 to 737 MB (721 algorithmic) and the 64x64 backward from 27.9 to 24.9 us (C3 shape); non-temporal
+// accesses of the once-read tensors: forward -4 ... -7 % at every shape, backward -8 % on the 128x128 maps and +6 % on the 64x64 ones
+// (their operands were written by the launches just before and are still cached).  PWR_DEC_NT bits: 1 forward, 2 backward 128x128,
+// 4 backward 64x64.
 extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, const float* m, const float* w,
                               float* p_out, float* uvd_out, int B, int J, int P, int method, void* stream) {
   if (B <= 0 || J <= 0 || P <= 1 || (method == 0 && !w)) return -1;
@@ -388,7 +423,7 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
   const int N = P * P, maps = B * J;
   int Bx = 0;
   const int grid = dec_grid(B, J, &Bx);
-  static const int nt = PWR_DBG_ENV("PWR_DEC_NT", 0);
+  static const int nt = PWR_DBG_ENV("PWR_DEC_NT", 3) & 1;
   if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0) {
     if (nt) hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4, 1, true>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
     else hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
@@ -399,10 +434,27 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
     // 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU: 4.28 TB/s (default); 1 = 1024 threads x 4 vectors: 4.24 TB/s;
     // 2 = 512 x 8 held to 128 VGPRs (two workgroups per CU, a few spilled registers): 3.87 TB/s
     static const int v = PWR_DBG_ENV("PWR_DEC_FWD128", 0);
+    // round 6: MPW maps per workgroup, software-pipelined (PWR_DEC_PIPE, 0 = off) -- where there are enough maps to keep every CU busy
+    // for several rounds anyway
+    static const int pipe = PWR_DBG_ENV("PWR_DEC_PIPE", 1);
+    const int mpw = (pipe && v == 0 && maps >= 8 * 256) ? (J % 3 == 0 ? 3 : (J % 2 == 0 ? 2 : 1)) : 1;
+    const int gp = dec_grid(B, J, &Bx, mpw);
     if (v == 1 && 4096 % P == 0)
       hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(grid), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
     else if (v == 2)
       hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (mpw == 3 && nt && pipe == 2)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 3, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (mpw == 2 && nt && pipe == 2)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 2, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (mpw == 3 && nt)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 3>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (mpw == 3)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, false, 3>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (mpw == 2 && nt)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 2>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    else if (mpw == 2)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, false, 2>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
     else if (nt)
       hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
     else
@@ -422,7 +474,8 @@ extern "C" int pwr_decode_bwd(const float* p, const float* z, const float* D, co
   const int N = P * P, maps = B * J;
   int Bx = 0;
   const int grid = dec_grid(B, J, &Bx);
-  static const int nt = PWR_DBG_ENV("PWR_DEC_NT", 0);
+  static const int ntf = PWR_DBG_ENV("PWR_DEC_NT", 3);
+  const int nt = P >= 128 ? (ntf & 2) : (ntf & 4);      // (see pwr_decode_fwd)
   static const int sc1 = PWR_DBG_ENV("PWR_DEC_SCALAR_SC1", 0);   // experiment switch (tools/race_hunt.py)
   if (sc1 && P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0)
     hipLaunchKernelGGL((pwr::decode_bwd_cached<256, 4, false, true>), dim3(grid), dim3(256), 0, s, p, z, D, L, m, w, uvd, gH, gD_in, gU, gz_out, gD_out, gw_part, J, P, method, Bx);

@@ -61,6 +61,7 @@ struct Ctx {
   int n_fork = 0, fork_rr = 0;
   int n_side = 0, side_rr = 0;
   size_t slab_off = 0, slab_stride = 0;   // byte offset of the current stream's slab inside the slab scratch
+  size_t napply_off = 0, napply_stride = 0;   // the same for the materialised-operand scratch (Engine::scr_napply)
   bool use_side = true;
   bool attached = false;    // side streams / events taken from the process-wide pool
   // Side ops held back while `defer` is set (run_on_side appends them here), issued by the op that clears it: the heads' weight gradients
@@ -165,9 +166,11 @@ static inline int run_on_side(Ctx& c, const std::function<int(Ctx&)>& op, bool f
   void* main_stream = c.stream;
   c.stream = c.side[k];
   c.slab_off = (size_t)k * c.slab_stride;
+  c.napply_off = (size_t)k * c.napply_stride;
   const int rc = op(c);
   c.stream = main_stream;
   c.slab_off = 0;
+  c.napply_off = 0;
   return rc;
 }
 
@@ -265,8 +268,15 @@ struct Engine {
   // Python in between): stage 0's input-conv data gradient writes the norm-backward reductions of the stem's last norm, the stem
   // segment's first op reads them.  It has a buffer of its own so that nothing else can ever touch it in between.
   size_t scr_handoff = 0, need_handoff = 0;
+  // round 6: relu(norm(.)) of a head tensor materialised for its weight gradient (pwr_norm_apply): one buffer per side stream, like the slabs
+  size_t scr_napply = 0, need_napply = 0;
   std::string err;
   long long generation = 0;
+  // round 6: the weight re-pack of a forward runs on a side stream beside the stem's first conv (Cin = 1: VALU, reads the fp32 parameters) and
+  // its norm statistics; the chain waits for it in front of the first op that reads a pack (pwr_engine_pack_beside_forward)
+  bool pack_pending = false;
+  size_t fwd_first_pack_op = ~(size_t)0;
+  hipEvent_t ev_pack = nullptr;
   Ctx ctx;
   bool join_each_segment = PWR_DBG_ENV("PWR_JOIN_EACH", 0) != 0;      // (debug build: PWR_JOIN_EACH=1 makes the caller's stream wait for the side streams after EVERY segment, rounds 2 - 3)
 
@@ -433,6 +443,28 @@ struct Engine {
   // reduction launch leaves the chain: ONE apply launch that sums the slab rows of its sample itself (pwr_norm_bwd_apply_from_partial,
   // bit-identical dy) and the parameter sums on a side stream from the same slab (nothing else ever writes it within a step).
   static constexpr size_t kNoOwn = ~(size_t)0;
+  // dgamma / dbeta of the folded norm backwards of the segment being built: ONE grouped launch on a side stream at the segment's end
+  // (pwr_norm_bwd_params_group; as a launch per layer they were 28 more small kernels per step on the side streams, and the step -- which
+  // ends when the side streams do -- got longer than with the reduction on the chain)
+  struct NormJob { size_t off; bool handoff; long long gamma, beta; int HW, C, chunks; };
+  std::vector<NormJob> seg_norm_jobs;
+  void flush_norm_jobs() {
+    if (seg_norm_jobs.empty()) return;
+    const std::vector<NormJob> jobs = seg_norm_jobs;
+    seg_norm_jobs.clear();
+    const int Bc = B;
+    Engine* E = this;
+    bwd_cur.push_back([=](Ctx& c) {
+      if (elim_mask() & 2) return 0;
+      return run_on_side(c, [=](Ctx& c2) {
+        std::vector<pwr_norm_param_job> arr;
+        for (auto& j : jobs)
+          arr.push_back(pwr_norm_param_job{(const float*)(c2.arena + (j.handoff ? E->scr_handoff + j.off : j.off)), c2.grads + j.gamma, c2.grads + j.beta,
+                                           j.HW, j.C, j.chunks});
+        return pwr_norm_bwd_params_group(arr.data(), (int)arr.size(), 0, Bc, c2.stream);
+      }, false, true);
+    });
+  }
   bool fold_ok(int C) const {
     static const bool on = PWR_DBG_ENV("PWR_NORM_BWD_FOLD", 1) != 0;
     return on && norm_mode == 0 && 2 * C <= 1024;
@@ -445,6 +477,7 @@ struct Engine {
     if ((size_t)B * C * 4 > need_sc) need_sc = (size_t)B * C * 4;
     const bool own = own_off != kNoOwn;
     const bool fold = chunks > 0 && (own || handoff) && fold_ok(C);
+    if (fold) seg_norm_jobs.push_back(NormJob{own ? own_off : cpart_off, !own, n.gamma, n.beta, HW, C, chunks});
     // (Measured and dropped, DESIGN.md section 4: one-block-per-sample, split and deferred-dgamma forms of this step.)
     bwd_cur.push_back([=](Ctx& c) {
       if (elim_mask() & 2) return 0;
@@ -455,11 +488,7 @@ struct Engine {
           int rc = pwr_norm_bwd_apply_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), part,
                                                    has_addend ? c.arena + addend_goff : nullptr, c.arena + t.goff, nullptr, nullptr, nullptr, nullptr,
                                                    nullptr, chunks, 1, Bc, HW, C, dt, c.stream);
-          if (rc) return rc;
-          return run_on_side(c, [=](Ctx& c2) {
-            float* part2 = own ? (float*)(c2.arena + own_off) : (float*)(c2.arena + E->*cpart + cpart_off);
-            return pwr_norm_bwd_params_from_partial(part2, c2.grads + n.gamma, c2.grads + n.beta, nullptr, nullptr, nullptr, chunks, 0, Bc, HW, C, c2.stream);
-          }, false, true);
+          return rc;     // (dgamma / dbeta: the segment's grouped launch, flush_norm_jobs)
         }
         return pwr_norm_bwd_from_partial(c.arena + t.goff, c.arena + t.off, (float*)(c.arena + n.state), part,
                                          chunks, (float*)(c.arena + E->scr_S1), (float*)(c.arena + E->scr_S2),
@@ -488,6 +517,10 @@ struct Engine {
     if ((size_t)2 * B * C * 4 > need_sc) need_sc = (size_t)2 * B * C * 4;
     const bool own = own_off != kNoOwn;
     const bool fold = own && fold_ok(C);
+    if (fold) {
+      seg_norm_jobs.push_back(NormJob{own_off, false, na.gamma, na.beta, HW, C, chunks});
+      seg_norm_jobs.push_back(NormJob{own_off + off_b, false, nb.gamma, nb.beta, HW, C, chunks});
+    }
     bwd_cur.push_back([=](Ctx& c) {
       if (elim_mask() & 2) return 0;
       float* pa = own ? (float*)(c.arena + own_off) : (float*)(c.arena + E->scr_cpartial);
@@ -496,12 +529,7 @@ struct Engine {
         int rc = pwr_norm_bwd_apply_from_partial(c.arena + ta.goff, c.arena + ta.off, (float*)(c.arena + na.state), pa, nullptr, c.arena + ta.goff,
                                                  c.arena + tb.goff, c.arena + tb.off, (float*)(c.arena + nb.state), pb, c.arena + tb.goff, chunks, 1, Bc,
                                                  HW, C, dt, c.stream);
-        if (rc) return rc;
-        return run_on_side(c, [=](Ctx& c2) {
-          return pwr_norm_bwd_params_from_partial((float*)(c2.arena + own_off), c2.grads + na.gamma, c2.grads + na.beta,
-                                                  (float*)(c2.arena + own_off + off_b), c2.grads + nb.gamma, c2.grads + nb.beta, chunks, 0, Bc, HW, C,
-                                                  c2.stream);
-        }, false, true);
+        return rc;     // (dgamma / dbeta: the segment's grouped launch, flush_norm_jobs)
       }
       return pwr_norm_bwd_from_partial_pair(c.arena + ta.goff, c.arena + ta.off, (float*)(c.arena + na.state), pa,
                                             c.arena + ta.goff, c.grads + na.gamma, c.grads + na.beta, c.arena + tb.goff, c.arena + tb.off,
@@ -998,6 +1026,8 @@ struct Engine {
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits3));
     want_slab((size_t)B * J * 4);
     const bool wpair = PWR_DBG_ENV("PWR_HEAD_WGRAD_PAIR", 0) != 0;      // weight gradients of the two heads in one launch (measured: no gain)
+    const bool napply = PWR_DBG_ENV("PWR_HEAD_NAPPLY", 1) != 0;         // round 6: the norm-fed layers' operand materialised once (see below)
+    if (napply && (size_t)B * P * P * F * esz > need_napply) need_napply = (size_t)B * P * P * F * esz;
     const int splits_pair = wpair ? std::max(1, splits_for(M, F, F, ks) / 2) : splits_for(M, F, F, ks);
     want_slab(2 * pwr_conv_wgrad_slab_bytes(F, F, ks, splits_pair));
     Engine* E = this;
@@ -1061,6 +1091,17 @@ struct Engine {
                                                 c2.arena + L.xd.off, c2.arena + L.yd.goff, (float*)(c2.arena + L.nd.state), c2.grads + L.cd.w, 1, slab, Bc, Pc, Pc,
                                                 Fc, Fc, splits_pair, dt, c2.stream);
           if (r2 != PWR_EUNSUPPORTED) return r2;
+          if (napply) {
+            // the operand relu(norm(x)) written out ONCE on this stream (67 MB of traffic), then the weight gradient's plain form: the same
+            // LDS tiles, the same slabs, the same dW -- without the in-LDS norm arithmetic of the loader waves (three kernel rows x 24
+            // splits did it over and over: 124.5 us per layer in the step against 84.9 us for the plain form)
+            char* na = c2.arena + E->scr_napply + c2.napply_off;
+            r2 = pwr_norm_apply(c2.arena + L.xp.off, (float*)(c2.arena + L.np.state), na, 1, Bc, Pc * Pc, Fc, dt, c2.stream);
+            if (!r2) r2 = pwr_conv_wgrad(na, c2.arena + L.yp.goff, nullptr, 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
+            if (!r2) r2 = pwr_norm_apply(c2.arena + L.xd.off, (float*)(c2.arena + L.nd.state), na, 1, Bc, Pc * Pc, Fc, dt, c2.stream);
+            if (!r2) r2 = pwr_conv_wgrad(na, c2.arena + L.yd.goff, nullptr, 1, slab, c2.grads + L.cd.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
+            return r2;
+          }
           r2 = pwr_conv_wgrad(c2.arena + L.xp.off, c2.arena + L.yp.goff, (float*)(c2.arena + L.np.state), 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
                               Fc, kk, 1, splits_pair, dt, c2.stream);
           if (r2) return r2;
@@ -1146,6 +1187,7 @@ struct Engine {
       Tn y0 = tensor(S, S, 32, tr);
       fwd.push_back([=](Ctx& c) { return pwr_stem_conv_fwd(c.img, c.params + c0.w, c.params + c0.b, c.arena + y0.off, Bc, S, 32, E->ks, dt, c.stream); });
       norm_fwd(y0, n0);
+      fwd_first_pack_op = fwd.size();            // everything from here on may read a weight pack
       sc.push_back(c0); sn.push_back(n0); sy.push_back(y0);
       int cch = 32;
       while (cch < F) {
@@ -1256,6 +1298,7 @@ struct Engine {
             return pwr_nhwc_to_cat_grad(c.arena + xcc.goff, (float*)(c.arena + Rp.gH), (float*)(c.arena + Rp.gD), Bc, Jc, N, Cp, dt, c.stream);
           });
         }
+        flush_norm_jobs();
         std::swap(stage_bwd[s], bwd_cur);
       }
     }
@@ -1279,6 +1322,7 @@ struct Engine {
           return pwr_stem_conv_wgrad(c2.img, c2.arena + y0.goff, (float*)(c2.arena + E->scr_slab + c2.slab_off), c2.grads + c0.w, 0, Bc, S, 32, E->ks, dt, c2.stream);
         });
       });
+      flush_norm_jobs();
       std::swap(stem_bwd, bwd_cur);
     }
     if (pcur != poff.size()) { err = "parameter table longer than the network"; return false; }
@@ -1290,6 +1334,9 @@ struct Engine {
     scr_S1 = alloc(need_sc, "S1"); scr_S2 = alloc(need_sc, "S2");
     scr_cpartial = alloc(need_cpartial, "cpartial");
     scr_handoff = alloc(need_handoff, "stem_handoff");
+    need_napply = (need_napply + 255) / 256 * 256;
+    scr_napply = alloc(need_napply * Ctx::kMaxSide, "napply");
+    ctx.napply_stride = need_napply;
     scr_slab_bytes = (scr_slab_bytes + 255) / 256 * 256;
     scr_slab = alloc(scr_slab_bytes * Ctx::kMaxSide, "slab");
     ctx.slab_stride = scr_slab_bytes;
@@ -1330,6 +1377,7 @@ extern "C" void* pwr_engine_create(const int* cfg, int B, int dtype, int trainin
 
 extern "C" void pwr_engine_destroy(void* h) {
   Engine* e = (Engine*)h;
+  if (e->ev_pack) hipEventDestroy(e->ev_pack);
   for (int k = 0; k < e->ctx.n_side; ++k) hipStreamSynchronize(e->ctx.side[k]);    // (shared streams: drained, not destroyed)
   delete e;
 }
@@ -1402,6 +1450,13 @@ extern "C" int pwr_engine_pack(void* h, void* stream) {
   Engine* e = (Engine*)h;
   return pwr_pack_weights(e->ctx.params, e->ctx.packs, e->ctx.packs + e->desc_dev_off, (int)e->descs.size(), stream);
 }
+// The same re-pack as PART OF the next pwr_engine_forward: issued on a side stream behind everything already on the forward's stream, beside
+// the stem's first conv (which reads the fp32 parameters) and its norm statistics; the forward waits for it in front of the first launch
+// that reads a pack.  ~28 us less on the critical path of every forward (the pack of all 88 layers is one launch of that length).
+extern "C" int pwr_engine_pack_beside_forward(void* h) {
+  ((Engine*)h)->pack_pending = true;
+  return 0;
+}
 
 // outs: host array of 3*stage device pointers {heatmaps_s, depthmaps_s, uvd_s}
 extern "C" int pwr_engine_forward(void* h, const float* img, const float* label, const float* mask, void* const* outs, int training,
@@ -1415,9 +1470,33 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
   e->generation++;
   auto run = [&](void* st) -> int {
     c.stream = st;
+    bool pack_wait = false;
+    if (e->pack_pending) {
+      e->pack_pending = false;
+      if (!c.attached) side_pool_attach(c, (hipStream_t)st);
+      static const bool beside = PWR_DBG_ENV("PWR_PACK_BESIDE", 1) != 0;
+      if (beside && c.use_side && c.n_side > 0 && c.n_fork > 0 && e->fwd_first_pack_op < e->fwd.size()) {
+        if (!e->ev_pack && hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming) != hipSuccess) e->ev_pack = nullptr;
+      }
+      if (beside && e->ev_pack && c.use_side && c.n_side > 0 && c.n_fork > 0 && e->fwd_first_pack_op < e->fwd.size()) {
+        // the pack must follow everything already on the caller's stream (the optimizer update, the previous step's readers of the packs)
+        hipEvent_t ev = c.ev_fork[c.fork_rr];
+        c.fork_rr = (c.fork_rr + 1) % c.n_fork;
+        hipEventRecord(ev, (hipStream_t)st);
+        hipStreamWaitEvent(c.side[0], ev, 0);
+        int rc = pwr_pack_weights(c.params, c.packs, c.packs + e->desc_dev_off, (int)e->descs.size(), c.side[0]);
+        if (rc) return rc;
+        hipEventRecord(e->ev_pack, c.side[0]);
+        pack_wait = true;
+      } else {
+        int rc = pwr_pack_weights(c.params, c.packs, c.packs + e->desc_dev_off, (int)e->descs.size(), st);
+        if (rc) return rc;
+      }
+    }
     // hand-off counters of the fused norm kernels live at the head of the partial scratch: zero once per call
     if (e->need_partial) hipMemsetAsync(c.arena + e->scr_partial, 0, 8192 < e->need_partial ? 8192 : e->need_partial, (hipStream_t)st);
     for (size_t i = 0; i < e->fwd.size(); ++i) {
+      if (pack_wait && i == e->fwd_first_pack_op) { hipStreamWaitEvent((hipStream_t)st, e->ev_pack, 0); pack_wait = false; }
 #ifdef PWR_DEBUG_BUILD
       if (e->timing && (i == 0 || e->fwd[i].tag != e->fwd[i - 1].tag)) e->mark("forward", e->fwd[i].tag, st);
 #endif

@@ -516,6 +516,60 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_fold_kernel(NormBwdFoldPai
                               blockIdx.x, blockIdx.y);
 }
 
+// The parameter sums of SEVERAL norm backwards in one launch (round 6): as a launch of its own per layer -- 16 blocks, ~8 us -- the folded
+// form's parameter sums added 28 small kernels per step to the side streams and the step got LONGER than with the reduction on the chain
+// (5.08 against 5.02 ms: the step ends when the side streams do).  Block x looks its job up in a prefix table and runs norm_bwd_sum_body
+// without the per-sample outputs: the same order, the same bits as pwr_norm_bwd_from_partial's dgamma / dbeta.
+struct NormParamGroup {
+  static constexpr int kMax = 40;
+  const float* partial[kMax]; float* dgamma[kMax]; float* dbeta[kMax];
+  int HW[kMax], C[kMax], chunks[kMax], first[kMax + 1];
+  int n, B, accumulate;
+};
+__global__ __launch_bounds__(256) void norm_bwd_params_group_kernel(NormParamGroup g) {
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.first[j + 1]) ++j;
+  norm_bwd_sum_body(g.partial[j], nullptr, nullptr, g.dgamma[j], g.dbeta[j], g.B, g.HW[j], g.C[j], g.chunks[j], 0, g.accumulate, blockIdx.x - g.first[j]);
+}
+
+// out = bf16 / fp32 of relu(norm(y)) as the convs and weight gradients compute it on operand load -- fmaf(y - mean, scale, beta), ReLU,
+// ONE rounding -- written out as a tensor (round 6).  The wave-specialised weight gradient of the heads' norm-fed layers spends a third of
+// its loader's issue slots on exactly this arithmetic, three times over (once per kernel row) and once per split: 124.5 us in the step
+// against 84.9 us for the same layer without a norm.  Materialising the operand once on the weight gradient's own (side) stream -- 67 MB
+// of traffic, ~15 us -- and running the plain form is the same LDS tile, the same slabs, the same dW bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ y, const float* __restrict__ state, T* __restrict__ out, int B,
+                                                         int HW, int C, int nchunks, int relu) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  if (pj >= pl) return;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const size_t base = (size_t)b * HW * C, plane = (size_t)B * C;
+  float mu[EP], sc[EP], be[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    const int c = b * C + cq * EP + e;
+    mu[e] = state[c]; sc[e] = state[2 * plane + c]; be[e] = state[3 * plane + c];
+  }
+#pragma unroll 4
+  for (int pp = p0 + pj; pp < p1; pp += pl) {
+    const size_t off = base + (size_t)pp * C + cq * EP;
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(y + off));
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      float f = fmaf(Elem<T>::to_f(v[e]) - mu[e], sc[e], be[e]);
+      if (relu) f = fmaxf(f, 0.f);
+      o[e] = Elem<T>::from_f(f);
+    }
+    *reinterpret_cast<V*>(out + off) = o;
+  }
+}
+
 static inline int norm_chunks(int B, int HW) {
   int n = (1024 + B - 1) / B;
   int maxc = (HW + 31) / 32;
@@ -849,5 +903,38 @@ extern "C" int pwr_norm_bwd_params_from_partial(const float* partial_a, float* d
     q.j[1] = NormBwdJob{nullptr, nullptr, nullptr, partial_b, nullptr, nullptr, nullptr, dgamma_b, dbeta_b};
     hipLaunchKernelGGL(norm_bwd_sum_pair_kernel, dim3((C + 7) / 8, 2), dim3(256), 0, s, q, B, HW, C, chunks, accumulate);
   }
+  return (int)hipGetLastError();
+}
+
+// The parameter gradients of `njobs` norm backwards (instance norm; each job = the slab of its data-gradient conv, pwr_conv_fwd_stats'
+// nb_partial) in as few launches as a kernel-argument table allows (40 jobs each): bit-identical to pwr_norm_bwd_params_from_partial per job.
+extern "C" int pwr_norm_bwd_params_group(const pwr_norm_param_job* jobs, int njobs, int accumulate, int B, void* stream) {
+  if (njobs < 0 || (njobs && !jobs)) return PWR_EINVAL;
+  for (int j0 = 0; j0 < njobs; j0 += pwr::NormParamGroup::kMax) {
+    pwr::NormParamGroup g;
+    g.n = njobs - j0 < pwr::NormParamGroup::kMax ? njobs - j0 : pwr::NormParamGroup::kMax;
+    g.B = B; g.accumulate = accumulate;
+    int blocks = 0;
+    for (int j = 0; j < g.n; ++j) {
+      const pwr_norm_param_job& q = jobs[j0 + j];
+      if (!q.partial || !q.dgamma || !q.dbeta || q.chunks < 1 || q.C < 1) return PWR_EINVAL;
+      g.partial[j] = q.partial; g.dgamma[j] = q.dgamma; g.dbeta[j] = q.dbeta; g.HW[j] = q.HW; g.C[j] = q.C; g.chunks[j] = q.chunks;
+      g.first[j] = blocks;
+      blocks += (q.C + 7) / 8;
+    }
+    g.first[g.n] = blocks;
+    hipLaunchKernelGGL(pwr::norm_bwd_params_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  }
+  return (int)hipGetLastError();
+}
+
+// out [B,HW,C] = relu(norm(y)) (relu optional) in the activation dtype, from the [4][B][C] state: the operand the convs / weight gradients
+// build on load, as a tensor (see norm_apply_kernel).
+extern "C" int pwr_norm_apply(const void* y, const float* state, void* out, int relu, int B, int HW, int C, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4;
+  if (C % EP || C / EP > 256 || !y || !state || !out) return PWR_EUNSUPPORTED;
+  const int nch = norm_chunks(B, HW);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_apply_kernel<bf16_t>), dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, state, (bf16_t*)out, B, HW, C, nch, relu);
+  else hipLaunchKernelGGL((norm_apply_kernel<float>), dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const float*)y, state, (float*)out, B, HW, C, nch, relu);
   return (int)hipGetLastError();
 }

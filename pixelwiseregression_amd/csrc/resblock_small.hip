@@ -65,7 +65,11 @@ struct RbGeom {
   static constexpr int R_BYTES = rb_max(ROWS * P128, R_PATCH + T64);  // 128-channel tile overlays both
   static constexpr int W_BYTES = rb_max(18 * 64 * 64, ROWS * P128);   // all 18 tiles of the 3x3 | raw 128-channel output
   static constexpr int RED_BYTES = 4 * 128 * 2 * 4;
-  static constexpr int TOTAL = R_BYTES + W_BYTES + RED_BYTES;
+  // forward: gamma / beta of the three norms (rb_params_to_lds, 2 KiB); backward: the sample's norm states (rb_states_store: 4 KiB, or 2 KiB
+  // without norm a's on the 16x16 maps, whose other regions leave 2496 bytes)
+  static constexpr int PRM_BYTES = LOGW == 4 ? 2048 : 4096;
+  static constexpr int TOTAL = R_BYTES + W_BYTES + RED_BYTES + PRM_BYTES;
+  static_assert(TOTAL <= 160 * 1024, "one workgroup's LDS");
 };
 
 // The workgroup has NW waves: 8 for the 16x16 and 8x8 maps, 4 below (round 2: with 4 waves = one per SIMD nothing hid the LDS /

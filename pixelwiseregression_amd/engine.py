@@ -113,7 +113,8 @@ def _run_forward(model, plan, img, label_img, mask):
     # Re-pack the conv weights from the flat fp32 parameters on every forward (one launch, ~10 us): in-place updates
     # through the per-parameter views (optimizers, load_state_dict) do not bump the flat buffer's version counter,
     # so there is no cheap, reliable "unchanged" test -- and a stale pack would be silently wrong.
-    _lib.check(l.pwr_engine_pack(plan.h, stream), "pwr_engine_pack")
+    # (round 6: the pack is issued INSIDE the forward call, on a side stream beside the stem's first conv)
+    _lib.check(l.pwr_engine_pack_beside_forward(plan.h), "pwr_engine_pack_beside_forward")
     outs = []
     for _ in range(model.stage):
         outs += [torch.empty(B, J, P, P, device=dev, dtype=torch.float32), torch.empty(B, J, P, P, device=dev, dtype=torch.float32),

@@ -520,3 +520,30 @@ def norm_finalize_partial_pair(partial_a, gamma_a, beta_a, partial_b, gamma_b, b
     _lib.check(l.pwr_norm_finalize_partial_pair(_p(partial_a), _p(gamma_a), _p(beta_a), _p(sa), _p(partial_b), _p(gamma_b), _p(beta_b), _p(sb), chunks, B, HW,
                                                 C, eps, _s(partial_a)), "pwr_norm_finalize_partial_pair")
     return sa, sb
+
+
+def norm_bwd_params_group(jobs, B):
+    """jobs: list of (partial, chunks, HW, C): the parameter gradients of several norm backwards in one launch (pwr_norm_bwd_params_group).
+    Returns [(dgamma, dbeta), ...]."""
+    import ctypes
+    l = _lib.lib()
+
+    class Job(ctypes.Structure):
+        _fields_ = [("partial", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("HW", ctypes.c_int), ("C", ctypes.c_int),
+                    ("chunks", ctypes.c_int)]
+    outs, arr = [], (Job * len(jobs))()
+    for i, (partial, chunks, HW, C) in enumerate(jobs):
+        dg, db = (torch.empty(C, dtype=torch.float32, device=partial.device) for _ in range(2))
+        outs.append((dg, db))
+        arr[i] = Job(partial.data_ptr(), dg.data_ptr(), db.data_ptr(), HW, C, chunks)
+    _lib.check(l.pwr_norm_bwd_params_group(ctypes.cast(arr, ctypes.c_void_p), len(jobs), 0, B, _s(jobs[0][0])), "pwr_norm_bwd_params_group")
+    return outs
+
+
+def norm_apply(y, state, relu=True):
+    """relu(norm(y)) as a tensor of y's dtype (pwr_norm_apply): the operand the convs / weight gradients build on load"""
+    l = _lib.lib()
+    B, H, W, C = y.shape
+    out = torch.empty_like(y)
+    _lib.check(l.pwr_norm_apply(_p(y), _p(state), _p(out), int(relu), B, H * W, C, _dt(y), _s(y)), "pwr_norm_apply")
+    return out

@@ -100,3 +100,38 @@ def test_decoder_autograd_matches_torch_ops():
     assert (uvd - uvd2).abs().max().item() < 1e-5
     for a, b_ in ((gz, gz2), (gD, gD2), (gw, gw2)):
         assert (a.double() - b_).abs().max().item() <= 1e-5 * max(1.0, b_.abs().max().item())
+
+
+@pytest.mark.parametrize("B,J", [(49, 42), (98, 21), (57, 37)])
+def test_decoder_128x128_many_maps_equal_the_same_maps_in_small_launches(B, J):
+    """Round 6: with >= 2048 maps of 128x128 a forward workgroup owns several consecutive maps of one sample and software-pipelines them
+    (the next map's operands are requested before this map's reductions and stores), and the workgroups are dealt to the XCDs sample by
+    sample.  Every map must come out as the SAME BYTES as in a small launch of its own sample (one map per workgroup, no pipeline) -- J = 42
+    takes the three-map form, J = 21 too, J = 37 (prime) the one-map form at the XCD-aware order with a padded grid (B = 57: 8 x 8 x J
+    blocks) -- forward and backward; and a sample's maps against the numpy oracle."""
+    from pixelwiseregression_amd import ops
+    P = 128
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + J)
+    dev = _dev()
+    z = (torch.randn(B, J, P, P, generator=g) * 2).to(dev)
+    D = torch.randn(B, J, P, P, generator=g).to(dev)
+    m = (torch.rand(B, 1, P, P, generator=g) < 0.4).float().to(dev)
+    L = (torch.randn(B, 1, P, P, generator=g)).to(dev) * m
+    w = (1 + 0.1 * torch.randn(J, 1, generator=g)).to(dev)
+    gH, gD = torch.randn(B, J, P, P, generator=g).to(dev), torch.randn(B, J, P, P, generator=g).to(dev)
+    gU = torch.randn(B, J, 3, generator=g).to(dev)
+    p, uvd = ops.decode_forward(z, D, L, m, w, "softmax")
+    gz, gDo, gw = ops.decode_backward(p, z, D, L, m, w, uvd, gH, gD, gU, "softmax")
+    for b in (0, 7, 8, B - 1):
+        sl = slice(b, b + 1)
+        p1, u1 = ops.decode_forward(z[sl].contiguous(), D[sl].contiguous(), L[sl].contiguous(), m[sl].contiguous(), w, "softmax")
+        assert torch.equal(p1, p[sl]) and torch.equal(u1, uvd[sl]), b
+        gz1, gD1, _ = ops.decode_backward(p1, z[sl].contiguous(), D[sl].contiguous(), L[sl].contiguous(), m[sl].contiguous(), w, u1,
+                                          gH[sl].contiguous(), gD[sl].contiguous(), gU[sl].contiguous(), "softmax")
+        assert torch.equal(gz1, gz[sl]) and torch.equal(gD1, gDo[sl]), b
+    b = B - 1
+    pr, ur = decoder_ref.decode_forward(z[b:b + 1].cpu().numpy(), D[b:b + 1].cpu().numpy(), L[b:b + 1].cpu().numpy(), m[b:b + 1].cpu().numpy(),
+                                        w.cpu().numpy(), "softmax", dtype=np.float64)
+    np.testing.assert_allclose(p[b:b + 1].cpu().numpy(), pr, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(uvd[b:b + 1].cpu().numpy(), ur, rtol=0, atol=1e-5)
+    assert float(gw.abs().max()) > 0

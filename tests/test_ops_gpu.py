@@ -899,6 +899,10 @@ def test_norm_backward_pair_launch(B, H, W, C):
     for one, two, three in zip(singles, fold_pair, fold_single):
         for a, b_, c_ in zip(one, two, three):
             assert float(a.float().abs().max()) > 0 and torch.equal(a, b_) and torch.equal(a, c_)
+    # ... and the parameter sums of several layers in one launch (what the engine issues once per backward segment)
+    grouped = K.norm_bwd_params_group([(pt, c_, H * W, C) for (_, _, _, pt, c_) in jobs] * 21, B)      # (42 jobs: two launches of <= 40)
+    for k_, (dg, db) in enumerate(grouped):
+        assert torch.equal(dg, singles[k_ % 2][1]) and torch.equal(db, singles[k_ % 2][2])
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 8, 64), (2, 64, 64)])
@@ -1089,3 +1093,25 @@ def test_wgrad_pair_launch(case, prologue):
     db = K.conv_wgrad(xb, dyb, Cout, 3, 1, norm=stb, splits=splits)
     pa, pb = K.conv_wgrad_pair(xa, dya, xb, dyb, norm_a=sta, norm_b=stb, splits=splits)
     assert float(da.abs().max()) > 0 and torch.equal(da, pa) and torch.equal(db, pb)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 128), (3, 8, 32, 64), (1, 5, 7, 32)])
+def test_norm_apply_and_the_weight_gradient_from_the_materialised_operand(dtype, B, H, W, C):
+    """pwr_norm_apply (round 6): relu(norm(y)) written out as a tensor equals fmaf(y - mean, scale, beta), ReLU, one rounding, in float64
+    arithmetic up to that rounding; and the weight gradient fed the materialised operand without a norm is BIT-IDENTICAL to the weight
+    gradient that applies the norm on load (what the engine relies on for the heads' norm-fed layers)."""
+    from pixelwiseregression_amd import kernels as K
+    y = rnd(B, C, H, W, seed=21)
+    yq, st = q(y, dtype), None
+    ref, st = apply_nr(yq, B, C, dtype)
+    got = K.norm_apply(nhwc(y, dtype), st)
+    if dtype == torch.float32:
+        assert_close(nchw(got), ref, 2e-6, "norm_apply")
+    else:
+        assert_close_out(nchw(got), ref, dtype, True, "norm_apply")
+    if W % 32 == 0 and C == 128:
+        dy = nhwc(rnd(B, C, H, W, seed=22), dtype)
+        a = K.conv_wgrad(nhwc(y, dtype), dy, C, 3, 1, norm=st, splits=8)
+        b_ = K.conv_wgrad(got, dy, C, 3, 1, norm=None, splits=8)
+        assert float(a.abs().max()) > 0 and torch.equal(a, b_)
