@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply, pwr_norm_stats_fused_src; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -187,6 +187,12 @@ size_t pwr_norm_partial_bytes(int B, int HW, int C);
 int pwr_norm_stats(const void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
                    float* partial, float* state, int B, int HW, int C, int mode, float eps, float momentum, int dtype,
                    void* stream);
+/* Round 6: the tensor's PRODUCER fused into the statistics launch (InstanceNorm): src 1: y = maxpool2x2(xa [B,2H,2W,C]) (model.py:40);
+ * src 2: y = xa [B,H,W,C] + nearest-upsample(xh [B,H/2,W/2,C]) (model.py:45-47).  y is written; y and `state` are bit-identical to
+ * pwr_maxpool_fwd / pwr_upsample_add_fwd followed by pwr_norm_stats(mode 0).  PWR_EUNSUPPORTED for H W <= 512 (pwr_norm_stats' one-block
+ * form): issue the separate launches then.  partial: pwr_norm_partial_bytes(B, H W, C). */
+int pwr_norm_stats_fused_src(int src, const void* xa, const void* xh, void* y, const float* gamma, const float* beta, float* partial, float* state,
+                             int B, int H, int W, int C, float eps, int dtype, void* stream);
 /* state from the per-tile sums of pwr_conv_fwd_stats (st_partial); mode 0 / 1. */
 int pwr_norm_finalize_partial(const float* partial, int chunks, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float* state, int B, int HW, int C, int mode, float eps,

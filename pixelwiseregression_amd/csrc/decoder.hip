@@ -436,6 +436,7 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
     static const int v = PWR_DBG_ENV("PWR_DEC_FWD128", 0);
     // round 6: MPW maps per workgroup, software-pipelined (PWR_DEC_PIPE, 0 = off) -- where there are enough maps to keep every CU busy
     // for several rounds anyway
+    // (pipe = 2: the next map's depth maps prefetched too, 223 registers: no faster than 1 -- 233.4 against 235.5 us, within the noise)
     static const int pipe = PWR_DBG_ENV("PWR_DEC_PIPE", 1);
     const int mpw = (pipe && v == 0 && maps >= 8 * 256) ? (J % 3 == 0 ? 3 : (J % 2 == 0 ? 2 : 1)) : 1;
     const int gp = dec_grid(B, J, &Bx, mpw);

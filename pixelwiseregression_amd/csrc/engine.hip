@@ -437,6 +437,27 @@ struct Engine {
                             c.stream);
     });
   }
+  // round 6: the statistics launch of a ResBlock's first norm with the tensor's producer fused in (hourglass(): the level's max-pool, the
+  // inner level's up-sample + skip, left pending in lazy_x for an UNFUSED ResBlock): two launches instead of three, same bytes
+  static bool src_fuse_on() {
+    static const bool on = PWR_DBG_ENV("PWR_NORM_SRC_FUSE", 1) != 0;
+    return on;
+  }
+  void norm_fwd_src(const Tn& t, const NormL& n, const LazyX& lx) {
+    const int C = t.C, Bc = B, dt = dtype, Hc = t.H, Wc = t.W;
+    norm_fwd_sizes(t);
+    Engine* E = this;
+    fwd.push_back([=](Ctx& c) {
+      int rc = pwr_norm_stats_fused_src(lx.mode, c.arena + lx.a_off, lx.mode == 2 ? c.arena + lx.h_off : nullptr, c.arena + t.off, c.params + n.gamma,
+                                        c.params + n.beta, (float*)(c.arena + E->scr_partial), (float*)(c.arena + n.state), Bc, Hc, Wc, C, 1e-5f, dt, c.stream);
+      if (rc != PWR_EUNSUPPORTED) return rc;
+      rc = lx.mode == 1 ? pwr_maxpool_fwd(c.arena + lx.a_off, c.arena + t.off, Bc, 2 * Hc, 2 * Wc, C, dt, c.stream)
+                        : pwr_upsample_add_fwd(c.arena + lx.h_off, c.arena + lx.a_off, c.arena + t.off, Bc, Hc / 2, Wc / 2, Hc, Wc, C, dt, c.stream);
+      if (rc) return rc;
+      return pwr_norm_stats(c.arena + t.off, c.params + n.gamma, c.params + n.beta, nullptr, nullptr, (float*)(c.arena + E->scr_partial),
+                            (float*)(c.arena + n.state), Bc, Hc * Wc, C, 0, 1e-5f, 0.1f, dt, c.stream);
+    });
+  }
   // grad buffer of t holds g = dL/d relu(norm(t)); result dy replaces it (plus addend tensor's grad if addend_goff != 0)
   // chunks > 0: the data-gradient conv that produced g already wrote the two reductions (conv_bwd's return value)
   // Round 6 (fold): with instance norm and a slab of its OWN (own_off: conv_bwd allocated it for this layer; or the hand-off buffer), the
@@ -738,8 +759,13 @@ struct Engine {
     r.nc = norm_params(Fh);
     r.cc = conv_params(Fh, x.C, 1, 1, true, true);
     if (pwr_resblock_small_supported(x.H, x.W, x.C, norm_mode, dtype)) return resblock_fused(x, r);
-    if (lazy_x.valid) err = "internal: a fused producer is pending in front of an unfused ResBlock (its input would never be written)";
-    norm_fwd(x, r.na);
+    if (lazy_x.valid && lazy_x.x_off == x.off && norm_mode == 0 && src_fuse_on()) {
+      norm_fwd_src(x, r.na, lazy_x);
+      lazy_x.valid = false;
+    } else {
+      if (lazy_x.valid) err = "internal: a fused producer is pending in front of an unfused ResBlock (its input would never be written)";
+      norm_fwd(x, r.na);
+    }
     r.t1 = conv_fwd(x, &r.na, r.ca, nullptr, tr, &r.nb);
     r.t2 = conv_fwd(r.t1, &r.nb, r.cb, nullptr, tr, &r.nc);
     Tn out = conv_fwd(r.t2, &r.nc, r.cc, &x, tr);
@@ -849,6 +875,10 @@ struct Engine {
     if (fuse_in && pwr_resblock_small_supported(h0.H, h0.W, h0.C, norm_mode, dtype)) {
       if (lazy_x.valid) { err = "unconsumed fused producer"; }
       lazy_x = LazyX{true, 1, h0.off, a.off, 0};
+    } else if (norm_mode == 0 && src_fuse_on() && a.H == 2 * h0.H && a.W == 2 * h0.W) {
+      // (round 6) ... and when it is an unfused ResBlock (the 32x32 level), its first norm's statistics launch pools on the fly (norm_fwd_src)
+      if (lazy_x.valid) { err = "unconsumed fused producer"; }
+      lazy_x = LazyX{true, 1, h0.off, a.off, 0};
     } else {
       fwd.push_back([=](Ctx& c) { return pwr_maxpool_fwd(c.arena + a.off, c.arena + h0.off, Bc, a.H, a.W, a.C, dt, c.stream); });
     }
@@ -884,6 +914,10 @@ struct Engine {
     // `out` of an inner level is consumed by the outer level's output ResBlock only: the same fusion (not for the outermost level --
     // hg_depth == 1 here -- whose result goes to the heads, nor for the big maps)
     if (fuse_in && hg_depth > 1 && a.H >= 4 && pwr_resblock_small_supported(a.H, a.W, a.C, norm_mode, dtype)) {
+      if (lazy_x.valid) { err = "unconsumed fused producer"; }
+      lazy_x = LazyX{true, 2, out.off, a.off, h2.off};
+    } else if (hg_depth > 1 && norm_mode == 0 && src_fuse_on() && a.H == 2 * h2.H && a.W == 2 * h2.W) {
+      // (round 6) the outer level's output ResBlock is an unfused one (the 32x32 map): norm_fwd_src adds the up-sampled map while it sums
       if (lazy_x.valid) { err = "unconsumed fused producer"; }
       lazy_x = LazyX{true, 2, out.off, a.off, h2.off};
     } else {
@@ -1026,7 +1060,9 @@ struct Engine {
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits3));
     want_slab((size_t)B * J * 4);
     const bool wpair = PWR_DBG_ENV("PWR_HEAD_WGRAD_PAIR", 0) != 0;      // weight gradients of the two heads in one launch (measured: no gain)
-    const bool napply = PWR_DBG_ENV("PWR_HEAD_NAPPLY", 1) != 0;         // round 6: the norm-fed layers' operand materialised once (see below)
+    // round 6: the norm-fed layers' operand materialised once (see below).  Measured: bit-identical and 0.04 ms per step SLOWER (5.196 / 5.235
+    // against 5.161 / 5.186 ms, interleaved): the extra 67 MB of traffic per layer beside the chain costs what the loader's arithmetic did.  Off.
+    const bool napply = PWR_DBG_ENV("PWR_HEAD_NAPPLY", 0) != 0;
     if (napply && (size_t)B * P * P * F * esz > need_napply) need_napply = (size_t)B * P * P * F * esz;
     const int splits_pair = wpair ? std::max(1, splits_for(M, F, F, ks) / 2) : splits_for(M, F, F, ks);
     want_slab(2 * pwr_conv_wgrad_slab_bytes(F, F, ks, splits_pair));
@@ -1474,7 +1510,9 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
     if (e->pack_pending) {
       e->pack_pending = false;
       if (!c.attached) side_pool_attach(c, (hipStream_t)st);
-      static const bool beside = PWR_DBG_ENV("PWR_PACK_BESIDE", 1) != 0;
+      // (measured, round 6: beside = 1 makes INFERENCE 4 % slower -- 1.70 against 1.63 ms, two interleaved runs -- and leaves the train step
+      // where it was: the two cross-stream dependencies per forward cost more than the 28-us launch they hide.  Off in the product.)
+      static const bool beside = PWR_DBG_ENV("PWR_PACK_BESIDE", 0) != 0;
       if (beside && c.use_side && c.n_side > 0 && c.n_fork > 0 && e->fwd_first_pack_op < e->fwd.size()) {
         if (!e->ev_pack && hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming) != hipSuccess) e->ev_pack = nullptr;
       }

@@ -61,6 +61,80 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const T* __restrict__
   }
 }
 
+// norm_partial_kernel with the tensor's PRODUCER fused in (round 6, instance norm): the input of a ResBlock's first norm on the 64x64 /
+// 32x32 hourglass levels is the 2x2 max-pool of the level above (model.py:40) or the nearest up-sample of the level below + the skip
+// (model.py:45-47); each was a launch of its own in front of the statistics launch.  SRC 1: y = maxpool2x2(xa [B,2H,2W,C]); SRC 2:
+// y = xa [B,H,W,C] + up(xh [B,H/2,W/2,C]).  The value is computed with maxpool_fwd_kernel's / upsample_add_kernel's arithmetic, WRITTEN to
+// y (the convs and the backward pass read it) and accumulated -- same thread -> (pixel, channel slot) map, same order as norm_partial_kernel:
+// the partials, the finalised state and y are the bytes the two launches gave.
+template <typename T, int SRC>
+__device__ __forceinline__ typename Vec16<T>::type norm_src_value(const T* __restrict__ xa, const T* __restrict__ xh, int b, int pp, int H, int W, int C,
+                                                                   int cq) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  const int oy = pp / W, ox = pp - oy * W;
+  V o;
+  if constexpr (SRC == 1) {
+    const T* p = xa + (((size_t)b * 2 * H + 2 * oy) * 2 * W + 2 * ox) * C + cq * EP;
+    const V v00 = *reinterpret_cast<const V*>(p), v01 = *reinterpret_cast<const V*>(p + C);
+    const V v10 = *reinterpret_cast<const V*>(p + (size_t)2 * W * C), v11 = *reinterpret_cast<const V*>(p + (size_t)2 * W * C + C);
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+      o[e] = Elem<T>::from_f(fmaxf(fmaxf(Elem<T>::to_f(v00[e]), Elem<T>::to_f(v01[e])), fmaxf(Elem<T>::to_f(v10[e]), Elem<T>::to_f(v11[e]))));
+  } else {
+    // (exact 2x up-sample: ATen's nearest source index floor(dst * 0.5f) = dst >> 1, as pool.hip's nearest_src gives for in = out / 2)
+    const V hv = *reinterpret_cast<const V*>(xh + (((size_t)b * (H / 2) + (oy >> 1)) * (W / 2) + (ox >> 1)) * C + cq * EP);
+    const V sv = *reinterpret_cast<const V*>(xa + ((size_t)b * H * W + pp) * C + cq * EP);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) o[e] = Elem<T>::from_f(Elem<T>::to_f(hv[e]) + Elem<T>::to_f(sv[e]));
+  }
+  return o;
+}
+template <typename T, int SRC>
+__global__ __launch_bounds__(256) void norm_partial_src_kernel(const T* __restrict__ xa, const T* __restrict__ xh, T* __restrict__ y,
+                                                               float* __restrict__ partial, int H, int W, int C, int nchunks) {
+  constexpr int EP = Elem<T>::kPer16B;
+  typedef typename Vec16<T>::type V;
+  extern __shared__ float red[];  // [pl][2][C]
+  const int HW = H * W;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  const int per = (HW + nchunks - 1) / nchunks;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  T* base = y + (size_t)b * HW * C;
+  float s1[EP], s2[EP], k[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (pj < pl) {
+    const V kv = norm_src_value<T, SRC>(xa, xh, b, 0, H, W, C, cq);      // shift: pixel 0 of the sample (computed, not read back)
+#pragma unroll
+    for (int e = 0; e < EP; ++e) k[e] = Elem<T>::to_f(kv[e]);
+#pragma unroll 4
+    for (int pp = p0 + pj; pp < p1; pp += pl) {
+      const V v = norm_src_value<T, SRC>(xa, xh, b, pp, H, W, C, cq);
+      *reinterpret_cast<V*>(base + (size_t)pp * C + cq * EP) = v;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) {
+        const float d = Elem<T>::to_f(v[e]) - k[e];
+        s1[e] += d;
+        s2[e] = fmaf(d, d, s2[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      red[(pj * 2 + 0) * C + cq * EP + e] = s1[e];
+      red[(pj * 2 + 1) * C + cq * EP + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int j = 0; j < pl; ++j) s += red[j * 2 * C + i];
+    partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+  }
+}
+
 // One thread per (b,c) [instance] or per c [batch].  Writes mean/rstd/scale/shift [B,C].
 template <typename T>
 __global__ void norm_finalize_kernel(const T* __restrict__ y, const float* __restrict__ partial,
@@ -936,5 +1010,34 @@ extern "C" int pwr_norm_apply(const void* y, const float* state, void* out, int 
   const int nch = norm_chunks(B, HW);
   if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_apply_kernel<bf16_t>), dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, state, (bf16_t*)out, B, HW, C, nch, relu);
   else hipLaunchKernelGGL((norm_apply_kernel<float>), dim3(nch, B), dim3(256), 0, (hipStream_t)stream, (const float*)y, state, (float*)out, B, HW, C, nch, relu);
+  return (int)hipGetLastError();
+}
+
+// pwr_maxpool_fwd (src 1: xa [B,2H,2W,C]) or pwr_upsample_add_fwd (src 2: xa [B,H,W,C] skip, xh [B,H/2,W/2,C]) writing y [B,H,W,C], fused
+// with pwr_norm_stats(y, ..., mode 0) of the InstanceNorm that follows: two launches (producer + partial sums, finalisation) instead of
+// three, y and the [4][B][C] state bit-identical.  PWR_EUNSUPPORTED where pwr_norm_stats would take its one-block-per-sample form
+// (H W <= 512) or the shape has no 16-byte channel slots: the caller then issues the separate launches.
+extern "C" int pwr_norm_stats_fused_src(int src, const void* xa, const void* xh, void* y, const float* gamma, const float* beta, float* partial,
+                                        float* state, int B, int H, int W, int C, float eps, int dtype, void* stream) {
+  const int EP = dtype == PWR_BF16 ? 8 : 4, HW = H * W;
+  static const int fwd_small = PWR_DBG_ENV("PWR_NORM_FWD_SMALL", 512);
+  if (C % EP || C / EP > 256 || HW <= fwd_small || (src != 1 && src != 2) || (src == 2 && ((H | W) & 1))) return PWR_EUNSUPPORTED;
+  if (!xa || (src == 2 && !xh) || !y || !partial || !state) return PWR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = norm_chunks(B, HW);
+  const int pl = 256 / (C / EP);
+  const size_t sh = (size_t)pl * 2 * C * 4;
+  partial = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + norm_counter_bytes(B));
+  if (dtype == PWR_BF16) {
+    if (src == 1) hipLaunchKernelGGL((norm_partial_src_kernel<bf16_t, 1>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)xa, (const bf16_t*)xh, (bf16_t*)y, partial, H, W, C, nch);
+    else hipLaunchKernelGGL((norm_partial_src_kernel<bf16_t, 2>), dim3(nch, B), dim3(256), sh, s, (const bf16_t*)xa, (const bf16_t*)xh, (bf16_t*)y, partial, H, W, C, nch);
+    hipLaunchKernelGGL((norm_finalize_kernel<bf16_t>), dim3((B * C + 255) / 256), dim3(256), 0, s, (const bf16_t*)y, partial, gamma, beta, state, nullptr,
+                       nullptr, B, HW, C, nch, 0, eps, 0.1f);
+  } else {
+    if (src == 1) hipLaunchKernelGGL((norm_partial_src_kernel<float, 1>), dim3(nch, B), dim3(256), sh, s, (const float*)xa, (const float*)xh, (float*)y, partial, H, W, C, nch);
+    else hipLaunchKernelGGL((norm_partial_src_kernel<float, 2>), dim3(nch, B), dim3(256), sh, s, (const float*)xa, (const float*)xh, (float*)y, partial, H, W, C, nch);
+    hipLaunchKernelGGL((norm_finalize_kernel<float>), dim3((B * C + 255) / 256), dim3(256), 0, s, (const float*)y, partial, gamma, beta, state, nullptr,
+                       nullptr, B, HW, C, nch, 0, eps, 0.1f);
+  }
   return (int)hipGetLastError();
 }

@@ -547,3 +547,19 @@ def norm_apply(y, state, relu=True):
     out = torch.empty_like(y)
     _lib.check(l.pwr_norm_apply(_p(y), _p(state), _p(out), int(relu), B, H * W, C, _dt(y), _s(y)), "pwr_norm_apply")
     return out
+
+
+def norm_stats_fused_src(src, xa, xh, gamma, beta, eps=1e-5):
+    """src 1: y = maxpool2x2(xa); src 2: y = xa + nearest-upsample(xh); fused with the InstanceNorm statistics of y (pwr_norm_stats_fused_src).
+    Returns (y, state) or None where the shape has no fused form."""
+    l = _lib.lib()
+    B, Ha, Wa, C = xa.shape
+    H, W = (Ha // 2, Wa // 2) if src == 1 else (Ha, Wa)
+    y = torch.empty(B, H, W, C, dtype=xa.dtype, device=xa.device)
+    partial = torch.zeros(l.pwr_norm_partial_bytes(B, H * W, C) // 4, dtype=torch.float32, device=xa.device)
+    state = torch.empty(4, B, C, dtype=torch.float32, device=xa.device)
+    rc = l.pwr_norm_stats_fused_src(src, _p(xa), _p(xh), _p(y), _p(gamma), _p(beta), _p(partial), _p(state), B, H, W, C, eps, _dt(xa), _s(xa))
+    if rc == -2:          # PWR_EUNSUPPORTED
+        return None
+    _lib.check(rc, "pwr_norm_stats_fused_src")
+    return y, state

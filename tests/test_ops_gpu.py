@@ -1115,3 +1115,24 @@ def test_norm_apply_and_the_weight_gradient_from_the_materialised_operand(dtype,
         a = K.conv_wgrad(nhwc(y, dtype), dy, C, 3, 1, norm=st, splits=8)
         b_ = K.conv_wgrad(got, dy, C, 3, 1, norm=None, splits=8)
         assert float(a.abs().max()) > 0 and torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(32, 32, 32, 128), (3, 64, 64, 128), (2, 32, 64, 64), (5, 24, 40, 32), (2, 16, 16, 128)])
+def test_norm_statistics_with_the_producer_fused_in(dtype, B, H, W, C):
+    """pwr_norm_stats_fused_src (round 6): the max-pool / the up-sample + skip add computed inside the statistics launch of the InstanceNorm that
+    follows -- the tensor AND the [4][B][C] state are the bytes of the separate launches (pwr_maxpool_fwd / pwr_upsample_add_fwd, then
+    pwr_norm_stats); H W <= 512 has no fused form (the engine then issues the separate launches)."""
+    from pixelwiseregression_amd import kernels as K
+    gamma, beta = (1 + 0.2 * rnd(C, seed=4)).float().to(DEV), (0.2 * rnd(C, seed=5)).float().to(DEV)
+    big = nhwc(rnd(B, C, 2 * H, 2 * W, seed=31) + 3.0, dtype)
+    skip, low = nhwc(rnd(B, C, H, W, seed=32) - 2.0, dtype), nhwc(rnd(B, C, H // 2, W // 2, seed=33), dtype)
+    for src, (xa, xh), sep in ((1, (big, None), lambda: K.maxpool_fwd(big)), (2, (skip, low), lambda: K.upsample_add(low, skip))):
+        y0 = sep()
+        st0 = K.norm_stats(y0, gamma, beta, mode=0)
+        got = K.norm_stats_fused_src(src, xa, xh, gamma, beta)
+        if H * W <= 512:
+            assert got is None
+            continue
+        y1, st1 = got
+        assert float(y0.float().abs().max()) > 0 and torch.equal(y0, y1) and torch.equal(st0, st1), (src, float((st0 - st1).abs().max()))

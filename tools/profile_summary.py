@@ -55,7 +55,8 @@ def entry(table_f, table_w, match, grid, alg, label, required=True):
     arguments up to a comma, e.g. "conv3x3_wstat_kernel<true, 0," -- a further template parameter then still matches); `grid` selects among
     launches of that kernel at several grid sizes.  Several (kernel, grid) keys matching with grid = None is an ERROR (round 5 averaged
     whichever came first: the 80-split reduce against round 4's 24-split one), so is no match when the pass has data at all."""
-    ks = sorted(k for k in table_f if match in k[0] and (grid is None or k[1] == str(grid)))
+    grids = None if grid is None else [str(g_) for g_ in (grid if isinstance(grid, (list, tuple)) else [grid])]
+    ks = sorted(k for k in table_f if match in k[0] and (grids is None or k[1] in grids))
     if not ks:
         if table_f and required:
             MISSING.append("%s (match %r, grid %s): no such kernel in the FETCH_SIZE pass" % (label, match, grid))
@@ -88,7 +89,9 @@ entry(fe, wr, "wgrad_reduce_fast_kernel<9", None, None, "wgrad_reduce_fast_kerne
 fd, wd = mean_by_kernel("pmc_fetch_dec", "FETCH_SIZE"), mean_by_kernel("pmc_write_dec", "WRITE_SIZE")
 for (Bd, Jd, Pd, nt) in ((32, 14, 64, 256), (64, 21, 64, 256), (128, 42, 128, 512)):
     grid = Bd * Jd * nt
-    entry(fd, wd, "decode_fwd_cached", grid, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+    # (round 6: with >= 2048 maps of 128 x 128 a forward workgroup owns 3 or 2 consecutive maps of a sample)
+    fgrid = [grid, Bd * (Jd // 3) * nt, Bd * (Jd // 2) * nt] if Pd == 128 else grid
+    entry(fd, wd, "decode_fwd_cached", fgrid, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
     entry(fd, wd, "decode_bwd_cached", grid, 28 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd, "decode_bwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
 if MISSING:
     out["ERRORS"] = MISSING
