@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply, pwr_norm_stats_fused_src; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply, pwr_norm_stats_fused_src, pwr_nchw_to_nhwc_pad_pair; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -292,6 +292,8 @@ int pwr_upsample_add_fwd(const void* h, const void* skip, void* out, int B, int 
 int pwr_upsample_bwd(const void* dout, void* dh, int B, int Hi, int Wi, int Ho, int Wo, int C, int dtype, void* stream);
 /* fp32 [B,J,N] -> `dtype` [B,N,Jp] with channels >= J zero (feeds decoder gradients to the head convs) */
 int pwr_nchw_to_nhwc_pad(const float* src, void* dst, int B, int J, int N, int Jp, int dtype, void* stream);
+/* two of them (one shape) in one launch: the two regression heads' output gradients of a stage (round 6) */
+int pwr_nchw_to_nhwc_pad_pair(const float* src_a, void* dst_a, const float* src_b, void* dst_b, int B, int J, int N, int Jp, int dtype, void* stream);
 int pwr_add_inplace(const void* x, void* y, long long n, int dtype, void* stream);
 /* bias gradients: out[c] (+)= sum_m x[m][c] for NHWC [M,C] (slab: pwr_colsum_blocks(M)*C floats); and
  * out[j] (+)= sum_{b,n} x[b][j][n] for fp32 NCHW planes */

@@ -59,17 +59,21 @@ __device__ __forceinline__ void dec_st(float* q, const f32x4& v) {
 // map i + 1 are requested before map i's block reductions and its p stores, so the CU (one workgroup of this size fits) has loads in flight
 // during what used to be a load-free third of every map.  Same arithmetic per map.
 // PFD: the next map's depth maps D are requested with its logits (another NV vectors of registers).
-template <int NT, int NV, int MINW = 1, bool NTL = false, int MPW = 1, bool PFD = false>
+// LDS_EV (round 6 experiment): the exponentials wait for the block reductions in LDS (64 KiB per 128x128 map) instead of in registers, so
+// that the kernel fits 128 registers and TWO workgroups share a CU (their load and store phases overlap by themselves).
+template <int NT, int NV, int MINW = 1, bool NTL = false, bool PIPE = false, bool PFD = false, bool LDS_EV = false>
 __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __restrict__ z, const float* __restrict__ D,
                                                         const float* __restrict__ L, const float* __restrict__ m,
                                                         const float* __restrict__ w, float* __restrict__ p_out,
-                                                        float* __restrict__ uvd, int J, int P, int method, int Bx) {
+                                                        float* __restrict__ uvd, int J, int P, int method, int Bx, int mpw_) {
+  const int MPW = PIPE ? mpw_ : 1;            // maps per workgroup (consecutive maps of one sample)
   // ONE dependent memory phase: every thread exponentiates against its OWN maximum (all its logits are in registers), so the
   // loads of D, L and m are not held back behind a workgroup-wide max reduction; the two block reductions (max of the thread
   // maxima, then the sums rescaled by exp(m_thread - M)) sit back to back at the end with no memory access between them.
   //   p = exp(e - m_t) * exp(m_t - M) / S      (one extra rounding vs exp(e - M) / S: ~1e-7 relative)
   constexpr int NW = NT / 64;
   __shared__ float red[8 * NW];
+  __shared__ __attribute__((aligned(16))) float evl[LDS_EV ? NT * NV * 4 : 4];
   const int map0 = dec_map(blockIdx.x, J / MPW, Bx) ;      // (group index: MPW maps per group)
   if (map0 < 0) return;
   const int N = P * P;
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
         ev.x = fmaxf(e[k].x, 0.f) + PWR_DEC_EPS; ev.y = fmaxf(e[k].y, 0.f) + PWR_DEC_EPS;
         ev.z = fmaxf(e[k].z, 0.f) + PWR_DEC_EPS; ev.w = fmaxf(e[k].w, 0.f) + PWR_DEC_EPS;
       }
-      e[k] = ev;
+      if constexpr (LDS_EV) *reinterpret_cast<f32x4*>(evl + (size_t)(k * NT + tid) * 4) = ev;
+      else e[k] = ev;
       cs[0] += ev.x; cs[1] += ev.y; cs[2] += ev.z; cs[3] += ev.w;
       const float gy = grid_coord(row0 + k * rows_per_step, P);
       sv += gy * ((ev.x + ev.y) + (ev.z + ev.w));
@@ -127,11 +132,11 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
       sd += (em.x * mr.x + em.y * mr.y) + (em.z * mr.z + em.w * mr.w);
       // 128x128 maps (NV = 8): keep at most two iterations' loads in flight per thread, otherwise the scheduler hoists all 24 and
       // the kernel needs 144 VGPRs = one workgroup per CU; with <= 128 two workgroups overlap their phases
-      if (MINW > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);
+      if (MINW > 1 && (LDS_EV || (k & 1))) __builtin_amdgcn_sched_barrier(0);
     }
     // the next map's logits: requested here, consumed at the top of the next trip
-    f32x4 en[MPW > 1 ? NV : 1];
-    if constexpr (MPW > 1) {
+    f32x4 en[PIPE ? NV : 1];
+    if constexpr (PIPE) {
       if (mi + 1 < MPW) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) en[k] = dec_ld<NTL>(z + mo + (size_t)N + (size_t)(k * NT + tid) * 4);
@@ -157,17 +162,20 @@ __global__ __launch_bounds__(NT, MINW) void decode_fwd_cached(const float* __res
     const float inv = __fdiv_rn(1.f, r[0]);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      f32x4 pv;
-      pv.x = __fdiv_rn(e[k].x * f, r[0]); pv.y = __fdiv_rn(e[k].y * f, r[0]);
-      pv.z = __fdiv_rn(e[k].z * f, r[0]); pv.w = __fdiv_rn(e[k].w * f, r[0]);
+      f32x4 pv, ek;
+      if constexpr (LDS_EV) ek = *reinterpret_cast<const f32x4*>(evl + (size_t)(k * NT + tid) * 4);      // (the thread's own stores)
+      else ek = e[k];
+      pv.x = __fdiv_rn(ek.x * f, r[0]); pv.y = __fdiv_rn(ek.y * f, r[0]);
+      pv.z = __fdiv_rn(ek.z * f, r[0]); pv.w = __fdiv_rn(ek.w * f, r[0]);
       dec_st<NTL>(p_out + mo + (size_t)(k * NT + tid) * 4, pv);
+      if (LDS_EV) __builtin_amdgcn_sched_barrier(0);
     }
     if (tid == 0) {
       uvd[(size_t)map * 3 + 0] = r[1] * inv;
       uvd[(size_t)map * 3 + 1] = r[2] * inv;
       uvd[(size_t)map * 3 + 2] = __fdiv_rn(r[4] * inv, r[3] * inv + PWR_DEC_EPS);
     }
-    if constexpr (MPW > 1) {
+    if constexpr (PIPE) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) e[k] = en[k];
     }
@@ -425,10 +433,10 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
   const int grid = dec_grid(B, J, &Bx);
   static const int nt = PWR_DBG_ENV("PWR_DEC_NT", 3) & 1;
   if (P % 4 == 0 && N == 256 * 4 * 4 && 1024 % P == 0) {
-    if (nt) hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4, 1, true>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    if (nt) hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4, 1, true>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
+    else hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 4>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
   } else if (P % 4 == 0 && N == 256 * 4 && 1024 % P == 0)
-    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+    hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 1>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
   else if (P % 4 == 0 && N == 512 * 8 * 4 && 2048 % P == 0) {
     // 128x128 maps.  A/B switch (tools/bench_decoder.py), measured at B=128, J=42 on MI355X (profiles/r2_decoder_bench.jsonl):
     // 0 = 512 threads x 8 vectors, 144 VGPRs, one workgroup per CU: 4.28 TB/s (default); 1 = 1024 threads x 4 vectors: 4.24 TB/s;
@@ -438,28 +446,43 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
     // for several rounds anyway
     // (pipe = 2: the next map's depth maps prefetched too, 223 registers: no faster than 1 -- 233.4 against 235.5 us, within the noise)
     static const int pipe = PWR_DBG_ENV("PWR_DEC_PIPE", 1);
-    const int mpw = (pipe && v == 0 && maps >= 8 * 256) ? (J % 3 == 0 ? 3 : (J % 2 == 0 ? 2 : 1)) : 1;
+    // maps per workgroup: a divisor of J; cost model = rounds of workgroups over the 256 CUs x maps per workgroup, the deepest pipeline among
+    // the cheapest (PWR_DEC_MPW, debug build: force a value)
+    int mpw = 1;
+    if (pipe && v == 0 && maps >= 8 * 256) {
+      const int Bp = 8 * ((B + 7) / 8);
+      long long best = -1;
+      for (int q = 1; q <= J; ++q) {
+        if (J % q) continue;
+        const long long wgs = (long long)Bp * (J / q), cost = ((wgs + 255) / 256) * q;
+        if (best < 0 || cost <= best) { best = cost; mpw = q; }
+      }
+      static const int force = PWR_DBG_ENV("PWR_DEC_MPW", 0);
+      if (force > 0 && J % force == 0) mpw = force;
+    }
     const int gp = dec_grid(B, J, &Bx, mpw);
     if (v == 1 && 4096 % P == 0)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(grid), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<1024, 4>), dim3(grid), dim3(1024), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
     else if (v == 2)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else if (mpw == 3 && nt && pipe == 2)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 3, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else if (mpw == 2 && nt && pipe == 2)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 2, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else if (mpw == 3 && nt)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 3>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else if (mpw == 3)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, false, 3>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else if (mpw == 2 && nt)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, 2>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
-    else if (mpw == 2)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, false, 2>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
+#ifdef PWR_DEBUG_BUILD
+    // (round 6 experiments, debug build only -- both SLOWER than the pipelined one-workgroup-per-CU form, 229 us: 4 = exponentials staged in
+    // LDS, 128 registers, two 512-thread workgroups per CU: 262 us; 3 = 256 threads x 16 vectors, two workgroups per CU: 253 us)
+    else if (v == 4)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 4, true, false, false, true>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
+    else if (v == 3 && 1024 % P == 0)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<256, 16, 2, true>), dim3(grid), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
+#endif
+    else if (mpw > 1 && nt && pipe == 2)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, true, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, mpw);
+    else if (mpw > 1 && nt)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, mpw);
+    else if (mpw > 1)
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, false, true>), dim3(gp), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, mpw);
     else if (nt)
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8, 1, true>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
     else
-      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx);
+      hipLaunchKernelGGL((pwr::decode_fwd_cached<512, 8>), dim3(grid), dim3(512), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method, Bx, 1);
   }
   else
     hipLaunchKernelGGL((pwr::decode_fwd_generic<256>), dim3(maps), dim3(256), 0, s, z, D, L, m, w, p_out, uvd_out, J, P, method);

@@ -1081,9 +1081,10 @@ struct Engine {
       const Head* hs[2] = {&P_, &D_};
       const size_t gsrc[2] = {gz_off, gD_off};
       int rc = 0;
+      rc = pwr_nchw_to_nhwc_pad_pair((const float*)(c.arena + gsrc[0]), c.arena + P_.gT, (const float*)(c.arena + gsrc[1]), c.arena + D_.gT, Bc, Jc, Pc * Pc,
+                                     Jp, dt, c.stream);       // (round 6: one launch for both heads)
       for (int k = 0; k < 2 && !rc; ++k) {
         const Head& h = *hs[k];
-        rc = pwr_nchw_to_nhwc_pad((const float*)(c.arena + gsrc[k]), c.arena + h.gT, Bc, Jc, Pc * Pc, Jp, dt, c.stream);
         // (the last conv's bias gradient feeds the flat gradient only: side stream, with that stream's slab as scratch -- round 4; it was two
         // launches of 6 us per head on the chain)
         const size_t src = gsrc[k];

@@ -155,10 +155,12 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 }
 
 // src [B,J,N] fp32 (optionally + src2) -> dst [B,N,Jp] T with channels >= J zeroed
+// (src2 / dst2 != null: a second tensor of the same shape in the same launch, blockIdx.z = 1 -- the two heads' output gradients, round 6)
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int J, int N,
-                                                               int Jp) {
+                                                               int Jp, const float* __restrict__ src2 = nullptr, T* __restrict__ dst2 = nullptr) {
   __shared__ float tile[64][65];
+  if (blockIdx.z) { src = src2; dst = dst2; }
   const int b = blockIdx.y, p0 = blockIdx.x * 64;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int j = i / 64, pp = i % 64;
@@ -279,6 +281,17 @@ extern "C" int pwr_nchw_to_nhwc_pad(const float* src, void* dst, int B, int J, i
   dim3 grid((N + 63) / 64, B);
   if (dtype == PWR_BF16) hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, B, J, N, Jp);
   else hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, B, J, N, Jp);
+  return (int)hipGetLastError();
+}
+
+// two pwr_nchw_to_nhwc_pad of one shape in one launch (the plane and the depth head's output gradients of a stage)
+extern "C" int pwr_nchw_to_nhwc_pad_pair(const float* src_a, void* dst_a, const float* src_b, void* dst_b, int B, int J, int N, int Jp, int dtype,
+                                         void* stream) {
+  if (Jp > 64 || J > Jp) return PWR_EUNSUPPORTED;
+  if (!src_a || !dst_a || !src_b || !dst_b) return PWR_EINVAL;
+  dim3 grid((N + 63) / 64, B, 2);
+  if (dtype == PWR_BF16) hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, src_a, (bf16_t*)dst_a, B, J, N, Jp, src_b, (bf16_t*)dst_b);
+  else hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src_a, (float*)dst_a, B, J, N, Jp, src_b, (float*)dst_b);
   return (int)hipGetLastError();
 }
 
