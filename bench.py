@@ -480,7 +480,7 @@ def main():
         out["step_mfma_frac"] = step_flops / (dt / args.steps) / (peak * 1e12)
         if True:   # (kept as a block: the roofline probes run on every rank-0 report)
             t, flops = time_head_conv(dev, B_PER_GPU, precision=args.precision)
-            # HBM bytes per launch are NOT measured in this run (PMC collection needs rocprofv3 passes of its own: tools/profile_r5.sh), so
+            # HBM bytes per launch are NOT measured in this run (PMC collection needs rocprofv3 passes of its own: tools/profile_r6.sh), so
             # `traffic` is null here; the counter result of the committed profile of the same kernel and shape is quoted beside it
             traffic_profile = None
             tkey = "conv3x3_wstat_kernel<norm prologue, no statistics> B=32 64x64 128->128"
@@ -514,7 +514,7 @@ def main():
                                        "frac": nb / td / 1e9 / PEAK_HBM_GBS, "traffic": None, "traffic_profile": dprofile,
                                        "us_per_launch": td * 1e6,
                                        "note": "23 MB per launch: launch / latency bound at this shape (the rocprofv3 average of the same probe is ~1 us longer than this "
-                                               "HIP-event figure: profiles/r5_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r5_dec_bench.jsonl)"}
+                                               "HIP-event figure: profiles/r6_rocprofv3_roof_kernel_stats.csv); HBM bound at the C5 shape (profiles/r6_dec_bench.jsonl)"}
         if world == 1 and args.with_pipeline and native:
             model.train()
             out["pipeline"] = pipeline_block(model, trainer, dev, max(10, min(args.steps, 100)))

@@ -446,17 +446,21 @@ extern "C" int pwr_decode_fwd(const float* z, const float* D, const float* L, co
     // for several rounds anyway
     // (pipe = 2: the next map's depth maps prefetched too, 223 registers: no faster than 1 -- 233.4 against 235.5 us, within the noise)
     static const int pipe = PWR_DBG_ENV("PWR_DEC_PIPE", 1);
-    // maps per workgroup: a divisor of J; cost model = rounds of workgroups over the 256 CUs x maps per workgroup, the deepest pipeline among
-    // the cheapest (PWR_DEC_MPW, debug build: force a value)
+    // maps per workgroup: a divisor of J; cost model = rounds of workgroups over the 256 CUs x maps per workgroup (PWR_DEC_MPW, debug build:
+    // force a value)
     int mpw = 1;
     if (pipe && v == 0 && maps >= 8 * 256) {
+      // (the SMALLEST such divisor > 1: the groups of a sample run side by side on one XCD and share its L and m in L2; with 21 maps per
+      // workgroup -- two groups per sample -- L and m were evicted between maps and the forward fetched 996 instead of 737 MB, for the same time)
       const int Bp = 8 * ((B + 7) / 8);
+      auto cost = [&](int q) { return (((long long)Bp * (J / q) + 255) / 256) * q; };
       long long best = -1;
-      for (int q = 1; q <= J; ++q) {
+      int bq = 1;
+      for (int q = 2; q <= J; ++q) {
         if (J % q) continue;
-        const long long wgs = (long long)Bp * (J / q), cost = ((wgs + 255) / 256) * q;
-        if (best < 0 || cost <= best) { best = cost; mpw = q; }
+        if (best < 0 || cost(q) < best) { best = cost(q); bq = q; }
       }
+      if (best >= 0 && best <= cost(1)) mpw = bq;
       static const int force = PWR_DBG_ENV("PWR_DEC_MPW", 0);
       if (force > 0 && J % force == 0) mpw = force;
     }

@@ -89,9 +89,13 @@ entry(fe, wr, "wgrad_reduce_fast_kernel<9", None, None, "wgrad_reduce_fast_kerne
 fd, wd = mean_by_kernel("pmc_fetch_dec", "FETCH_SIZE"), mean_by_kernel("pmc_write_dec", "WRITE_SIZE")
 for (Bd, Jd, Pd, nt) in ((32, 14, 64, 256), (64, 21, 64, 256), (128, 42, 128, 512)):
     grid = Bd * Jd * nt
-    # (round 6: with >= 2048 maps of 128 x 128 a forward workgroup owns 3 or 2 consecutive maps of a sample)
-    fgrid = [grid, Bd * (Jd // 3) * nt, Bd * (Jd // 2) * nt] if Pd == 128 else grid
-    entry(fd, wd, "decode_fwd_cached", fgrid, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+    # (round 6: with >= 2048 maps of 128 x 128 a forward workgroup owns several consecutive maps of a sample, so its grid is a fraction of
+    # B J workgroups: the 512-thread kernels serve the 128 x 128 maps only, which one shape of the run has -- matched by name)
+    if Pd == 128:
+        entry(fd, wd, "decode_fwd_cached<512", None, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+        entry(fd, wd, "decode_bwd_cached<512", None, 28 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd, "decode_bwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
+        continue
+    entry(fd, wd, "decode_fwd_cached", grid, 12 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd + 12 * Bd * Jd, "decode_fwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
     entry(fd, wd, "decode_bwd_cached", grid, 28 * Bd * Jd * Pd * Pd + 8 * Bd * Pd * Pd, "decode_bwd B=%d J=%d P=%d" % (Bd, Jd, Pd))
 if MISSING:
     out["ERRORS"] = MISSING

@@ -2,7 +2,7 @@
 segment {decoder, heads, hourglass levels, stage input, stem}, from events the DEBUG build of the engine puts at every change of scope in its
 launch lists (pwr_engine_set_timing / pwr_engine_timing_report).  Train steps only -- no inference loop, no probes in the same process.
 The side streams' weight-gradient kernels are not in these numbers (they run beside the chain); `step_ms` is the untimed step for scale.
-    python tools/step_breakdown.py [steps=30]  ->  JSON (profiles/r5_step_breakdown.json)"""
+    python tools/step_breakdown.py [steps=30]  ->  JSON (profiles/r6_step_breakdown.json)"""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
