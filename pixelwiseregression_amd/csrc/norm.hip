@@ -522,6 +522,19 @@ __device__ __forceinline__ void norm_bwd_apply_fold_body(const T* __restrict__ g
   constexpr int EP = Elem<T>::kPer16B;
   typedef typename Vec16<T>::type V;
   __shared__ float ssum[1024];     // [2][C], C <= 512
+  // the per-channel state of this thread's slot: requested BEFORE the slab sums, so that its round trip and the sums' overlap (behind the
+  // barrier below they were one more dependent L2 round trip in every workgroup)
+  const int cpp = C / EP, pl = 256 / cpp;
+  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
+  const size_t plane = (size_t)B * C;
+  float mu[EP], rs[EP], sc[EP], sh[EP];
+  if (pj < pl) {
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      const int c = b * C + cq * EP + e;
+      mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
+    }
+  }
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int qq = i >= C ? 1 : 0, c = i - qq * C;
     const float* pp = partial + ((size_t)b * pchunks * 2 + qq) * C + c;      // slab row k of this sum: pp[k * 2 C]
@@ -546,20 +559,13 @@ __device__ __forceinline__ void norm_bwd_apply_fold_body(const T* __restrict__ g
     ssum[i] = sacc / (float)HW;
   }
   __syncthreads();
-  const int cpp = C / EP, pl = 256 / cpp;
-  const int cq = threadIdx.x % cpp, pj = threadIdx.x / cpp;
   if (pj >= pl) return;
   const int per = (HW + nchunks - 1) / nchunks;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
   const size_t base = (size_t)b * HW * C;
-  const size_t plane = (size_t)B * C;
-  float mu[EP], rs[EP], sc[EP], sh[EP], s1[EP], s2[EP];
+  float s1[EP], s2[EP];
 #pragma unroll
-  for (int e = 0; e < EP; ++e) {
-    const int c = b * C + cq * EP + e;
-    mu[e] = state[c]; rs[e] = state[plane + c]; sc[e] = state[2 * plane + c]; sh[e] = state[3 * plane + c];
-    s1[e] = ssum[cq * EP + e]; s2[e] = ssum[C + cq * EP + e];
-  }
+  for (int e = 0; e < EP; ++e) { s1[e] = ssum[cq * EP + e]; s2[e] = ssum[C + cq * EP + e]; }
 #pragma unroll 4
   for (int pp = p0 + pj; pp < p1; pp += pl) {
     const size_t off = base + (size_t)pp * C + cq * EP;
@@ -952,7 +958,11 @@ extern "C" int pwr_norm_bwd_apply_from_partial(const void* ga, const void* ya, c
   const int EP = dtype == PWR_BF16 ? 8 : 4;
   if (C % EP || C / EP > 256 || 2 * C > 1024 || chunks < 1) return PWR_EUNSUPPORTED;
   if (!ga || !ya || !state_a || !partial_a || !dya || (gb && (!yb || !state_b || !partial_b || !dyb))) return PWR_EINVAL;
-  const int nch = norm_chunks(B, HW);
+  // (the apply step's pixel chunks are a matter of launch shape only -- every element is computed alike -- so the fold launch may take
+  // FEWER, larger workgroups than the two-launch form: each one pays the slab sums once.  PWR_FOLD_DIV, debug build: 1, 2, 4)
+  static const int fdiv = PWR_DBG_ENV("PWR_FOLD_DIV", 1);
+  int nch = norm_chunks(B, HW) / (fdiv > 0 ? fdiv : 1);
+  if (nch < 1) nch = 1;
   NormBwdFoldPair q;
   q.j[0] = NormBwdFoldJob{ga, ya, state_a, partial_a, addend_a, dya};
   q.j[1] = NormBwdFoldJob{gb, yb, state_b, partial_b, nullptr, dyb};
