@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restri
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     float s = 0.f;
     for (int j = 0; j < pl; ++j) s += red[j * 2 * C + i];
-    partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+    // (hand-off form: write-through `sc1` stores -- the bytes are in memory when the store is acknowledged, no L2 write-back fence per block)
+    if constexpr (SINGLE) partial[((size_t)(b * nchunks + chunk) * 2) * C + i] = s;
+    else __hip_atomic_store(&partial[((size_t)(b * nchunks + chunk) * 2) * C + i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (SINGLE) {   // one block owns the whole sample: its own partials are visible after a workgroup barrier
     __syncthreads();
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (round 6: no release fence -- every partial was stored `sc1` and drained by its wave's vmcnt(0) above, behind the barrier;
+    // MI355X_MICROARCH.md, Valid forms.  The LAST arriver still runs the acquire: several of these blocks share a CU.)
     const int t = __hip_atomic_fetch_add(&counters[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = t == nchunks - 1;
     if (last) {
@@ -276,9 +278,20 @@ __global__ __launch_bounds__(256) void norm_stats_fused_kernel(const T* __restri
   const size_t plane = (size_t)B * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     float a1 = 0.f, a2 = 0.f;
-    for (int kk = 0; kk < nchunks; ++kk) {
-      a1 += partial[((size_t)(b * nchunks + kk) * 2 + 0) * C + c];
-      a2 += partial[((size_t)(b * nchunks + kk) * 2 + 1) * C + c];
+    int kk = 0;
+    for (; kk + 8 <= nchunks; kk += 8) {      // (8 loads of a sum in flight, added in norm_finalize_kernel's order; `sc1` loads: L2-served)
+      float u1[8], u2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        u1[u] = __hip_atomic_load(&partial[((size_t)(b * nchunks + kk + u) * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u2[u] = __hip_atomic_load(&partial[((size_t)(b * nchunks + kk + u) * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a1 += u1[u]; a2 += u2[u]; }
+    }
+    for (; kk < nchunks; ++kk) {
+      a1 += __hip_atomic_load(&partial[((size_t)(b * nchunks + kk) * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a2 += __hip_atomic_load(&partial[((size_t)(b * nchunks + kk) * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const float n = (float)HW;
     const float k0 = Elem<T>::to_f(base[c]);
@@ -692,7 +705,8 @@ extern "C" int pwr_norm_stats(const void* y, const float* gamma, const float* be
   // Measured on MI355X (BASELINE C2): the in-kernel hand-off costs more than the launch it saves (1024 blocks x release
   // fence): train step 13.0 ms fused vs 12.6 ms as two launches.  So it is opt-in; small maps, where ONE block owns the
   // whole sample and no hand-off is needed, always take the single-launch form.
-  const bool fuse = false;     // (measured: see above; the hand-off form is unreachable in the shipped configuration)
+  // (round 6: the hand-off form without the release fence -- `sc1` partial stores -- behind PWR_NORM_FUSE, debug build; measured below)
+  static const bool fuse = PWR_DBG_ENV("PWR_NORM_FUSE", 0) != 0;
   static const int fwd_small = PWR_DBG_ENV("PWR_NORM_FWD_SMALL", 512);
   if (mode == 0 && HW <= fwd_small) {
     if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_stats_fused_kernel<bf16_t, true>), dim3(1, B), dim3(256), sh, s, (const bf16_t*)y, partial, counters, gamma, beta, state, B, HW, C, 1, eps);
