@@ -33,6 +33,7 @@ struct RbFwdParams {
   // one launch of 5 - 7 us less on the chain per level.
   int xmode = 0;
   const bf16_t* xa = nullptr; const bf16_t* xh = nullptr; bf16_t* xw = nullptr;
+  long long* stamps = nullptr;      // (debug build: s_memtime of thread 0 at the phase boundaries, 16 x int64 per workgroup; pwr_debug_set_stamps)
 };
 struct RbBwdParams {
   const bf16_t* gout; const bf16_t* x; const bf16_t* t1; const bf16_t* t2;
@@ -50,7 +51,14 @@ struct RbBwdParams {
   //   (maxpool_bwd_kernel: the gradient goes to the first maximum of each window in scan order).
   const bf16_t* up_src = nullptr; bf16_t* gout_w = nullptr;
   const bf16_t* pool_a = nullptr; const bf16_t* pool_addend = nullptr; bf16_t* pool_dst = nullptr;
+  long long* stamps = nullptr;      // (debug build, as in RbFwdParams)
 };
+#ifdef PWR_DEBUG_BUILD
+long long* wstat_stamps();        // conv_patch.hip: the buffer of pwr_debug_set_stamps
+#define RB_STAMP(p, i) do { if ((p).stamps && threadIdx.x == 0) (p).stamps[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RB_STAMP(p, i) do { } while (0)
+#endif
 
 constexpr int rb_max(int a, int b) { return a > b ? a : b; }
 
@@ -194,6 +202,9 @@ extern "C" int pwr_resblock_fwd_small_x(int xmode, const void* xa, const void* x
   p.sa = state_a; p.sb = state_b; p.sc = state_c;
   p.B = B; p.eps = eps;
   p.xmode = xmode; p.xa = (const bf16_t*)xa; p.xh = (const bf16_t*)xh; p.xw = (bf16_t*)x;
+#ifdef PWR_DEBUG_BUILD
+  p.stamps = wstat_stamps();
+#endif
   return rb_fwd_launch(p, W, (hipStream_t)stream);
 }
 
@@ -232,6 +243,9 @@ extern "C" int pwr_resblock_bwd_small_x(const void* up_src, const void* pool_a, 
   p.sa = state_a; p.sb = state_b; p.sc = state_c;
   p.sums_a = sums_a; p.sums_b = sums_b; p.sums_c = sums_c; p.bias_sums = bias_sums;
   p.B = B;
+#ifdef PWR_DEBUG_BUILD
+  p.stamps = wstat_stamps();
+#endif
   hipStream_t s = (hipStream_t)stream;
   const int wide = PWR_DBG_ENV("PWR_RESBLOCK_WAVES", 1);
   // 0: four waves everywhere (round 1); 1: eight on the 16x16 / 8x8 maps (measured best); 2: eight everywhere.
