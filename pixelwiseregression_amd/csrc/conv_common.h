@@ -1,5 +1,6 @@
 // Shared by the implicit-GEMM convolution kernels (conv_mfma.hip: universal; conv_patch.hip: LDS-resident input patch).
 #pragma once
+#include <type_traits>
 #include "pwr_common.h"
 
 namespace pwr {
@@ -163,10 +164,18 @@ struct EpiStats {
   __device__ __forceinline__ void finish(const ConvParams& p, float* lds, int b, int chunk, int nchunks, int n0) {
     if (kind == 0) return;   // (uniform)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, slot = tid % CPR;
+    // (lane ^ o through DPP / v_permlane swaps, pwr_common.h: the same sums as the __shfl_xor loop -- o = CPR, 2 CPR, ... 32 -- without its
+    // ds_bpermute_b32 round trips at the tail of every workgroup)
+    auto step = [&](auto O) __attribute__((always_inline)) {
+      constexpr int o = decltype(O)::value;
+      if constexpr (o >= CPR) {
 #pragma unroll
-    for (int o = CPR; o < 64; o <<= 1)
-#pragma unroll
-      for (int e = 0; e < EP; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        for (int e = 0; e < EP; ++e) { s1[e] = lane_xor_add<o>(s1[e]); s2[e] = lane_xor_add<o>(s2[e]); }
+      }
+    };
+    static_assert(CPR == 2 || CPR == 4 || CPR == 8 || CPR == 16 || CPR == 32, "slots per tile row");
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 8>{});
+    step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 32>{});
     if (lane < CPR) {
 #pragma unroll
       for (int e = 0; e < EP; ++e) { lds[((wid * 2 + 0) * CPR + slot) * EP + e] = s1[e]; lds[((wid * 2 + 1) * CPR + slot) * EP + e] = s2[e]; }

@@ -547,9 +547,15 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
       }
       if (est.kind) {           // the 16 lanes of a group share the slot: fixed-order butterfly, lane 0 of the group writes
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1)
+        for (int e = 0; e < EP; ++e) {      // (lane ^ 1, 2, 4, 8 by DPP, pwr_common.h: the __shfl_xor loop's sums without its 64 ds_bpermute_b32)
+          est.s1[e] = lane_xor_add<1>(est.s1[e]); est.s2[e] = lane_xor_add<1>(est.s2[e]);
+        }
 #pragma unroll
-          for (int e = 0; e < EP; ++e) { est.s1[e] += __shfl_xor(est.s1[e], o, 64); est.s2[e] += __shfl_xor(est.s2[e], o, 64); }
+        for (int e = 0; e < EP; ++e) { est.s1[e] = lane_xor_add<2>(est.s1[e]); est.s2[e] = lane_xor_add<2>(est.s2[e]); }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { est.s1[e] = lane_xor_add<4>(est.s1[e]); est.s2[e] = lane_xor_add<4>(est.s2[e]); }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { est.s1[e] = lane_xor_add<8>(est.s1[e]); est.s2[e] = lane_xor_add<8>(est.s2[e]); }
         if (li == 0) {
           const size_t srow = (size_t)b * (p.st_nchunks ? p.st_nchunks : tiles_img) + p.st_chunk0 + tr;
           float* out = est.kind == 1 ? p.st_partial + (srow * 3) * p.Cout : p.nb_partial + (srow * 2) * p.Cout;

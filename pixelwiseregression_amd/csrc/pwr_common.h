@@ -30,14 +30,53 @@ static inline int pwr_dbg_env_(const char* name, int dflt) { const char* e = get
 
 namespace pwr {
 
+// The value of lane ^ O (O a power of two below 64) WITHOUT the LDS crossbar (round 6).  __shfl_xor compiles to ds_bpermute_b32: an LDS-pipe
+// round trip per value and butterfly step, which the latency-bound kernels of the chain (one-launch ResBlocks, conv epilogue statistics,
+// decoder reductions) pay in full -- they have no other wave to hide it behind.  O = 1, 2: DPP quad permutes; 4: row_shl:4 / row_shr:4 under
+// bank masks; 8: row_ror:8; 16 / 32: v_permlane16_swap / v_permlane32_swap of the value with itself (the swap leaves the pair's lower and
+// upper value in its two results; the partner's is the one that is not the lane's own).  Butterflies built on it add or max self and
+// partner exactly like `v op= __shfl_xor(v, O)`: both operations commute, the bits are the same.
+template <int O>
+__device__ __forceinline__ float lane_xor(float x) {
+  const int u = __builtin_bit_cast(int, x);
+  if constexpr (O == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, u, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+  else if constexpr (O == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, u, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+  else if constexpr (O == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, u, 0x104 /* row_shl:4 */, 0xf, 0x5, false);       // lanes 0-3 and 8-11 of a row read lane + 4
+    t = __builtin_amdgcn_update_dpp(t, u, 0x114 /* row_shr:4 */, 0xf, 0xA, false);           // lanes 4-7 and 12-15 read lane - 4
+    return __builtin_bit_cast(float, t);
+  } else if constexpr (O == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, u, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  else if constexpr (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    return __builtin_bit_cast(float, (__builtin_amdgcn_workitem_id_x() & 16) ? (unsigned)r[0] : (unsigned)r[1]);
+  } else {
+    static_assert(O == 32, "butterfly step");
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+    return __builtin_bit_cast(float, (__builtin_amdgcn_workitem_id_x() & 32) ? (unsigned)r[0] : (unsigned)r[1]);
+  }
+}
+// x + (x of lane ^ O): for 16 / 32 the swap's two results ARE self and partner, whichever lane: their sum needs no select
+template <int O>
+__device__ __forceinline__ float lane_xor_add(float x) {
+  if constexpr (O == 16) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  } else if constexpr (O == 32) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  } else return x + lane_xor<O>(x);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = lane_xor_add<32>(v); v = lane_xor_add<16>(v); v = lane_xor_add<8>(v);
+  v = lane_xor_add<4>(v); v = lane_xor_add<2>(v); v = lane_xor_add<1>(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, lane_xor<32>(v)); v = fmaxf(v, lane_xor<16>(v)); v = fmaxf(v, lane_xor<8>(v));
+  v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<1>(v));
   return v;
 }
 
