@@ -104,7 +104,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < TP; ++t) {
       float a = acc[e][t];
-      for (int o = NSL; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      // (lane ^ o for o = NSL ... 32 -- NSL, the channel slots, is a run-time power of two -- by DPP / v_permlane swaps, pwr_common.h: the sums of
+      // the __shfl_xor loop; the conditions are wave-uniform)
+      if (NSL <= 1) a = lane_xor_add<1>(a);
+      if (NSL <= 2) a = lane_xor_add<2>(a);
+      if (NSL <= 4) a = lane_xor_add<4>(a);
+      if (NSL <= 8) a = lane_xor_add<8>(a);
+      if (NSL <= 16) a = lane_xor_add<16>(a);
+      if (NSL <= 32) a = lane_xor_add<32>(a);
       if (lane < NSL) red[(wid * C0 + slot * EP + e) * TP + t] = a;
     }
   __syncthreads();

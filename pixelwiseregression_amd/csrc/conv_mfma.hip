@@ -955,11 +955,10 @@ __device__ __forceinline__ void wgrad_reduce_fast_body(const float* __restrict__
   }
 #pragma unroll
   for (int t = 0; t < TC; ++t) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      acc[t].x += __shfl_xor(acc[t].x, o, 64); acc[t].y += __shfl_xor(acc[t].y, o, 64);
-      acc[t].z += __shfl_xor(acc[t].z, o, 64); acc[t].w += __shfl_xor(acc[t].w, o, 64);
-    }
+    // (lane ^ 8, 16, 32 by DPP / v_permlane swaps, pwr_common.h: the sums of the __shfl_xor loop without its ds_bpermute_b32 round trips)
+    acc[t].x = lane_xor_add<8>(acc[t].x); acc[t].y = lane_xor_add<8>(acc[t].y); acc[t].z = lane_xor_add<8>(acc[t].z); acc[t].w = lane_xor_add<8>(acc[t].w);
+    acc[t].x = lane_xor_add<16>(acc[t].x); acc[t].y = lane_xor_add<16>(acc[t].y); acc[t].z = lane_xor_add<16>(acc[t].z); acc[t].w = lane_xor_add<16>(acc[t].w);
+    acc[t].x = lane_xor_add<32>(acc[t].x); acc[t].y = lane_xor_add<32>(acc[t].y); acc[t].z = lane_xor_add<32>(acc[t].z); acc[t].w = lane_xor_add<32>(acc[t].w);
     if ((threadIdx.x & 63) < 8) {
       float* q = tile + (wave * 32 + c4 * 4) * pitch + t;
       q[0] = acc[t].x; q[pitch] = acc[t].y; q[2 * pitch] = acc[t].z; q[3 * pitch] = acc[t].w;

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_pair_kernel(NormBwdPair q,
 // after the other in every one of the 1024 workgroups and lost 3.5 % of the step), added in norm_bwd_sum_body's order (k ascending), divided
 // by HW like there: S1, S2 and therefore dy are the same bits.  The parameter sums run on a side stream (norm_bwd_sum_kernel with
 // S1 = null) from the same slab, which therefore has to be the layer's own (the engine allocates one per norm).
-template <typename T>
+template <typename T, int NTL = 0>
 __device__ __forceinline__ void norm_bwd_apply_fold_body(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ state, int B,
                                                          const float* __restrict__ partial, int pchunks, const T* __restrict__ addend,
                                                          T* __restrict__ dy, int HW, int C, int nchunks, int relu, int chunk, int b) {
@@ -582,8 +582,9 @@ __device__ __forceinline__ void norm_bwd_apply_fold_body(const T* __restrict__ g
 #pragma unroll 4
   for (int pp = p0 + pj; pp < p1; pp += pl) {
     const size_t off = base + (size_t)pp * C + cq * EP;
-    V gv = *reinterpret_cast<const V*>(g + off);
-    V yv = *reinterpret_cast<const V*>(y + off);
+    // (NTL bits, debug build's PWR_FOLD_NT: 1 = g and y read non-temporally -- each is read once here --, 2 = dy stored non-temporally)
+    V gv = (NTL & 1) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(g + off)) : *reinterpret_cast<const V*>(g + off);
+    V yv = (NTL & 1) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(y + off)) : *reinterpret_cast<const V*>(y + off);
     V av = {};
     if (addend) av = *reinterpret_cast<const V*>(addend + off);
     V o;
@@ -597,15 +598,16 @@ __device__ __forceinline__ void norm_bwd_apply_fold_body(const T* __restrict__ g
       if (addend) r += Elem<T>::to_f(av[e]);
       o[e] = Elem<T>::from_f(r);
     }
-    *reinterpret_cast<V*>(dy + off) = o;
+    if (NTL & 2) __builtin_nontemporal_store(o, reinterpret_cast<V*>(dy + off));
+    else *reinterpret_cast<V*>(dy + off) = o;
   }
 }
 struct NormBwdFoldJob { const void* g; const void* y; const float* state; const float* partial; const void* addend; void* dy; };
 struct NormBwdFoldPair { NormBwdFoldJob j[2]; };
-template <typename T>
+template <typename T, int NTL = 0>
 __global__ __launch_bounds__(256) void norm_bwd_apply_fold_kernel(NormBwdFoldPair q, int B, int HW, int C, int nchunks, int pchunks, int relu) {
   const NormBwdFoldJob& j = q.j[blockIdx.z];
-  norm_bwd_apply_fold_body<T>((const T*)j.g, (const T*)j.y, j.state, B, j.partial, pchunks, (const T*)j.addend, (T*)j.dy, HW, C, nchunks, relu,
+  norm_bwd_apply_fold_body<T, NTL>((const T*)j.g, (const T*)j.y, j.state, B, j.partial, pchunks, (const T*)j.addend, (T*)j.dy, HW, C, nchunks, relu,
                               blockIdx.x, blockIdx.y);
 }
 
@@ -981,7 +983,10 @@ extern "C" int pwr_norm_bwd_apply_from_partial(const void* ga, const void* ya, c
   q.j[0] = NormBwdFoldJob{ga, ya, state_a, partial_a, addend_a, dya};
   q.j[1] = NormBwdFoldJob{gb, yb, state_b, partial_b, nullptr, dyb};
   const dim3 grid(nch, B, gb ? 2 : 1);
-  if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
+  static const int ntl = PWR_DBG_ENV("PWR_FOLD_NT", 0);
+  if (dtype == PWR_BF16 && ntl == 1) hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
+  else if (dtype == PWR_BF16 && ntl == 3) hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<bf16_t, 3>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
+  else if (dtype == PWR_BF16) hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
   else hipLaunchKernelGGL((norm_bwd_apply_fold_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, q, B, HW, C, nch, chunks, relu);
   return (int)hipGetLastError();
 }
