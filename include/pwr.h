@@ -102,7 +102,7 @@ int pwr_conv_fwd(const void* x, const void* wpack, const float* bias, const floa
  * Exactly one of st_partial ([B * chunks][3][Cout] fp32: shifted sum, shifted sum of squares, the tile's shift) /
  * nb_partial ([B * chunks][2][Cout]); chunks = pwr_conv_stats_chunks(...) > 0 (0: shape not supported -- use pwr_conv_fwd and
  * pwr_norm_stats / pwr_norm_bwd).  mode 1 (the data gradient of a stride-2 3x3 conv, model.py:182, H x W = the gradient's map): nb_partial
- * only; the four parity-class launches write one slab of 4 x (H / 4) x (W / 32) rows per sample. */
+ * only; the four parity classes (one launch) write one slab of 4 x (H / 4) x (W / 32) rows per sample. */
 int pwr_conv_stats_chunks(int H, int W, int Cin, int Cout, int ksize, int stride, int mode, int dtype);
 int pwr_conv_fwd_stats(const void* x, const void* wpack, const float* bias, const float* in_norm, int relu_in,
                        const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int mode,

@@ -1265,7 +1265,7 @@ extern "C" int pwr_conv_stats_chunks(int H, int W, int Cin, int Cout, int ksize,
   if (conv_params_fill(p, nullptr, nullptr, nullptr, nullptr, 0, nullptr, (void*)1, nullptr, 1, H, W, Cin, Cout, ksize, stride, mode, dtype)) return 0;
   static const bool on = (PWR_DBG_ENV("PWR_CONV_STATS", 1) != 0);
   if (!on) return 0;
-  // mode 1 (the data gradient of a stride-2 conv, H x W = the gradient's map): the four parity-class launches of the patch kernel write the
+  // mode 1 (the data gradient of a stride-2 conv, H x W = the gradient's map): the four parity classes of the patch kernel (one launch) write the
   // norm-backward sums of the tensor they produce (round 4; nb_partial only)
   if (mode == 1) return (pwr::conv_tr2_applicable(p, dtype) && PWR_DBG_ENV("PWR_TR2_STATS", 1)) ? pwr::conv_tr2_stats_chunks(p, dtype) : 0;
   if (mode != 0) return 0;

@@ -44,7 +44,8 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 // which for these memory-bound layers (the ResBlocks' bottleneck convs, the stage-input conv) meant ~2 TB/s.
 // GEO = 2 + 2 py + px: the data gradient of a STRIDE-2 3x3 conv for the output pixels of parity (py, px): dx[2a+py, 2c+px] reads
 // dy[a + oy, c + ox] for 1, 2, 2 or 4 taps (py = 0: ky = 1; py = 1: ky = 2 at oy = 0 and ky = 0 at oy = 1; same in x) -- a stride-1
-// patch conv over dy with a (1+py) x (1+px) window whose output is scattered to every second pixel.  Four launches (one per class)
+// patch conv over dy with a (1+py) x (1+px) window whose output is scattered to every second pixel.  Four classes (one launch since round 6:
+// conv3x3_patch_tr4_kernel; four launches before)
 // replace the gather form of the universal kernel (180 us isolated for the stem's 128 <- 128 layer at 128x128).
 // GEO = 6: the FORWARD of a stride-2 3x3 conv (the stem's last layer, model.py:182): y[oy, ox] reads x[2 oy + ky - 1, 2 ox + kx - 1], i.e.
 // tap (ky, kx) reads the input pixels of parity class (ky != 1, kx != 1), which form a stride-1 image of their own.  The workgroup walks
@@ -58,11 +59,25 @@ __device__ __forceinline__ void stamp(const ConvParams& p, int slot) {
 // DVFS give-back item 7: build both at the same tile, keep the faster by wall on random data).
 __host__ __device__ constexpr int s2_tap(int q) { return q == 0 ? 4 : q == 1 ? 3 : q == 2 ? 5 : q == 3 ? 1 : q == 4 ? 7 : q == 5 ? 0 : q == 6 ? 2 : q == 7 ? 6 : 8; }
 __host__ __device__ constexpr bool s2_first(int q) { return q == 0 || q == 1 || q == 3 || q == 5; }       // first tap position of a class
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32>
+// Patch + weight-ring (or epilogue image) bytes of one variant of the kernel: conv3x3_patch_body's own LDS array has this size; a kernel that
+// holds SEVERAL variants (conv3x3_patch_tr4_kernel) declares one array of the largest and hands it in (EXT)
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW, int GEO>
+__host__ __device__ constexpr int patch_lds_bytes() {
+  constexpr int EP = Mma<T>::EP, KE = Mma<T>::KE, NT = WM * WN * 64, BM = WM * MR * 32, BN = WN * NR * 32, TH = WM * MR;
+  constexpr int RH = TW == 32 ? TH : (TW * TW < BM ? TW : BM / TW), SUB = BM / (RH * TW);
+  constexpr bool TR = GEO >= 2 && GEO <= 5, S2 = GEO == 6;
+  constexpr int CPY = TR ? ((GEO - 2) >> 1) : 0, CPX = TR ? ((GEO - 2) & 1) : 0, HALO = GEO == 0 ? 1 : 0;
+  constexpr int PH = RH + (TR ? CPY : (S2 ? 1 : 2 * HALO)), PW = TW + (TR ? CPX : (S2 ? 1 : 2 * HALO));
+  constexpr int PATCH = SUB * PH * PW * ((CIN / EP) * 16 + 16), WB = BN * 64, EPI = 64 * (BN + 4) * 4;
+  constexpr int NSTAGE = DMA ? (GEO == 1 ? CIN / KE : 3) : 2;
+  (void)NT;
+  return (PATCH + NSTAGE * WB) > EPI ? (PATCH + NSTAGE * WB) : EPI;
+}
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32, bool EXT = false>
 #ifndef PWR_OCC_HINT
 #define PWR_OCC_HINT 1
 #endif
-__device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
+__device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p, char* ext_smem = nullptr) {
   typedef typename Vec16<T>::type V;
   static_assert(MF == 32 || (MF == 16 && sizeof(T) == 2 && DMA), "the 16x16x32 form exists for the bf16 LDS-DMA kernel");
   constexpr int MR4 = MR * 2, NR4 = NR * 2;     // 16-row / 16-column blocks of the wave tile (MF == 16)
@@ -103,7 +118,9 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p) {
   constexpr int EPI_BYTES = EROWS * EPITCH * 4;
   constexpr int NSTAGE = DMA ? (GEO == 1 ? KCH : 3) : 2;   // weight ring: LDS-DMA runs two K steps ahead (1x1: ALL <= 4 stages resident)
   constexpr int LDS_BYTES = (PATCH_BYTES + NSTAGE * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + NSTAGE * WBUF_BYTES) : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  static_assert(LDS_BYTES == patch_lds_bytes<T, CIN, WM, WN, MR, NR, DMA, TW, GEO>(), "patch_lds_bytes() out of step with the kernel body");
+  __shared__ __attribute__((aligned(16))) char smem_own[EXT ? 16 : LDS_BYTES];
+  char* smem = EXT ? ext_smem : smem_own;
   char* patch = smem;
   char* wbuf = smem + PATCH_BYTES;
 
@@ -728,6 +745,24 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
   conv3x3_patch_body<T, CIN, WM, WN, MR, NR, DMA, TW, GEO, MF>(blockIdx.z ? g.b : g.a);
 }
 
+// The four parity classes of a stride-2 data gradient (GEO 2 .. 5) in ONE launch: blockIdx.z = 0 .. 3 runs the class with 4, 2, 2, 1 taps --
+// the order the four launches had -- into its own rows of the norm-backward slab.  Same code per class, so the same bits; three launch
+// boundaries and three ragged launch ends less, and the one-tap class's workgroups (memory-bound) run beside the four-tap class's.
+template <typename T, int WM, int WN, int MR, int NR, int MF>
+__global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && WM * WN == 4) ? 2 : 1) void conv3x3_patch_tr4_kernel(ConvParams p) {
+  constexpr int L5 = patch_lds_bytes<T, 128, WM, WN, MR, NR, true, 32, 5>();      // (the four-tap class has the largest patch)
+  static_assert(L5 >= patch_lds_bytes<T, 128, WM, WN, MR, NR, true, 32, 4>() && L5 >= patch_lds_bytes<T, 128, WM, WN, MR, NR, true, 32, 3>() &&
+                L5 >= patch_lds_bytes<T, 128, WM, WN, MR, NR, true, 32, 2>(), "class (1, 1) has the largest LDS footprint");
+  __shared__ __attribute__((aligned(16))) char smem[L5];
+  const int tiles = (p.H / 4) * (p.W / 32);
+  switch (blockIdx.z) {
+    case 0: p.st_chunk0 = 3 * tiles; conv3x3_patch_body<T, 128, WM, WN, MR, NR, true, 32, 5, MF, true>(p, smem); break;
+    case 1: p.st_chunk0 = 2 * tiles; conv3x3_patch_body<T, 128, WM, WN, MR, NR, true, 32, 4, MF, true>(p, smem); break;
+    case 2: p.st_chunk0 = 1 * tiles; conv3x3_patch_body<T, 128, WM, WN, MR, NR, true, 32, 3, MF, true>(p, smem); break;
+    default: p.st_chunk0 = 0; conv3x3_patch_body<T, 128, WM, WN, MR, NR, true, 32, 2, MF, true>(p, smem); break;
+  }
+}
+
 // small square maps of the inner hourglass levels (64 -> 64 channels): whole images per tile
 static bool small_map(const ConvParams& p, int dtype) {
   static const bool on = (PWR_DBG_ENV("PWR_PATCH_SMALL", 1) != 0);
@@ -857,7 +892,8 @@ static int launch_patch_1x1(const ConvParams& p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-// data gradient of a stride-2 3x3 conv (ConvParams::mode 1: x = dy [B,H,W,Cin], output [B,2H,2W,Cout]) as four parity-class launches
+// data gradient of a stride-2 3x3 conv (ConvParams::mode 1: x = dy [B,H,W,Cin], output [B,2H,2W,Cout]) as four parity classes -- ONE launch
+// (conv3x3_patch_tr4_kernel, round 6; PWR_TR2_ONE=0 in the debug build: the four launches of rounds 3 - 5, same bits)
 int conv_tr2_stats_chunks(const ConvParams& p, int dtype);
 bool conv_tr2_applicable(const ConvParams& p, int dtype) {
   static const bool on = (PWR_DBG_ENV("PWR_PATCH_TR2", 1) != 0);
@@ -891,6 +927,17 @@ int launch_conv_tr2(const ConvParams& p0, hipStream_t s) {
   p.stamps = nullptr;
   const int tiles = (p.H / 4) * (p.W / 32);
   p.st_nchunks = 4 * tiles;      // (norm-backward sums: one slab, class c at rows c * tiles ... of every sample)
+  static const bool one = PWR_DBG_ENV("PWR_TR2_ONE", 1) != 0;
+  if (one) {
+    const int bn = pick_bn(p.Cout);
+    dim3 grid(p.B * tiles, p.CoutPad / bn, 4), block(256);
+    static const bool mf16 = PWR_DBG_ENV("PWR_TR2_MF16", 1) != 0;
+    if (bn == 128 && mf16 && !p.residual && p.Cout % 128 == 0) hipLaunchKernelGGL((conv3x3_patch_tr4_kernel<bf16_t, 2, 2, 2, 2, 16>), grid, block, 0, s, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv3x3_patch_tr4_kernel<bf16_t, 2, 2, 2, 2, 32>), grid, block, 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv3x3_patch_tr4_kernel<bf16_t, 2, 2, 2, 1, 32>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_patch_tr4_kernel<bf16_t, 4, 1, 1, 1, 32>), grid, block, 0, s, p);
+    return (int)hipGetLastError();
+  }
   p.st_chunk0 = 3 * tiles; launch_tr2_class<5>(p, s);     // (the four-tap class first: the longest)
   p.st_chunk0 = 2 * tiles; launch_tr2_class<4>(p, s);
   p.st_chunk0 = 1 * tiles; launch_tr2_class<3>(p, s);

@@ -907,7 +907,7 @@ def test_norm_backward_pair_launch(B, H, W, C):
 
 @pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 8, 64), (2, 64, 64)])
 def test_stride2_dgrad_norm_backward_sums(B, H, W):
-    """The data gradient of the stride-2 3x3 conv (four parity-class launches) + the norm-backward sums of the tensor it produces from
+    """The data gradient of the stride-2 3x3 conv (four parity classes in one launch) + the norm-backward sums of the tensor it produces from
     the class launches' epilogues (one slab, 4 x tiles rows per sample) == the same data gradient, then the three-launch norm backward."""
     from pixelwiseregression_amd import kernels as K
     C, dtype = 128, torch.bfloat16

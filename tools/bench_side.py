@@ -1,7 +1,8 @@
 """Isolated timing of the parameter-gradient (side-stream) layers and the stem's data gradients at the BASELINE C2 shapes, each at the
 engine's split count (HIP events, interleaved rounds):   python tools/bench_side.py [which = all] [iters = 20] [--debug-lib]
 `which`: comma list of s2 (stride-2 stem conv), last (heads' 128 -> J conv), stem (64 -> 128 and 32 -> 64 at 128 x 128), pw (the 1x1
-convs of the 64 x 64 ResBlock and the stage input conv), dg (the stem's data gradients)."""
+convs of the 64 x 64 ResBlock and the stage input conv), dg (the stem's data gradients), s2dg (the stride-2 conv's data gradient with
+the norm-backward sums, as the stem's backward runs it; the time includes the wrapper's two allocations + NaN fill)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if "--debug-lib" in sys.argv:
@@ -68,3 +69,12 @@ if which & {"all", "dg"}:
         ts = [timeit(lambda: K.conv_fwd(x, pack, Cout, 3, 1)) for _ in range(3)]
         fl = 2.0 * B * H * H * Cin * Cout * 9
         print(json.dumps({"layer": tag, "us": [round(t, 1) for t in ts], "TFLOPs": round(fl / min(ts) / 1e6, 1)}), flush=True)
+if which & {"all", "s2dg"}:
+    dy, y = act(64, 128), act(128, 128)
+    w = torch.randn(128, 128, 3, 3, device=dev) * 0.03
+    pack = K.pack_conv(w, 2, K.BF16)
+    st = K.norm_stats(y, torch.ones(128, device=dev), torch.zeros(128, device=dev), mode=0)
+    ts = [timeit(lambda: K.conv_fwd_stats(dy, pack, 128, 3, 1, mode=1, nb_y=y, nb_state=st)) for _ in range(3)]
+    fl = 2.0 * B * 64 * 64 * 128 * 128 * 9
+    print(json.dumps({"layer": "stem stride-2 data gradient 128 <- 128, 64x64 -> 128x128 (+ norm-backward sums)", "us": [round(t, 1) for t in ts],
+                      "TFLOPs": round(fl / min(ts) / 1e6, 1), "switches": {k: v for k, v in os.environ.items() if k.startswith("PWR_TR2")}}), flush=True)
