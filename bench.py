@@ -450,6 +450,21 @@ def main():
             model(batch["img"], batch["label_img"], batch["mask"])
         torch.cuda.synchronize()
         dt_inf = (time.perf_counter() - t1) / n_inf
+        # the same loop with two batches in flight on two streams (serving.py: two plans of the same weights); reported BESIDE the figure above
+        dt_inf2 = None
+        if world == 1 and native:
+            from pixelwiseregression_amd.serving import StreamedInference
+            srv = StreamedInference(model, streams=2)
+            feed = lambda n: ((batch["img"], batch["label_img"], batch["mask"]) for _ in range(n))
+            for _ in srv.run(feed(6)):
+                pass
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in srv.run(feed(2 * n_inf)):
+                pass
+            torch.cuda.synchronize()
+            dt_inf2 = (time.perf_counter() - t1) / (2 * n_inf)
+            del srv
 
     if rank == 0:
         out = {
@@ -466,6 +481,7 @@ def main():
                        "harness": args.harness,
                        "parallelism": "dp%d" % world if use_dist else "single"},
             "infer_frames_per_s": world * B_PER_GPU / dt_inf,
+            "infer_frames_per_s_two_streams": (B_PER_GPU / dt_inf2) if dt_inf2 else None,
             "final_loss": final_loss,
         }
         if use_dist:

@@ -1533,7 +1533,10 @@ extern "C" int pwr_engine_forward(void* h, const float* img, const float* label,
       }
     }
     // hand-off counters of the fused norm kernels live at the head of the partial scratch: zero once per call
-    if (e->need_partial) hipMemsetAsync(c.arena + e->scr_partial, 0, 8192 < e->need_partial ? 8192 : e->need_partial, (hipStream_t)st);
+    // (only the hand-off form of the statistics kernel reads them -- debug build's PWR_NORM_FUSE; the product's forward issued this fill,
+    // a 5-us launch at the head of every pass, for nobody until round 6)
+    static const bool handoff_counters = PWR_DBG_ENV("PWR_NORM_FUSE", 0) != 0;
+    if (handoff_counters && e->need_partial) hipMemsetAsync(c.arena + e->scr_partial, 0, 8192 < e->need_partial ? 8192 : e->need_partial, (hipStream_t)st);
     for (size_t i = 0; i < e->fwd.size(); ++i) {
       if (pack_wait && i == e->fwd_first_pack_op) { hipStreamWaitEvent((hipStream_t)st, e->ev_pack, 0); pack_wait = false; }
 #ifdef PWR_DEBUG_BUILD

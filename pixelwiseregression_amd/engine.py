@@ -114,7 +114,12 @@ def _run_forward(model, plan, img, label_img, mask):
     # through the per-parameter views (optimizers, load_state_dict) do not bump the flat buffer's version counter,
     # so there is no cheap, reliable "unchanged" test -- and a stale pack would be silently wrong.
     # (round 6: the pack is issued INSIDE the forward call, on a side stream beside the stem's first conv)
-    _lib.check(l.pwr_engine_pack_beside_forward(plan.h), "pwr_engine_pack_beside_forward")
+    # The one exception: a module whose owner PROMISED that its parameters stand still (model.freeze_weight_packs(), taken by
+    # serving.StreamedInference for its private replicas): a no-grad plan then packs once per promise.
+    epoch = getattr(model, "_pack_epoch", None)
+    if plan.need_grad or epoch is None or plan.packed_version != epoch:
+        _lib.check(l.pwr_engine_pack_beside_forward(plan.h), "pwr_engine_pack_beside_forward")
+        plan.packed_version = epoch
     outs = []
     for _ in range(model.stage):
         outs += [torch.empty(B, J, P, P, device=dev, dtype=torch.float32), torch.empty(B, J, P, P, device=dev, dtype=torch.float32),
