@@ -281,7 +281,7 @@ class PixelwiseRegression(nn.Module):
     def freeze_weight_packs(self, on=True):
         """A promise by the owner that the parameters do not change from here on (until the next call): forwards without gradient then
         re-pack the conv weights (fp32 -> the kernels' bf16 / fp32 fragment order, one launch of ~28 us) once instead of on every call.
-        Every call -- True again after the weights were replaced, or False -- ends the previous promise.  Training forwards always re-pack."""
+        Every call -- True again after the weights were replaced, or False -- ends the previous promise.  Forwards that keep a graph (a plan with gradients) always re-pack."""
         self._pack_count = getattr(self, "_pack_count", 0) + 1
         self._pack_epoch = self._pack_count if on else None
         return self
