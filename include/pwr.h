@@ -34,7 +34,7 @@ extern "C" {
 #define PWR_HEATMAP_SUM 1     /* model.py:86-90 */
 
 /* ABI version of this header; pwr_abi_version() must return the same number. */
-#define PWR_ABI_VERSION 6   /* 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply, pwr_norm_stats_fused_src, pwr_nchw_to_nhwc_pad_pair; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
+#define PWR_ABI_VERSION 7   /* 7 (round 6): pwr_conv_dgrad_fold_stats_pair; 6 (round 6): pwr_norm_bwd_apply_from_partial, pwr_norm_bwd_params_from_partial, pwr_norm_bwd_params_group, pwr_norm_finalize_partial_pair, pwr_engine_pack_beside_forward, pwr_norm_apply, pwr_norm_stats_fused_src, pwr_nchw_to_nhwc_pad_pair; 5 (round 5): pwr_conv_fwd_nchw_pair, the order field of the pack records and the tag bit of a fragment-order pack; 4 (round 4): pwr_conv_dgrad_stats_pair, pwr_conv_wgrad_pair, pwr_engine_wait_segment, pwr_resblock_bwd_small_x, pwr_norm_bwd_from_partial_pair, pwr_conv_fwd_stats mode 1; 3 (round 3): experiment entry points removed, debugging aids moved to pwr_debug.h */
 int pwr_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -129,6 +129,18 @@ int pwr_conv_fwd_nchw_pair(const void* xa, const void* wa, const float* bias_a, 
 int pwr_conv_dgrad_stats_pair(const void* dya, const void* wa, void* dxa, const void* nb_y_a, const float* nb_state_a, float* nb_partial_a,
                               const void* dyb, const void* wb, void* dxb, const void* nb_y_b, const float* nb_state_b, float* nb_partial_b,
                               int nb_relu, int B, int H, int W, int Cin, int Cout, int ksize, int dtype, void* stream);
+
+/* pwr_conv_dgrad_stats_pair with the norm backward of the layer ABOVE folded into its staging (round 6): g_* are the RAW gradients
+ * dL/d relu(norm(fb_y_*)) that the data gradient above wrote, fb_partial_* its norm-backward sums (fb_pchunks slab rows of [2][Cin] per
+ * sample), fb_state_* the norm's state [4][B][Cin].  The launch computes dy = pwr_norm_bwd_apply_from_partial's result on the way into LDS
+ * (same bits), convolves it, and writes it to fb_dy_* (the weight gradients' operand; must not alias g_*).  bf16, 3x3, Cin = Cout = 128,
+ * H % 4 == 0, W % 32 == 0; PWR_EUNSUPPORTED otherwise: call pwr_norm_bwd_apply_from_partial + pwr_conv_dgrad_stats_pair. */
+int pwr_conv_dgrad_fold_stats_pair(const void* ga, const void* wa, void* dxa, const void* nb_y_a, const float* nb_state_a, float* nb_partial_a,
+                                   const void* fb_y_a, const float* fb_state_a, const float* fb_partial_a, void* fb_dy_a,
+                                   const void* gb, const void* wb, void* dxb, const void* nb_y_b, const float* nb_state_b, float* nb_partial_b,
+                                   const void* fb_y_b, const float* fb_state_b, const float* fb_partial_b, void* fb_dy_b,
+                                   int fb_pchunks, int fb_relu, int nb_relu, int B, int H, int W, int Cin, int Cout, int ksize, int dtype,
+                                   void* stream);
 
 size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits);
 /* dw[cout_real][cin_real][k][k] (+)= sum_{b,pixels} dy * NR(x)  (OIHW fp32, the layout of the nn.Parameter gradient).

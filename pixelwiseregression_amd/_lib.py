@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpwr_hip.so")     # the one product library (tools/dbglib.py swaps in the debug build for measurements)
-ABI_VERSION = 6
+ABI_VERSION = 7
 _HEADERS = ["pwr.h"]
 
 _lib = None

@@ -33,6 +33,15 @@ struct ConvParams {
   // image of this launch.  The four parity-class launches of a stride-2 data gradient (conv_patch.hip, GEO 2 - 5) write one slab between
   // them: 4 x tiles rows per sample, class c at rows c * tiles ...
   int st_nchunks = 0, st_chunk0 = 0;
+  // FOLD (round 6, conv_patch.hip's FB forms): x is the RAW gradient g = dL/d relu(norm(fb_y)).  The staging computes the norm backward's
+  // dy from g, fb_y, fb_state ([4][B][Cin]) and the sums of fb_partial (fb_pchunks slab rows of [2][Cin] per sample) on the way into LDS --
+  // the values pwr_norm_bwd_apply_from_partial would have written, bit for bit -- and stores the tile's own pixels of it to fb_dy (the
+  // weight gradient's operand): the apply launch between two data gradients is gone.
+  const void* fb_y = nullptr;
+  const float* fb_state = nullptr;
+  const float* fb_partial = nullptr;
+  void* fb_dy = nullptr;
+  int fb_pchunks = 0, fb_relu = 1;
   int epi16 = 1;            // (debug build: 0 = the two-pass fp32 epilogue also for the 16x16x32 tile)
   int w_frag = 0;           // the pack is in conv_wstat.hip's fragment order (PackDesc::order 1; the caller passed the pack address with bit 0 set)
 };

@@ -1343,6 +1343,31 @@ extern "C" int pwr_conv_dgrad_stats_pair(const void* dya, const void* wa, void* 
   return pwr::launch_conv_patch_pair(a, b, (hipStream_t)stream);
 }
 
+// pwr_conv_dgrad_stats_pair whose inputs are the RAW gradients g = dL/d relu(norm(fb_y)) of the layer above: the norm backward that stood
+// between two data gradients (pwr_norm_bwd_apply_from_partial) runs in this launch's staging, from the slab the data gradient above wrote
+// (ConvParams::fb_*; conv_patch.hip, FB).  fb_dy_* receive the dy that launch would have written (the weight gradients' operand).
+extern "C" int pwr_conv_dgrad_fold_stats_pair(const void* ga, const void* wa, void* dxa, const void* nb_y_a, const float* nb_state_a, float* nb_partial_a,
+                                              const void* fb_y_a, const float* fb_state_a, const float* fb_partial_a, void* fb_dy_a,
+                                              const void* gb, const void* wb, void* dxb, const void* nb_y_b, const float* nb_state_b, float* nb_partial_b,
+                                              const void* fb_y_b, const float* fb_state_b, const float* fb_partial_b, void* fb_dy_b,
+                                              int fb_pchunks, int fb_relu, int nb_relu, int B, int H, int W, int Cin, int Cout, int ksize, int dtype,
+                                              void* stream) {
+  pwr::ConvParams a, b;
+  int rc = conv_params_fill(a, ga, wa, nullptr, nullptr, 0, nullptr, dxa, nullptr, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  rc = conv_params_fill(b, gb, wb, nullptr, nullptr, 0, nullptr, dxb, nullptr, B, H, W, Cin, Cout, ksize, 1, 0, dtype);
+  if (rc) return rc;
+  if (!nb_partial_a || !nb_partial_b || !dxa || !dxb || !nb_y_a || !nb_y_b || !nb_state_a || !nb_state_b) return PWR_EINVAL;
+  if (!fb_y_a || !fb_y_b || !fb_state_a || !fb_state_b || !fb_partial_a || !fb_partial_b || !fb_dy_a || !fb_dy_b || fb_pchunks < 1) return PWR_EINVAL;
+  if (fb_dy_a == ga || fb_dy_b == gb) return PWR_EINVAL;       // (a tile's halo reads its neighbours' RAW pixels: dy cannot replace g in place)
+  if (dtype != PWR_BF16 || Cin != 128 || ksize != 3 || !pwr::conv_patch_pair_applicable(a, b, dtype)) return PWR_EUNSUPPORTED;
+  a.nb_y = nb_y_a; a.nb_state = nb_state_a; a.nb_partial = nb_partial_a; a.nb_relu = nb_relu;
+  b.nb_y = nb_y_b; b.nb_state = nb_state_b; b.nb_partial = nb_partial_b; b.nb_relu = nb_relu;
+  a.fb_y = fb_y_a; a.fb_state = fb_state_a; a.fb_partial = fb_partial_a; a.fb_dy = fb_dy_a; a.fb_pchunks = fb_pchunks; a.fb_relu = fb_relu;
+  b.fb_y = fb_y_b; b.fb_state = fb_state_b; b.fb_partial = fb_partial_b; b.fb_dy = fb_dy_b; b.fb_pchunks = fb_pchunks; b.fb_relu = fb_relu;
+  return pwr::launch_conv_patch_pair(a, b, (hipStream_t)stream);
+}
+
 extern "C" size_t pwr_conv_wgrad_slab_bytes(int cout, int cin, int ksize, int splits) {
   const int cinpad = (cin + 127) / 128 * 128;
   return (size_t)splits * ksize * ksize * cinpad * pwr_conv_out_pad(cout) * sizeof(float);

@@ -61,7 +61,7 @@ __host__ __device__ constexpr int s2_tap(int q) { return q == 0 ? 4 : q == 1 ? 3
 __host__ __device__ constexpr bool s2_first(int q) { return q == 0 || q == 1 || q == 3 || q == 5; }       // first tap position of a class
 // Patch + weight-ring (or epilogue image) bytes of one variant of the kernel: conv3x3_patch_body's own LDS array has this size; a kernel that
 // holds SEVERAL variants (conv3x3_patch_tr4_kernel) declares one array of the largest and hands it in (EXT)
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW, int GEO>
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW, int GEO, bool FB = false>
 __host__ __device__ constexpr int patch_lds_bytes() {
   constexpr int EP = Mma<T>::EP, KE = Mma<T>::KE, NT = WM * WN * 64, BM = WM * MR * 32, BN = WN * NR * 32, TH = WM * MR;
   constexpr int RH = TW == 32 ? TH : (TW * TW < BM ? TW : BM / TW), SUB = BM / (RH * TW);
@@ -71,9 +71,9 @@ __host__ __device__ constexpr int patch_lds_bytes() {
   constexpr int PATCH = SUB * PH * PW * ((CIN / EP) * 16 + 16), WB = BN * 64, EPI = 64 * (BN + 4) * 4;
   constexpr int NSTAGE = DMA ? (GEO == 1 ? CIN / KE : 3) : 2;
   (void)NT;
-  return (PATCH + NSTAGE * WB) > EPI ? (PATCH + NSTAGE * WB) : EPI;
+  return ((PATCH + NSTAGE * WB) > EPI ? (PATCH + NSTAGE * WB) : EPI) + (FB ? 2 * CIN * 4 : 0);     // (FB: the 2 Cin sums of the fold behind everything)
 }
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32, bool EXT = false>
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32, bool EXT = false, bool FB = false>
 #ifndef PWR_OCC_HINT
 #define PWR_OCC_HINT 1
 #endif
@@ -117,8 +117,10 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p, char* ex
   constexpr int EROWS = 64, EPITCH = BN + 4;
   constexpr int EPI_BYTES = EROWS * EPITCH * 4;
   constexpr int NSTAGE = DMA ? (GEO == 1 ? KCH : 3) : 2;   // weight ring: LDS-DMA runs two K steps ahead (1x1: ALL <= 4 stages resident)
-  constexpr int LDS_BYTES = (PATCH_BYTES + NSTAGE * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + NSTAGE * WBUF_BYTES) : EPI_BYTES;
-  static_assert(LDS_BYTES == patch_lds_bytes<T, CIN, WM, WN, MR, NR, DMA, TW, GEO>(), "patch_lds_bytes() out of step with the kernel body");
+  constexpr int LDS_MAIN = (PATCH_BYTES + NSTAGE * WBUF_BYTES) > EPI_BYTES ? (PATCH_BYTES + NSTAGE * WBUF_BYTES) : EPI_BYTES;
+  constexpr int LDS_BYTES = LDS_MAIN + (FB ? 2 * CIN * 4 : 0);
+  static_assert(LDS_BYTES == patch_lds_bytes<T, CIN, WM, WN, MR, NR, DMA, TW, GEO, FB>(), "patch_lds_bytes() out of step with the kernel body");
+  static_assert(!FB || (GEO == 0 && TW == 32 && sizeof(T) == 2 && NT == 2 * CIN), "the fold form: bf16 3x3 stride-1 tiles, one thread per sum");
   __shared__ __attribute__((aligned(16))) char smem_own[EXT ? 16 : LDS_BYTES];
   char* smem = EXT ? ext_smem : smem_own;
   char* patch = smem;
@@ -268,7 +270,86 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvParams& p, char* ex
       }
     }
   };
-  stage_patch(0);
+  // FB: the norm backward of the tensor this conv's input gradient belongs to, applied while the patch is staged (ConvParams::fb_*).
+  // norm_bwd_apply_fold_body's arithmetic in its order: every thread sums one of the 2 Cin slab columns of the sample (all loads in flight,
+  // k ascending, / HW), the sums cross LDS, then dy = scale * (g m - S1 - xhat S2) per element.  The tile's own 4 x 32 pixels of dy go out
+  // to fb_dy (each pixel is the interior of exactly one tile); halo pixels are computed again by the neighbour, out-of-image ones are zero.
+  auto stage_patch_fold = [&]() {
+    float* ssum = reinterpret_cast<float*>(smem + LDS_MAIN);
+    const T* __restrict__ fy = reinterpret_cast<const T*>(p.fb_y) + (size_t)sb * HW * CIN;
+    T* __restrict__ fdy = reinterpret_cast<T*>(p.fb_dy) + (size_t)sb * HW * CIN;
+    float sacc = 0.f;
+    {
+      const int qq = tid >= CIN ? 1 : 0, c = tid - qq * CIN;
+      const float* pp = p.fb_partial + ((size_t)sb * p.fb_pchunks * 2 + qq) * CIN + c;
+      const size_t st = (size_t)2 * CIN;
+      int k = 0;
+      for (; k + 32 <= p.fb_pchunks; k += 32) {
+        float a[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) a[u] = pp[(size_t)(k + u) * st];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) sacc += a[u];
+      }
+      for (; k + 8 <= p.fb_pchunks; k += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = pp[(size_t)(k + u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += a[u];
+      }
+      for (; k < p.fb_pchunks; ++k) sacc += pp[(size_t)k * st];
+    }
+    float mu[EP], rs[EP], sc[EP], sh[EP];
+    {
+      const size_t plane = (size_t)p.B * CIN;
+      const float* st = p.fb_state + (size_t)sb * CIN + st_slot * EP;
+#pragma unroll
+      for (int e = 0; e < EP; ++e) { mu[e] = st[e]; rs[e] = st[plane + e]; sc[e] = st[2 * plane + e]; sh[e] = st[3 * plane + e]; }
+    }
+    V gv[NITP], yv[NITP];
+    bool ok[NITP];
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) {
+      const int pix = st_pl + k * PL;
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = sy0 + py - HALO, ix = sx0 + px - HALO;
+      ok[k] = pix < PP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+      const size_t o = ((size_t)cy * p.W + cx) * CIN + st_slot * EP;
+      gv[k] = *reinterpret_cast<const V*>(xs + o);
+      yv[k] = *reinterpret_cast<const V*>(fy + o);
+    }
+    ssum[tid] = sacc / (float)HW;
+    __syncthreads();
+    float s1[EP], s2[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { s1[e] = ssum[st_slot * EP + e]; s2[e] = ssum[CIN + st_slot * EP + e]; }
+    const bool writer = blockIdx.y == 0;
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) {
+      const int pix = st_pl + k * PL;
+      if (pix < PP) {
+        const int py = pix / PW, px = pix - py * PW;
+        V o;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+          const float yy = Elem<T>::to_f(yv[k][e]);
+          float gg = Elem<T>::to_f(gv[k][e]);
+          if (p.fb_relu && !(fmaf(yy - mu[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
+          const float xn = (yy - mu[e]) * rs[e];
+          const float r = sc[e] * (gg - s1[e] - xn * s2[e]);     // (norm_bwd_apply_body's expression)
+          o[e] = Elem<T>::from_f(r);
+        }
+        if (!ok[k]) o = V{};
+        *reinterpret_cast<V*>(patch + pix * PITCH + st_slot * 16) = o;
+        if (writer && py >= HALO && py < HALO + RH && px >= HALO && px < HALO + TW)
+          *reinterpret_cast<V*>(fdy + ((size_t)(sy0 + py - HALO) * p.W + sx0 + px - HALO) * CIN + st_slot * EP) = o;
+      }
+    }
+  };
+  if constexpr (FB) stage_patch_fold();
+  else stage_patch(0);
   if constexpr (!DMA) store_w(0);
   stamp(p, 1);
   __syncthreads();     // (drains the two DMA stages in flight as well)
@@ -740,9 +821,9 @@ __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM
 // same three 128 -> 128 convs on different tensors (model.py:54-65 / :103-114), and a launch boundary between two full-chip launches of
 // this kernel costs 8 - 9 us (tools/launch_bubble.py: 2 x B = 32 takes 85.5 us, 1 x B = 64 takes 76.4 us).
 struct ConvPair { ConvParams a, b; };
-template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32>
+template <typename T, int CIN, int WM, int WN, int MR, int NR, bool DMA, int TW = 32, int GEO = 0, int MF = 32, bool FB = false>
 __global__ __launch_bounds__(WM * WN * 64, (PWR_OCC_HINT && sizeof(T) == 2 && WM * WN == 4) ? 2 : 1) void conv3x3_patch_pair_kernel(ConvPair g) {
-  conv3x3_patch_body<T, CIN, WM, WN, MR, NR, DMA, TW, GEO, MF>(blockIdx.z ? g.b : g.a);
+  conv3x3_patch_body<T, CIN, WM, WN, MR, NR, DMA, TW, GEO, MF, false, FB>(blockIdx.z ? g.b : g.a);
 }
 
 // The four parity classes of a stride-2 data gradient (GEO 2 .. 5) in ONE launch: blockIdx.z = 0 .. 3 runs the class with 4, 2, 2, 1 taps --
@@ -975,13 +1056,19 @@ bool conv_patch_pair_applicable(const ConvParams& a, const ConvParams& b, int dt
   return on && ok(a) && ok(b) && a.B == b.B && a.H == b.H && a.W == b.W && a.Cin == b.Cin && PWR_DBG_ENV("PWR_PATCH_MF16", 1) == 1 && PWR_DBG_ENV("PWR_PATCH_BIG", 0) == 0;
 }
 int launch_conv_patch_pair(const ConvParams& a, const ConvParams& b, hipStream_t s) {
-  if (conv_wstat_pair_applicable(a, b, PWR_BF16)) return launch_conv_wstat(a, &b, s);
+  if (!a.fb_y && !b.fb_y && conv_wstat_pair_applicable(a, b, PWR_BF16)) return launch_conv_wstat(a, &b, s);
   if (a.w_frag || b.w_frag) return PWR_EINVAL;       // a fragment-order pack and a launch that is not conv_wstat.hip's
   ConvPair g{a, b};
   g.a.epi16 = g.b.epi16 = 1;
   g.a.stamps = g.b.stamps = nullptr;
   g.a.dbg_delay = g.b.dbg_delay = PWR_DBG_ENV("PWR_PAIR_DELAY", 0);
   dim3 grid(a.B * (a.H / 4) * (a.W / 32), a.CoutPad / 128, 2), block(256);
+  if ((a.fb_y != nullptr) != (b.fb_y != nullptr)) return PWR_EINVAL;
+  if (a.fb_y) {        // the fold form exists for the heads' shape only
+    if (a.Cin != 128 || !a.fb_state || !a.fb_partial || !a.fb_dy || !b.fb_state || !b.fb_partial || !b.fb_dy || a.fb_pchunks < 1 || a.in_norm || b.in_norm) return PWR_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, 0, 16, true>), grid, block, 0, s, g);
+    return (int)hipGetLastError();
+  }
   if (a.Cin == 128) hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 128, 2, 2, 2, 2, true, 32, 0, 16>), grid, block, 0, s, g);
   else if (a.Cin == 64) hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 64, 2, 2, 2, 2, true>), grid, block, 0, s, g);
   else hipLaunchKernelGGL((conv3x3_patch_pair_kernel<bf16_t, 32, 2, 2, 2, 2, true>), grid, block, 0, s, g);

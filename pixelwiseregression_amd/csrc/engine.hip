@@ -1060,6 +1060,13 @@ struct Engine {
     want_slab(pwr_conv_wgrad_slab_bytes(Jp, F, ks, splits3));
     want_slab((size_t)B * J * 4);
     const bool wpair = PWR_DBG_ENV("PWR_HEAD_WGRAD_PAIR", 0) != 0;      // weight gradients of the two heads in one launch (measured: no gain)
+    // round 6: the norm backward between two paired data gradients (h3 / n2 and h2 / n1) runs in the staging of the data gradient BELOW it
+    // (pwr_conv_dgrad_fold_stats_pair): the apply launch leaves the chain, the dy it would have written goes to a buffer of its own
+    // (gdy: a tile's halo reads its neighbours' RAW pixels, so dy cannot replace g in place) which the weight gradients read
+    const bool fdg = fold && PWR_DBG_ENV("PWR_HEAD_FOLD_DGRAD", 1) != 0;
+    size_t gdy[2][2] = {{0, 0}, {0, 0}};       // [level q][head]: dy of h3 (q = 0) / h2 (q = 1)
+    for (int q = 0; q < 2 && fdg; ++q)
+      for (int k = 0; k < 2; ++k) gdy[q][k] = alloc((size_t)B * P * P * F * esz, "gdy");
     // round 6: the norm-fed layers' operand materialised once (see below).  Measured: bit-identical and 0.04 ms per step SLOWER (5.196 / 5.235
     // against 5.161 / 5.186 ms, interleaved): the extra 67 MB of traffic per layer beside the chain costs what the loader's arithmetic did.  Off.
     const bool napply = PWR_DBG_ENV("PWR_HEAD_NAPPLY", 0) != 0;
@@ -1113,19 +1120,27 @@ struct Engine {
       return pwr_conv_fwd_stats(c.arena + D_.gT, c.packs + D_.c3.pack_d, nullptr, nullptr, 0, nullptr, c.arena + D_.h3.goff, Bc, Pc, Pc, Jp, Fc, kk, 1, 0,
                                 nullptr, c.arena + D_.h3.off, (float*)(c.arena + D_.n2.state), pb, 1, dt, c.stream);
     });
-    norm_bwd_pair(hp.h3, hp.n2, hd.h3, hd.n2, ch, half, own[0]);
+    if (!fdg) norm_bwd_pair(hp.h3, hp.n2, hd.h3, hd.n2, ch, half, own[0]);
+    else {       // (its parameter sums still come from the slab: the segment's grouped launch)
+      seg_norm_jobs.push_back(NormJob{own[0], false, hp.n2.gamma, hp.n2.beta, P * P, F, ch});
+      seg_norm_jobs.push_back(NormJob{own[0] + half, false, hd.n2.gamma, hd.n2.beta, P * P, F, ch});
+    }
     // ---- conv depth 2, 1: (x, its norm, conv, y) per head
     struct Lvl { Tn xp, xd, yp, yd; NormL np, nd; ConvL cp, cd; };
     const Lvl lv[2] = {{hp.h2, hd.h2, hp.h3, hd.h3, hp.n1, hd.n1, hp.c2, hd.c2}, {hp.h1, hd.h1, hp.h2, hd.h2, hp.n0, hd.n0, hp.c1, hd.c1}};
     for (int q = 0; q < 2; ++q) {
       const Lvl L = lv[q];
       const size_t ownq = own[q + 1];
+      // y's gradient as the weight gradient reads it (dy), and -- folded form -- y's norm (the one ABOVE this conv) with its slab
+      const size_t dyp = fdg ? gdy[q][0] : L.yp.goff, dyd = fdg ? gdy[q][1] : L.yd.goff;
+      const NormL nyp = q == 0 ? hp.n2 : hp.n1, nyd = q == 0 ? hd.n2 : hd.n1;
+      const size_t own_above = own[q];
       bwd_cur.push_back([=](Ctx& c) {
-        int rc = run_on_side(c, [=](Ctx& c2) {
+        auto wgrads = [=](Ctx& c) { return run_on_side(c, [=](Ctx& c2) {
           float* slab = (float*)(c2.arena + E->scr_slab + c2.slab_off);
           int r2 = !wpair ? PWR_EUNSUPPORTED
-                          : pwr_conv_wgrad_pair(c2.arena + L.xp.off, c2.arena + L.yp.goff, (float*)(c2.arena + L.np.state), c2.grads + L.cp.w,
-                                                c2.arena + L.xd.off, c2.arena + L.yd.goff, (float*)(c2.arena + L.nd.state), c2.grads + L.cd.w, 1, slab, Bc, Pc, Pc,
+                          : pwr_conv_wgrad_pair(c2.arena + L.xp.off, c2.arena + dyp, (float*)(c2.arena + L.np.state), c2.grads + L.cp.w,
+                                                c2.arena + L.xd.off, c2.arena + dyd, (float*)(c2.arena + L.nd.state), c2.grads + L.cd.w, 1, slab, Bc, Pc, Pc,
                                                 Fc, Fc, splits_pair, dt, c2.stream);
           if (r2 != PWR_EUNSUPPORTED) return r2;
           if (napply) {
@@ -1134,21 +1149,31 @@ struct Engine {
             // splits did it over and over: 124.5 us per layer in the step against 84.9 us for the plain form)
             char* na = c2.arena + E->scr_napply + c2.napply_off;
             r2 = pwr_norm_apply(c2.arena + L.xp.off, (float*)(c2.arena + L.np.state), na, 1, Bc, Pc * Pc, Fc, dt, c2.stream);
-            if (!r2) r2 = pwr_conv_wgrad(na, c2.arena + L.yp.goff, nullptr, 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
+            if (!r2) r2 = pwr_conv_wgrad(na, c2.arena + dyp, nullptr, 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
             if (!r2) r2 = pwr_norm_apply(c2.arena + L.xd.off, (float*)(c2.arena + L.nd.state), na, 1, Bc, Pc * Pc, Fc, dt, c2.stream);
-            if (!r2) r2 = pwr_conv_wgrad(na, c2.arena + L.yd.goff, nullptr, 1, slab, c2.grads + L.cd.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
+            if (!r2) r2 = pwr_conv_wgrad(na, c2.arena + dyd, nullptr, 1, slab, c2.grads + L.cd.w, 0, Bc, Pc, Pc, Fc, Fc, Fc, Fc, kk, 1, splits_pair, dt, c2.stream);
             return r2;
           }
-          r2 = pwr_conv_wgrad(c2.arena + L.xp.off, c2.arena + L.yp.goff, (float*)(c2.arena + L.np.state), 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
+          r2 = pwr_conv_wgrad(c2.arena + L.xp.off, c2.arena + dyp, (float*)(c2.arena + L.np.state), 1, slab, c2.grads + L.cp.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
                               Fc, kk, 1, splits_pair, dt, c2.stream);
           if (r2) return r2;
-          return pwr_conv_wgrad(c2.arena + L.xd.off, c2.arena + L.yd.goff, (float*)(c2.arena + L.nd.state), 1, slab, c2.grads + L.cd.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
+          return pwr_conv_wgrad(c2.arena + L.xd.off, c2.arena + dyd, (float*)(c2.arena + L.nd.state), 1, slab, c2.grads + L.cd.w, 0, Bc, Pc, Pc, Fc, Fc, Fc,
                                 Fc, kk, 1, splits_pair, dt, c2.stream);
-        });
+        }); };
+        int rc = fdg ? 0 : wgrads(c);        // (folded: dy does not exist before the data gradient below has run)
         if (rc) return rc;
         if (elim_mask() & 4) return 0;
         float* pa = (float*)(c.arena + (fold ? ownq : E->scr_cpartial));
         float* pb = (float*)(c.arena + (fold ? ownq : E->scr_cpartial) + half);
+        if (fdg) {
+          rc = pwr_conv_dgrad_fold_stats_pair(c.arena + L.yp.goff, c.packs + L.cp.pack_d, c.arena + L.xp.goff, c.arena + L.xp.off, (float*)(c.arena + L.np.state), pa,
+                                              c.arena + L.yp.off, (float*)(c.arena + nyp.state), (float*)(c.arena + own_above), c.arena + dyp,
+                                              c.arena + L.yd.goff, c.packs + L.cd.pack_d, c.arena + L.xd.goff, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb,
+                                              c.arena + L.yd.off, (float*)(c.arena + nyd.state), (float*)(c.arena + own_above + half), c.arena + dyd,
+                                              ch, 1, 1, Bc, Pc, Pc, Fc, Fc, kk, dt, c.stream);
+          if (rc) return rc;
+          return wgrads(c);
+        }
         rc = pwr_conv_dgrad_stats_pair(c.arena + L.yp.goff, c.packs + L.cp.pack_d, c.arena + L.xp.goff, c.arena + L.xp.off, (float*)(c.arena + L.np.state), pa,
                                        c.arena + L.yd.goff, c.packs + L.cd.pack_d, c.arena + L.xd.goff, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb,
                                        1, Bc, Pc, Pc, Fc, Fc, kk, dt, c.stream);
@@ -1159,7 +1184,11 @@ struct Engine {
         return pwr_conv_fwd_stats(c.arena + L.yd.goff, c.packs + L.cd.pack_d, nullptr, nullptr, 0, nullptr, c.arena + L.xd.goff, Bc, Pc, Pc, Fc, Fc, kk, 1, 0,
                                   nullptr, c.arena + L.xd.off, (float*)(c.arena + L.nd.state), pb, 1, dt, c.stream);
       });
-      norm_bwd_pair(L.xp, L.np, L.xd, L.nd, ch, half, ownq);
+      if (!fdg || q == 1) norm_bwd_pair(L.xp, L.np, L.xd, L.nd, ch, half, ownq);      // (h1 / n0: the first convs' data gradients are not the pair kernel)
+      else {
+        seg_norm_jobs.push_back(NormJob{ownq, false, L.np.gamma, L.np.beta, P * P, F, ch});
+        seg_norm_jobs.push_back(NormJob{ownq + half, false, L.nd.gamma, L.nd.beta, P * P, F, ch});
+      }
     }
     // (PWR_DEFER_FLUSH=1, debug build: release the held-back side work one op earlier, beside the two first-conv data gradients)
     if (defer_mode && PWR_DBG_ENV("PWR_DEFER_FLUSH", 0) == 1) bwd_cur.push_back(flush_deferred_op());

@@ -439,6 +439,25 @@ def conv_dgrad_stats_pair(dya, wa, nb_y_a, nb_state_a, dyb, wb, nb_y_b, nb_state
     return (xa, pa), (xb, pb), chunks
 
 
+def conv_dgrad_fold_stats_pair(ga, wa, nb_y_a, nb_state_a, fb_y_a, fb_state_a, fb_partial_a, gb, wb, nb_y_b, nb_state_b, fb_y_b, fb_state_b,
+                               fb_partial_b, fb_pchunks, cout, ksize, fb_relu=True, nb_relu=True):
+    """conv_dgrad_stats_pair on RAW gradients: the norm backward of (fb_y, fb_state) with the sums of fb_partial runs in the staging.
+    Returns (dxa, partial_a, dya), (dxb, partial_b, dyb), chunks -- dy* = what norm_bwd_fold would have written."""
+    l = _lib.lib()
+    B, H, W, Cin = ga.shape
+    chunks = l.pwr_conv_stats_chunks(H, W, Cin, cout, ksize, 1, 0, _dt(ga))
+    if chunks <= 0:
+        raise _lib.PwrError("conv shape does not support epilogue statistics")
+    xa, xb = (torch.empty(B, H, W, cout, dtype=ga.dtype, device=ga.device) for _ in range(2))
+    da, db = (torch.full((B, H, W, Cin), float("nan"), dtype=ga.dtype, device=ga.device) for _ in range(2))
+    pa, pb = (torch.full((B * chunks, 2, cout), float("nan"), dtype=torch.float32, device=ga.device) for _ in range(2))
+    _lib.check(l.pwr_conv_dgrad_fold_stats_pair(_p(ga), _p(wa), _p(xa), _p(nb_y_a), _p(nb_state_a), _p(pa), _p(fb_y_a), _p(fb_state_a), _p(fb_partial_a), _p(da),
+                                                _p(gb), _p(wb), _p(xb), _p(nb_y_b), _p(nb_state_b), _p(pb), _p(fb_y_b), _p(fb_state_b), _p(fb_partial_b), _p(db),
+                                                int(fb_pchunks), int(fb_relu), int(nb_relu), B, H, W, Cin, cout, ksize, _dt(ga), _s(ga)),
+               "pwr_conv_dgrad_fold_stats_pair")
+    return (xa, pa, da), (xb, pb, db), chunks
+
+
 def conv_wgrad_pair(xa, dya, xb, dyb, norm_a=None, norm_b=None, relu_in=True, splits=42):
     """Two 3x3 stride-1 weight gradients of one geometry in one launch + one reduce (pwr_conv_wgrad_pair).  Returns dwa, dwb."""
     l = _lib.lib()

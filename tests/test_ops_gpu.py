@@ -1042,6 +1042,34 @@ def test_conv_dgrad_pair_launch(B, H, W, Cin):
     assert torch.equal(pa, pa2) and torch.equal(pb, pb2)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 8, 32), (2, 16, 96)])
+def test_conv_dgrad_pair_with_the_norm_backward_folded_in(B, H, W):
+    """pwr_conv_dgrad_fold_stats_pair: two layers of the heads' backward chain.  Reference: data gradient of the layer above (raw g + slab) ->
+    pwr_norm_bwd_apply_from_partial (dy) -> pwr_conv_dgrad_stats_pair on dy.  Folded: the second launch reads the RAW g and the slab and
+    applies the norm backward in its staging -- data gradients, their slab rows and the dy it writes out equal the reference bit for bit
+    (image borders, several tiles per sample, more than one sample)."""
+    from pixelwiseregression_amd import kernels as K
+    C, bf = 128, torch.bfloat16
+    top = [nhwc(rnd(B, C, H, W, seed=61 + i), bf) for i in range(2)]                       # dy of the layer above (already folded)
+    w_up = [K.pack_conv(rnd(C, C, 3, 3, seed=63 + i, scale=(9 * C) ** -0.5).float().to(DEV), 1, K.BF16) for i in range(2)]
+    w_lo = [K.pack_conv(rnd(C, C, 3, 3, seed=65 + i, scale=(9 * C) ** -0.5).float().to(DEV), 1, K.BF16) for i in range(2)]
+    y_mid = [nhwc(rnd(B, C, H, W, seed=67 + i), bf) for i in range(2)]                     # pre-norm tensors between the two layers
+    y_low = [nhwc(rnd(B, C, H, W, seed=69 + i), bf) for i in range(2)]                     # ... and below the lower layer
+    st_mid = [K.norm_stats(y_mid[i], (1 + 0.2 * rnd(C, seed=71 + i)).float().to(DEV), (0.2 * rnd(C, seed=73 + i)).float().to(DEV)) for i in range(2)]
+    st_low = [K.norm_stats(y_low[i], (1 + 0.2 * rnd(C, seed=75 + i)).float().to(DEV), (0.2 * rnd(C, seed=77 + i)).float().to(DEV)) for i in range(2)]
+    (ga, pa), (gb, pb), chunks = K.conv_dgrad_stats_pair(top[0], w_up[0], y_mid[0], st_mid[0], top[1], w_up[1], y_mid[1], st_mid[1], C, 3)
+    dya = K.norm_bwd_fold(ga.clone(), y_mid[0], st_mid[0], pa, chunks)
+    dyb = K.norm_bwd_fold(gb.clone(), y_mid[1], st_mid[1], pb, chunks)
+    dya, dyb = (d[0] if isinstance(d, (tuple, list)) else d for d in (dya, dyb))
+    (xa, qa), (xb, qb), _ = K.conv_dgrad_stats_pair(dya, w_lo[0], y_low[0], st_low[0], dyb, w_lo[1], y_low[1], st_low[1], C, 3)
+    (xa2, qa2, da2), (xb2, qb2, db2), _ = K.conv_dgrad_fold_stats_pair(ga, w_lo[0], y_low[0], st_low[0], y_mid[0], st_mid[0], pa,
+                                                                      gb, w_lo[1], y_low[1], st_low[1], y_mid[1], st_mid[1], pb, chunks, C, 3)
+    assert float(xa.float().abs().max()) > 0 and not torch.isnan(da2.float()).any()
+    assert torch.equal(da2, dya) and torch.equal(db2, dyb)
+    assert torch.equal(xa2, xa) and torch.equal(xb2, xb)
+    assert torch.equal(qa2, qa) and torch.equal(qb2, qb)
+
+
 @pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 85), (5, 64, 64, 128, 128, 37), (3, 20, 96, 128, 128, 24), (2, 8, 32, 128, 256, 3), (2, 32, 32, 256, 128, 8),
                                   (32, 64, 64, 128, 128, 85), (2, 128, 128, 64, 128, 40), (3, 20, 96, 64, 128, 12), (5, 8, 32, 64, 256, 3)])
 @pytest.mark.parametrize("prologue", [False, True])
