@@ -40,7 +40,8 @@ err = (m.flat_grad() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-
 gathered = [torch.empty_like(m.flat_parameters()) for _ in range(world)]
 dist.all_gather(gathered, m.flat_parameters())
 same = all(torch.equal(gathered[0], g) for g in gathered)
-print("RESULT", rank, err, same, flush=True)
+# one file per rank: two processes' prints into one pipe can interleave inside a line (seen once in ~40 runs: one merged RESULT line)
+open(os.path.join(os.environ["DDP_TEST_OUT"], "result_%d.txt" % rank), "w").write("RESULT %d %r %s\n" % (rank, err, same))
 dist.destroy_process_group()
 """ % ROOT
 
@@ -48,11 +49,12 @@ dist.destroy_process_group()
 def test_ddp_two_ranks_one_gpu(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DDP_TEST_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29611", str(script)], capture_output=True, text=True, env=env, timeout=600)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-    assert len(lines) == 2, (r.stdout[-2000:], r.stderr[-2000:])
+    files = [tmp_path / ("result_%d.txt" % k) for k in range(2)]
+    assert all(f.exists() for f in files), (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [f.read_text().strip() for f in files]
     for l in lines:
         _, rank, err, same = l.split()
         assert float(err) < 1e-5, l
@@ -145,7 +147,7 @@ torch.cuda.synchronize()
 gathered = [torch.empty_like(m2.flat_parameters()) for _ in range(world)]
 dist.all_gather(gathered, m2.flat_parameters())
 same = all(torch.equal(gathered[0], t) for t in gathered)
-print("RESULT", rank, rel, same, flush=True)
+open(os.path.join(os.environ["DDP_TEST_OUT"], "result_%d.txt" % rank), "w").write("RESULT %d %r %s\n" % (rank, rel, same))      # (one file per rank: prints of two processes can interleave)
 dist.destroy_process_group()
 """ % ROOT
 
@@ -164,13 +166,14 @@ def test_rccl_two_ranks_gradient_equals_the_big_batch_gradient(tmp_path):
     parallelism dp2 and the RCCL fields."""
     script = tmp_path / "worker_rccl2.py"
     script.write_text(WORKER_RCCL2)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", DDP_TEST_OUT=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29655", str(script)], capture_output=True, text=True, env=env, timeout=1200)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-    assert len(lines) == 2, (r.stdout[-2000:], r.stderr[-3000:])
+    files = [tmp_path / ("result_%d.txt" % k) for k in range(2)]
+    assert all(f.exists() for f in files), (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [f.read_text().strip() for f in files]
     for l in lines:
         _, rank, rel, same = l.split()
         assert float(rel) < 1e-6, l
