@@ -41,7 +41,7 @@ gathered = [torch.empty_like(m.flat_parameters()) for _ in range(world)]
 dist.all_gather(gathered, m.flat_parameters())
 same = all(torch.equal(gathered[0], g) for g in gathered)
 # one file per rank: two processes' prints into one pipe can interleave inside a line (seen once in ~40 runs: one merged RESULT line)
-open(os.path.join(os.environ["DDP_TEST_OUT"], "result_%d.txt" % rank), "w").write("RESULT %d %r %s\n" % (rank, err, same))
+open(os.path.join(os.environ["DDP_TEST_OUT"], "result_%%d.txt" %% rank), "w").write("RESULT %%d %%r %%s\n" %% (rank, err, same))
 dist.destroy_process_group()
 """ % ROOT
 
@@ -147,7 +147,7 @@ torch.cuda.synchronize()
 gathered = [torch.empty_like(m2.flat_parameters()) for _ in range(world)]
 dist.all_gather(gathered, m2.flat_parameters())
 same = all(torch.equal(gathered[0], t) for t in gathered)
-open(os.path.join(os.environ["DDP_TEST_OUT"], "result_%d.txt" % rank), "w").write("RESULT %d %r %s\n" % (rank, rel, same))      # (one file per rank: prints of two processes can interleave)
+open(os.path.join(os.environ["DDP_TEST_OUT"], "result_%%d.txt" %% rank), "w").write("RESULT %%d %%r %%s\n" %% (rank, rel, same))      # (one file per rank: prints of two processes can interleave)
 dist.destroy_process_group()
 """ % ROOT
 
