@@ -3,6 +3,7 @@
 (``recover_uvd`` -> ``uvd2xyz`` -> mean over joints of the Euclidean distance, train.py:271-276,285).
 
     errs, losses = validate(model, batches, dataset="NYU")       # errs[s] = mean mm error of stage s over all samples
+    errs, losses = validate(model, batches, dataset="NYU", streams=2)      # the same numbers, two batches in flight (serving.py)
 
 ``batches`` is an iterable of dicts with the reference loader's fields (img, label_img, mask, box_size, cube_size, com,
 uvd[, heatmaps, depthmaps]); the dense loss terms are skipped when the dense targets are absent (alpha == 1 training).
@@ -10,21 +11,47 @@ uvd[, heatmaps, depthmaps]); the dense loss terms are skipped when the dense tar
 ``train_and_validate`` is the build's stand-in for "run train.py for a while": the reference's loop (train.py:158-212) on a
 stream of rendered synthetic hands (synthetic.make_pose_batch, a new seed per step), validated on held-out batches.
 """
+import collections
+
 import numpy as np
 import torch
 
 from .metric import INTRINSICS, recover_uvd, uvd2xyz, mean_joint_error
 
 
-def validate(model, batches, dataset="NYU", alpha=1.0, lambda_h=1.0, lambda_d=0.01):
+def _forwards(model, batches, streams):
+    """(batch, results) in the order of the batches; streams > 1: through serving.StreamedInference (the helper and its plans are kept on
+    the module between calls; its replicas get the module's current weights at every call), so that the host's metric arithmetic and
+    the .cpu() copies of one batch run beside the next batch's forward pass."""
+    if streams <= 1 or not next(model.parameters()).is_cuda:
+        for b in batches:
+            yield b, model(b["img"], b["label_img"], b["mask"])
+        return
+    from .serving import StreamedInference
+    srv = model.__dict__.get("_streamed")
+    if srv is None or len(srv.streams) != streams:
+        srv = StreamedInference(model, streams)
+        model.__dict__["_streamed"] = srv
+    else:
+        srv.refresh()
+    waiting = collections.deque()
+
+    def feed():
+        for b in batches:
+            waiting.append(b)
+            yield b["img"], b["label_img"], b["mask"]
+    for results in srv.run(feed()):
+        yield waiting.popleft(), results
+
+
+def validate(model, batches, dataset="NYU", alpha=1.0, lambda_h=1.0, lambda_d=0.01, streams=1):
     intr = INTRINSICS[dataset]
     was_training = model.training
     model.eval()
     per_stage, losses, num = None, None, 0
     with torch.no_grad():
-        for b in batches:
+        for b, results in _forwards(model, batches, streams):
             num += 1
-            results = model(b["img"], b["label_img"], b["mask"])
             if per_stage is None:
                 per_stage = [[] for _ in results]
                 losses = [[0.0, 0.0, 0.0] for _ in results]

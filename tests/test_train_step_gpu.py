@@ -152,3 +152,23 @@ def test_bf16_engine_learns_like_the_fp32_engine():
     # the training losses follow each other too: mean of the last 50 steps within 15 %
     l16, l32 = sum(r16["train_loss"][-50:]) / 50, sum(r32["train_loss"][-50:]) / 50
     assert abs(l16 - l32) < 0.15 * l32, (l16, l32)
+
+
+def test_validation_pass_with_two_batches_in_flight_gives_the_same_numbers():
+    """evaluate.validate(..., streams=2): the reference's validation pass (train.py:230-285) through serving.StreamedInference -- errors
+    and loss terms EQUAL to the plain loop's (same kernels, same order of the batches), on a second call after the weights moved too."""
+    from pixelwiseregression_amd import PixelwiseRegression
+    from pixelwiseregression_amd.evaluate import validate
+    from pixelwiseregression_amd.synthetic import make_pose_batch
+    torch.manual_seed(2)
+    m = PixelwiseRegression(14, stage=2, label_size=64, features=128, level=4, norm_method="instance").to(DEV).set_precision("bf16").train()
+    val = [make_pose_batch(8, 14, 128, seed=900 + i, device=DEV) for i in range(5)]
+    e1, l1 = validate(m, val, streams=1)
+    e2, l2 = validate(m, val, streams=2)
+    assert m.training and e1 == e2 and l1 == l2, (e1, e2, l1, l2)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.02)
+    e3, l3 = validate(m, val, streams=1)
+    e4, l4 = validate(m, val, streams=2)          # (the helper is reused: its replicas must have been refreshed)
+    assert e3 == e4 and l3 == l4 and e3 != e1
