@@ -33,7 +33,8 @@
 //     first MFMA.  The zero padding is folded into the ReLU: v_med3_f32(x, 0, keep), keep = +inf or 0.
 //   * The weights of taps 3 .. 7 are requested from INSIDE the first tile's first K loop, three taps ahead of their use (vmcnt counts in
 //     order: requested up front, the first wait for anything behind them is a wait for all 288 KiB).  They still bound the first tile:
-//     a CU gets ~26 B / clock out of its XCD's L2 while all 32 CUs of the XCD fetch the same 288 KiB (~11 k cycles however arranged).
+//     inside this kernel a CU gets ~26 B / clock of them while all 32 CUs of the XCD fetch the same 288 KiB (~11 k cycles in either arrangement;
+//     not the L2's limit: tools/probes/wload_probe.cpp loads them alone at 55 B / clock per CU, in any order).
 //   * KIND 3, the NARROW form (the heads' last conv, 128 -> J <= 32, fp32 NCHW out): the four waves hold the same 32 channels and split the
 //     tile's rows; the staging pipeline is two tiles deep there (the registers exist).  Staging-bound: 13 x 38 vector instructions per tile
 //     beside 72 MFMAs.
