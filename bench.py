@@ -453,18 +453,22 @@ def main():
         # the same loop with two batches in flight on two streams (serving.py: two plans of the same weights); reported BESIDE the figure above
         dt_inf2 = None
         if world == 1 and native:
-            from pixelwiseregression_amd.serving import StreamedInference
-            srv = StreamedInference(model, streams=2)
-            feed = lambda n: ((batch["img"], batch["label_img"], batch["mask"]) for _ in range(n))
-            for _ in srv.run(feed(6)):
-                pass
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in srv.run(feed(2 * n_inf)):
-                pass
-            torch.cuda.synchronize()
-            dt_inf2 = (time.perf_counter() - t1) / (2 * n_inf)
-            del srv
+            try:      # (an auxiliary figure: whatever goes wrong here must not cost the run its headline line)
+                from pixelwiseregression_amd.serving import StreamedInference
+                srv = StreamedInference(model, streams=2)
+                feed = lambda n: ((batch["img"], batch["label_img"], batch["mask"]) for _ in range(n))
+                for _ in srv.run(feed(6)):
+                    pass
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in srv.run(feed(2 * n_inf)):
+                    pass
+                torch.cuda.synchronize()
+                dt_inf2 = (time.perf_counter() - t1) / (2 * n_inf)
+                del srv
+            except Exception as e:      # noqa: BLE001
+                print("bench.py: two-stream inference figure skipped: %r" % (e,), file=sys.stderr)
+                dt_inf2 = None
 
     if rank == 0:
         out = {
