@@ -1,8 +1,12 @@
 """N train steps of the bench configuration (BASELINE C2, B = 32, bf16, AdamW) and nothing else -- no inference loop, no roofline probe, no
 vendor-GEMM yardstick in the same process: the program rocprofv3 wraps for the per-step kernel statistics (calls / N = launches per step).
-    python tools/train_steps.py [N=40]"""
+    python tools/train_steps.py [N=40] [--debug-lib]      (--debug-lib: the debug build, whose PWR_* switches are live)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--debug-lib" in sys.argv:
+    sys.argv.remove("--debug-lib")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dbglib  # noqa: F401
 import torch
 from pixelwiseregression_amd import PixelwiseRegression
 from pixelwiseregression_amd.synthetic import make_batch
