@@ -49,6 +49,58 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 
+// The same conv for 3x3, C0 = 32 (4 chunks of 8 bf16 channels), S % 128 == 0 (round 6): a workgroup owns 4 rows x 128 columns.  The 6 x 130
+// image window goes to LDS once (zero padding included), a thread keeps the 72 weights + 8 biases of ITS channel chunk in registers and
+// walks 8 pixels (pass i: pixel 64 i + tid / 4 of the tile), so that a store instruction of a wave writes 16 consecutive pixels = 1 KiB.
+// Per output vector: 9 LDS reads + 72 FMAs against 72 LDS reads + 72 FMAs + 9 bounds-checked global loads + 64-bit index arithmetic
+// above.  Same FMA order per channel (taps ascending, then the bias): same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_tile_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ y, int B, int S) {
+  constexpr int EP = Elem<T>::kPer16B, C0 = 32, CPP = C0 / EP, PPW = 256 / CPP, TW = 128, TH = 4, LW = TW + 2;
+  typedef typename Vec16<T>::type V;
+  __shared__ float simg[(TH + 2) * LW];
+  __shared__ float sw[C0 * 9 + C0];
+  const int tid = threadIdx.x;
+  const int tiles_x = S / TW, tiles_y = S / TH;
+  const int t = blockIdx.x, b = t / (tiles_x * tiles_y), tr = t - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+  for (int i = tid; i < C0 * 9; i += 256) sw[i] = w[i];
+  if (tid < C0) sw[C0 * 9 + tid] = bias[tid];
+  for (int i = tid; i < (TH + 2) * LW; i += 256) {
+    const int r = i / LW, c = i - r * LW;
+    const int iy = y0 + r - 1, ix = x0 + c - 1;
+    simg[i] = (iy >= 0 && iy < S && ix >= 0 && ix < S) ? img[((size_t)b * S + iy) * S + ix] : 0.f;
+  }
+  __syncthreads();
+  const int cq = tid % CPP, pl = tid / CPP;
+  float wr[EP][9], br[EP];
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[e][k] = sw[(cq * EP + e) * 9 + k];
+    br[e] = sw[C0 * 9 + cq * EP + e];
+  }
+#pragma unroll
+  for (int i = 0; i < TW * TH / PPW; ++i) {
+    const int p = i * PPW + pl, py = p / TW, px = p - py * TW;
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) in[ky * 3 + kx] = simg[(py + ky) * LW + px + kx];
+    V o;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a = fmaf(in[k], wr[e][k], a);
+      o[e] = Elem<T>::from_f(a + br[e]);
+    }
+    *reinterpret_cast<V*>(y + (((size_t)b * S + y0 + py) * S + x0 + px) * C0 + cq * EP) = o;
+  }
+}
+
 // dW[c][tap] partials: slab[block][c*taps + tap].  A thread owns one 16-byte channel slot of dy for every PLN-th pixel of the
 // block's pixel range (coalesced 16-byte loads, coordinates stepped incrementally: no divisions in the loop); the 3x3 (k x k)
 // image neighbourhood is loaded once per pixel and shared by the slot's channels.  Pixel lanes are combined with wave shuffles,
@@ -309,6 +361,11 @@ extern "C" int pwr_stem_conv_fwd(const float* img, const float* w, const float* 
   const long long total = (long long)B * S * S * (C0 / EP);
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   const size_t sh = (size_t)(C0 * ksize * ksize + C0) * 4;
+  static const bool tile_on = PWR_DBG_ENV("PWR_STEM_TILE", 1) != 0;
+  if (tile_on && dtype == PWR_BF16 && ksize == 3 && C0 == 32 && S % 128 == 0) {
+    hipLaunchKernelGGL((stem_fwd_tile_kernel<bf16_t>), dim3(B * (S / 128) * (S / 4)), dim3(256), 0, (hipStream_t)stream, img, w, bias, (bf16_t*)y, B, S);
+    return (int)hipGetLastError();
+  }
 #define PWR_STEM_F(KS_) \
   if (dtype == PWR_BF16) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, KS_>), dim3(grid), dim3(256), sh, (hipStream_t)stream, img, w, bias, (bf16_t*)y, B, S, C0); \
   else hipLaunchKernelGGL((stem_fwd_kernel<float, KS_>), dim3(grid), dim3(256), sh, (hipStream_t)stream, img, w, bias, (float*)y, B, S, C0)
